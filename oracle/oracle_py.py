@@ -1,0 +1,272 @@
+"""ctypes binding of the CPU oracle (oracle/librs_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (radiosaber_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "librs_oracle.so"
+REF_DIR = HERE / "_ref"
+
+SCHED_PF, SCHED_NVS, SCHED_SEQUENTIAL, SCHED_MAXCELL, SCHED_VOGEL = 1, 7, 8, 9, 103
+
+
+def build(quiet=True):
+    """(Re)build the oracle (and oracle/_ref when /root/reference is present)."""
+    subprocess.run(["make", "-C", str(HERE)], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None,
+                   stderr=subprocess.DEVNULL if quiet else None)
+
+
+class _Config(C.Structure):
+    _fields_ = [("n_slices", C.c_int), ("n_users", C.c_int), ("n_rbgs", C.c_int),
+                ("rbg_size", C.c_int), ("sched", C.c_int),
+                ("weights", C.POINTER(C.c_double)), ("alpha", C.POINTER(C.c_int)),
+                ("beta", C.POINTER(C.c_int)), ("epsilon", C.POINTER(C.c_int)),
+                ("psi", C.POINTER(C.c_int)), ("user_to_slice", C.POINTER(C.c_int))]
+
+
+class _TtiOut(C.Structure):
+    _fields_ = [("target_rbs", C.POINTER(C.c_int)), ("quota_rbgs", C.POINTER(C.c_int)),
+                ("rbg_to_user", C.POINTER(C.c_int)), ("user_nprb", C.POINTER(C.c_int)),
+                ("user_final_cqi", C.POINTER(C.c_int)), ("user_mcs", C.POINTER(C.c_int)),
+                ("user_tbs_bits", C.POINTER(C.c_int)), ("served_slice", C.c_int)]
+
+
+class _TraceRun(C.Structure):
+    _fields_ = [("trace", C.POINTER(C.c_uint8)), ("n_traces", C.c_int), ("n_rows", C.c_int),
+                ("mapping", C.POINTER(C.c_int)), ("n_map", C.c_int), ("row_modulus", C.c_int),
+                ("seed", C.c_uint), ("rand_skip", C.c_long), ("phy_error_draws", C.c_int),
+                ("first_tti", C.c_int), ("n_ttis", C.c_int)]
+
+
+class _Rng(C.Structure):
+    _fields_ = [("r", C.c_int32 * 34), ("f", C.c_int), ("b", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB.exists():
+            build()
+        L = C.CDLL(str(LIB))
+        L.rso_tbs_table.restype = C.POINTER(C.c_int)
+        L.rso_mcs_to_itbs.restype = C.POINTER(C.c_int)
+        L.rso_cqi_to_mcs.restype = C.POINTER(C.c_int)
+        L.rso_sinr_for_cqi.restype = C.POINTER(C.c_double)
+        L.rso_efficiency_from_cqi.restype = C.c_double
+        L.rso_efficiency_from_cqi.argtypes = [C.c_int]
+        L.rso_cqi_from_sinr.argtypes = [C.c_double]
+        L.rso_tbs_bits.argtypes = [C.c_int, C.c_int]
+        L.rso_eesm_effective_sinr.restype = C.c_double
+        L.rso_eesm_effective_sinr.argtypes = [C.POINTER(C.c_double), C.c_int]
+        L.rso_final_cqi.argtypes = [C.POINTER(C.c_uint8), C.c_int]
+        L.rso_cell_create.restype = C.c_void_p
+        L.rso_cell_create.argtypes = [C.POINTER(_Config)]
+        L.rso_cell_destroy.argtypes = [C.c_void_p]
+        L.rso_cell_set_cqi.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        L.rso_cell_set_last_update.argtypes = [C.c_void_p, C.c_double]
+        L.rso_cell_set_avg_rate.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.rso_cell_step.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(_TtiOut)]
+        L.rso_cell_allocate.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(_TtiOut)]
+        L.rso_cell_get_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+        L.rso_run_trace.argtypes = [C.c_void_p, C.POINTER(_TraceRun)] + [C.POINTER(C.c_int)] * 5
+        L.rso_run_synth.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_uint,
+                                    C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.rso_srand.argtypes = [C.POINTER(_Rng), C.c_uint]
+        L.rso_rand.argtypes = [C.POINTER(_Rng)]
+        for fn in ("rso_greedy_by_row", "rso_maximize_cell", "rso_vogel"):
+            getattr(L, fn).argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.c_int,
+                                       C.POINTER(C.c_int)]
+        L.rso_maximize_cell_order.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _optp(a, t):
+    return _p(a, t) if a is not None else None
+
+
+def tables():
+    L = lib()
+    return {
+        "tbs": np.ctypeslib.as_array(L.rso_tbs_table(), (110, 27)).copy(),
+        "mcs_to_itbs": np.ctypeslib.as_array(L.rso_mcs_to_itbs(), (29,)).copy(),
+        "cqi_to_mcs": np.ctypeslib.as_array(L.rso_cqi_to_mcs(), (15,)).copy(),
+        "sinr_for_cqi": np.ctypeslib.as_array(L.rso_sinr_for_cqi(), (15,)).copy(),
+    }
+
+
+def eesm(sinr_db):
+    a = np.ascontiguousarray(sinr_db, np.float64)
+    return lib().rso_eesm_effective_sinr(_p(a, C.c_double), len(a))
+
+
+def final_cqi(cqi_per_prb):
+    a = np.ascontiguousarray(cqi_per_prb, np.uint8)
+    return lib().rso_final_cqi(_p(a, C.c_uint8), len(a))
+
+
+class Rng:
+    """glibc TYPE_3 rand() restatement."""
+
+    def __init__(self, seed):
+        self.g = _Rng()
+        lib().rso_srand(C.byref(self.g), seed)
+
+    def rand(self):
+        return lib().rso_rand(C.byref(self.g))
+
+
+def interslice(fn, eff, quota):
+    """fn in {'greedy_by_row','maximize_cell','vogel'}; eff [R][S] float64 -> rbg_to_slice [R]."""
+    eff = np.ascontiguousarray(eff, np.float64)
+    R, S = eff.shape
+    q = np.ascontiguousarray(quota, np.int32)
+    out = np.empty(R, np.int32)
+    getattr(lib(), "rso_" + fn)(_p(eff, C.c_double), _p(q, C.c_int), R, S, _p(out, C.c_int))
+    return out
+
+
+def maximize_cell_order(eff):
+    eff = np.ascontiguousarray(eff, np.float64)
+    R, S = eff.shape
+    out = np.empty(R * S, np.int32)
+    lib().rso_maximize_cell_order(_p(eff, C.c_double), R, S, _p(out, C.c_int))
+    return out
+
+
+class TtiOut:
+    def __init__(self, S, U, R):
+        self.target_rbs = np.zeros(S, np.int32)
+        self.quota_rbgs = np.zeros(S, np.int32)
+        self.rbg_to_user = np.zeros(R, np.int32)
+        self.user_nprb = np.zeros(U, np.int32)
+        self.user_final_cqi = np.zeros(U, np.int32)
+        self.user_mcs = np.zeros(U, np.int32)
+        self.user_tbs_bits = np.zeros(U, np.int32)
+        self.c = _TtiOut(_p(self.target_rbs, C.c_int), _p(self.quota_rbgs, C.c_int),
+                         _p(self.rbg_to_user, C.c_int), _p(self.user_nprb, C.c_int),
+                         _p(self.user_final_cqi, C.c_int), _p(self.user_mcs, C.c_int),
+                         _p(self.user_tbs_bits, C.c_int), -1)
+
+    @property
+    def served_slice(self):
+        return self.c.served_slice
+
+
+class Cell:
+    """One cell of the oracle.  ues_per_slice: list[int]; weights/eps/psi per slice."""
+
+    def __init__(self, ues_per_slice, n_rbgs, rbg_size, sched, weights=None, epsilon=None, psi=None,
+                 alpha=None, beta=None):
+        S = len(ues_per_slice)
+        self.S, self.R, self.rbg_size, self.sched = S, n_rbgs, rbg_size, sched
+        self.u2s = np.repeat(np.arange(S, dtype=np.int32), ues_per_slice).astype(np.int32)
+        self.U = len(self.u2s)
+        self.weights = np.ascontiguousarray(weights if weights is not None else np.full(S, 1.0 / S), np.float64)
+        self.eps = np.ascontiguousarray(epsilon if epsilon is not None else np.ones(S), np.int32)
+        self.psi = np.ascontiguousarray(psi if psi is not None else np.ones(S), np.int32)
+        self.alpha = np.ascontiguousarray(alpha if alpha is not None else np.zeros(S), np.int32)
+        self.beta = np.ascontiguousarray(beta if beta is not None else np.zeros(S), np.int32)
+        cfg = _Config(S, self.U, n_rbgs, rbg_size, sched, _p(self.weights, C.c_double),
+                      _p(self.alpha, C.c_int), _p(self.beta, C.c_int), _p(self.eps, C.c_int),
+                      _p(self.psi, C.c_int), _p(self.u2s, C.c_int))
+        self.h = lib().rso_cell_create(C.byref(cfg))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().rso_cell_destroy(self.h)
+            self.h = None
+
+    def new_out(self):
+        return TtiOut(self.S, self.U, self.R)
+
+    def set_cqi(self, cqi):
+        a = np.ascontiguousarray(cqi, np.uint8)
+        assert a.shape == (self.U, self.R)
+        lib().rso_cell_set_cqi(self.h, _p(a, C.c_uint8))
+
+    def set_avg_rate(self, avg):
+        a = np.ascontiguousarray(avg, np.float64)
+        lib().rso_cell_set_avg_rate(self.h, _p(a, C.c_double))
+
+    def set_last_update(self, t):
+        lib().rso_cell_set_last_update(self.h, t)
+
+    def step(self, now, rand0, rand1, out):
+        return lib().rso_cell_step(self.h, now, rand0, rand1, C.byref(out.c))
+
+    def allocate(self, avg_rate, rand0, rand1, out):
+        a = np.ascontiguousarray(avg_rate, np.float64)
+        return lib().rso_cell_allocate(self.h, _p(a, C.c_double), rand0, rand1, C.byref(out.c))
+
+    def state(self):
+        avg = np.zeros(self.U, np.float64)
+        cb = np.zeros(self.U, np.int64)
+        cr = np.zeros(self.U, np.int64)
+        sl = np.zeros(self.S, np.float64)
+        lib().rso_cell_get_state(self.h, _p(avg, C.c_double), _p(cb, C.c_int64), _p(cr, C.c_int64),
+                                 _p(sl, C.c_double))
+        return {"avg_rate": avg, "cum_bytes": cb, "cum_rbs": cr, "slice_state": sl}
+
+    def run_trace(self, trace, mapping, seed, rand_skip, n_ttis, phy_error_draws=1, first_tti=100,
+                  row_modulus=475, log=True):
+        trace = np.ascontiguousarray(trace, np.uint8)
+        mapping = np.ascontiguousarray(mapping, np.int32)
+        n_tr, n_rows, R = trace.shape
+        assert R == self.R
+        run = _TraceRun(_p(trace, C.c_uint8), n_tr, n_rows, _p(mapping, C.c_int), len(mapping),
+                        row_modulus, seed, rand_skip, phy_error_draws, first_tti, n_ttis)
+        logs = None
+        if log:
+            logs = {"rbg_to_user": np.zeros((n_ttis, self.R), np.int32),
+                    "final_cqi": np.zeros((n_ttis, self.U), np.int32),
+                    "quota": np.zeros((n_ttis, self.S), np.int32),
+                    "target": np.zeros((n_ttis, self.S), np.int32),
+                    "tbs_bits": np.zeros((n_ttis, self.U), np.int32)}
+        rc = lib().rso_run_trace(self.h, C.byref(run),
+                                 _optp(logs and logs["rbg_to_user"], C.c_int),
+                                 _optp(logs and logs["final_cqi"], C.c_int),
+                                 _optp(logs and logs["quota"], C.c_int),
+                                 _optp(logs and logs["target"], C.c_int),
+                                 _optp(logs and logs["tbs_bits"], C.c_int))
+        if rc:
+            raise RuntimeError(f"rso_run_trace rc={rc}")
+        return logs
+
+    def run_synth(self, cqi_epochs, seed, n_ttis, refresh=40, phy_error_draws=0, log=True):
+        e = np.ascontiguousarray(cqi_epochs, np.uint8)
+        assert e.shape[1:] == (self.U, self.R)
+        logs = None
+        if log:
+            logs = {"rbg_to_user": np.zeros((n_ttis, self.R), np.int32),
+                    "tbs_bits": np.zeros((n_ttis, self.U), np.int32)}
+        rc = lib().rso_run_synth(self.h, _p(e, C.c_uint8), e.shape[0], refresh, seed, phy_error_draws,
+                                 n_ttis, _optp(logs and logs["rbg_to_user"], C.c_int),
+                                 _optp(logs and logs["tbs_bits"], C.c_int))
+        if rc:
+            raise RuntimeError(f"rso_run_synth rc={rc}")
+        return logs
+
+
+def ref_lib(name):
+    """Load a prebuilt reference piece from oracle/_ref (None if absent)."""
+    p = REF_DIR / name
+    if not p.exists():
+        return None
+    return C.CDLL(str(p))
