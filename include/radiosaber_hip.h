@@ -1,0 +1,206 @@
+/*
+ * radiosaber_hip.h -- C ABI of the MI355X-native RadioSaber downlink RBG allocation path.
+ *
+ * Plain C, caller-owned flat buffers, int status returns, no exceptions, no torch types.
+ * One context per host thread / HIP stream.  Implemented by libradiosaber_hip.so
+ * (radiosaber_amd/csrc/, hand-written HIP for gfx950; there is NO CPU fallback: every entry point
+ * that computes returns RS_ERR_NO_DEVICE / RS_ERR_HIP when no MI355X is usable).
+ *
+ * The reference (elvinlife/RadioSaber, an LTE-Sim fork) has no C ABI or plug-in loader: its
+ * boundary is the C++ virtual seam
+ *     PacketScheduler::Schedule() -> virtual DoSchedule() -> virtual RBsAllocation()
+ *     (src/protocolStack/mac/packet-scheduler/packet-scheduler.cpp:72-90, packet-scheduler.h:133-137)
+ * installed by ENodeB::SetDLScheduler (src/device/ENodeB.cpp:303-391).  Each entry point below
+ * names the reference function(s) it replaces; INTEGRATION.md shows the C++ adapter class a
+ * maintainer adds to the LTE-Sim tree to call them.  `ref:` paths are relative to the reference's
+ * src/protocolStack/mac/packet-scheduler/ unless they start with src/.
+ */
+#ifndef RADIOSABER_HIP_H_
+#define RADIOSABER_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_ABI_VERSION 1
+
+/* status codes */
+enum {
+  RS_OK = 0,
+  RS_ERR_INVALID = -1,    /* bad argument / unsupported configuration (message: rs_last_error) */
+  RS_ERR_NO_DEVICE = -2,  /* no usable HIP device */
+  RS_ERR_HIP = -3,        /* a HIP runtime call failed */
+  RS_ERR_STATE = -4,      /* call order (e.g. run before a CQI source is set) */
+  RS_ERR_RANGE = -5       /* device-side check failed (trace row out of range, ...) */
+};
+
+/* scheduler selection, numbered like the reference CLI `sched` argument
+ * (ref: src/scenarios/single-cell-with-interference.h:94-123, src/device/ENodeB.h:66-81) */
+enum {
+  RS_SCHED_PF = 1,         /* DL_PF_PacketScheduler -> DownlinkPacketScheduler::RBsAllocation
+                              (ref: downlink-packet-scheduler.cpp:179-331, dl-pf-packet-scheduler.cpp:128-140) */
+  RS_SCHED_NVS = 7,        /* DownlinkNVSScheduler (ref: downlink-nvs-scheduler.cpp:94-142,275-358) */
+  RS_SCHED_SEQUENTIAL = 8, /* DownlinkTransportScheduler + GreedyByRow (ref: downlink-transport-scheduler.cpp:249-272) */
+  RS_SCHED_MAXCELL = 9     /* DownlinkTransportScheduler + MaximizeCell = RadioSaber (ref: :351-376) */
+};
+
+#define RS_MAX_SLICES 64
+#define RS_MAX_RBGS 64
+#define RS_MAX_USERS 1024
+
+/* What the reference scheduler constructors parse out of the JSON config
+ * (ref: downlink-transport-scheduler.cpp:55-97, downlink-nvs-scheduler.cpp:44-86,
+ *  dl-pf-packet-scheduler.cpp:40-58) plus the cell's PRB grid
+ * (ref: RBsAllocation :457-461 nb_rbs/rbg_size; src/utility/eesm-effective-sinr.h:82-103). */
+typedef struct rs_config {
+  int32_t n_slices;             /* S = ues_per_slice.size()                      (1..64)   */
+  int32_t n_users;              /* U = sum(ues_per_slice); user ids are 0..U-1   (1..1024) */
+  int32_t n_rbgs;               /* R = nb_rbs / rbg_size                         (1..64)   */
+  int32_t rbg_size;             /* PRBs per RBG = get_rbg_size(nb_rbs)           (1..8)    */
+  int32_t sched;                /* RS_SCHED_*                                               */
+  int32_t device;               /* HIP device ordinal                                       */
+  const double* slice_weight;   /* [S] "weight"                                             */
+  const int32_t* algo_alpha;    /* [S] must be 0 (backlogged PF family; alpha=1 is SURVEY 8f N3) */
+  const int32_t* algo_beta;     /* [S] unused while alpha == 0                              */
+  const int32_t* algo_epsilon;  /* [S] 0 or 1 (pow(x,0)=1, pow(x,1)=x are exact)            */
+  const int32_t* algo_psi;      /* [S] 0 or 1                                               */
+  const int32_t* user_to_slice; /* [U] non-decreasing (run-length expansion of ues_per_slice) */
+  void* stream;                 /* hipStream_t to launch on, NULL = a stream owned by the context */
+} rs_config;
+
+const char* rs_last_error(void);   /* thread-local message of the last failing call */
+int rs_abi_version(void);
+int rs_device_count(void);         /* number of HIP devices (0 when none)           */
+
+/* Link-adaptation constants the device uses, computed by the HOST libm exactly as the reference
+ * evaluates them (ref: src/utility/eesm-effective-sinr.h:33-46, src/protocolStack/mac/AMCModule.cpp:253-261,320-327):
+ *   eff[c]  = (TBS(1 PRB, mcs(c)) / 0.001) / 180000.            c = 1..15  (eff[0] = 0)
+ *   kbps[c] = eff[c] * 180000 / 1000
+ *   E[c]    = exp(-pow(10, SINRForCQIIndex[c-1] / 10))
+ *   X[k]    = max{ x : 10*log10(-1*log(x)) >= SINRForCQIIndex[k] }   k = 1..13
+ * final CQI of an allocation = 1 + #{k : x <= X[k]}, x = (sum of E over its PRBs) / nPRB; x == 0 -> 15.
+ * Needs no GPU.  Returns RS_ERR_INVALID if the host libm is not monotone around a threshold. */
+int rs_link_tables(double eff[16], double kbps[16], double eesm_e[16], double eesm_x[16]);
+
+/* ------------------------------------------------------------------------------------------
+ * Drop-in mode: one RBsAllocation() call.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rs_ctx rs_ctx;
+
+/* replaces the scheduler constructor + ENodeB::SetDLScheduler (ref: src/device/ENodeB.cpp:303-391) */
+rs_ctx* rs_create(const rs_config* cfg);
+void rs_destroy(rs_ctx* ctx);
+
+/* What RBsAllocation() sees on entry (ref: GetUsersToSchedule(): packet-scheduler.h:88-123):
+ * the users with queued data, in first-seen (= ascending user id) order. */
+typedef struct rs_tti_in {
+  int32_t n_users;          /* users to schedule this TTI (<= cfg.n_users)                          */
+  const int32_t* user_id;   /* [n] ascending user ids; NULL = 0..n-1                                */
+  const uint8_t* cqi;       /* [n][R] CQI (1..15) of PRB rbg*rbg_size = GetCqiFeedbacks().at(rbg*rbg_size);
+                               the whole RBG carries that CQI (true for every shipped trace)        */
+  const double* avg_rate;   /* [n] sum over the user's bearers of GetAverageTransmissionRate()      */
+  int32_t rand0, rand1;     /* the two rand() values RBsAllocation draws (ref: :490, :511);
+                               ignored by RS_SCHED_PF / RS_SCHED_NVS                                */
+} rs_tti_in;
+
+/* What RBsAllocation() leaves behind (ref: :589-620 allocation lists + slice_rbs_offset_,
+ * :630-674 UpdateAllocatedBits / PDCCH records). All arrays caller-allocated. */
+typedef struct rs_tti_out {
+  int32_t* target_rbs;      /* [S] slice_target_rbs   (0 for PF/NVS)                      */
+  int32_t* quota_rbgs;      /* [S] slice_quota_rbgs   (0 for PF/NVS)                      */
+  int32_t* rbg_to_user;     /* [R] user id owning RBG r (its PRBs r*rbg_size..+rbg_size-1), -1 = none */
+  int32_t* user_nprb;       /* [n] GetListOfAllocatedRBs()->size()                        */
+  int32_t* user_final_cqi;  /* [n] GetCQIFromSinr(GetEesmEffectiveSinr(..)), 0 = not scheduled */
+  int32_t* user_mcs;        /* [n] mcs of the PDCCH records                               */
+  int32_t* user_tbs_bits;   /* [n] UpdateAllocatedBits() argument                         */
+} rs_tti_out;
+
+/* replaces DownlinkTransportScheduler::RBsAllocation (ref: downlink-transport-scheduler.cpp:453-675),
+ * DownlinkPacketScheduler::RBsAllocation (ref: downlink-packet-scheduler.cpp:179-331) and
+ * DownlinkNVSScheduler::RBsAllocation (ref: downlink-nvs-scheduler.cpp:275-358; pass the users of the
+ * slice SelectSliceToServe chose).  The context carries slice_rbs_offset_ between calls. */
+int rs_schedule_tti(rs_ctx* ctx, const rs_tti_in* in, rs_tti_out* out);
+/* slice_rbs_offset_ accessors (ref: downlink-transport-scheduler.h:38) */
+int rs_get_slice_offset(rs_ctx* ctx, double* offset /* [S] */);
+int rs_set_slice_offset(rs_ctx* ctx, const double* offset /* [S] */);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched mode: many independent cells resident on the device, whole DoSchedule() loops
+ * (EWMA update -> RBsAllocation -> DoStopSchedule accounting) run in one launch.
+ * Replaces, per cell and per TTI: RadioBearer::UpdateAverageTransmissionRate
+ * (ref: src/flows/radio-bearer.cpp:139-164), SelectSliceToServe (NVS), RBsAllocation,
+ * DoStopSchedule's counters (ref: downlink-transport-scheduler.cpp:170-221), the CQI refresh
+ * (ref: src/protocolStack/mac/enb-mac-entity.cc:160-193, src/device/CqiManager/cqi-manager.cpp:94-123)
+ * and the simulator clock t_k = fl(t_{k-1} + 0.001) (ref: src/core/eventScheduler/simulator.cc:117-126).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rs_batch rs_batch;
+
+typedef struct rs_batch_config {
+  rs_config cell;            /* every cell of the batch shares this configuration              */
+  int32_t n_cells;
+  int32_t first_tti;         /* TTI index of the first scheduled TTI (reference: 100 = 0.1 s)   */
+  int32_t cqi_refresh;       /* synthetic/epoch source: new grid every this many TTIs (40)      */
+  int32_t phy_error_draws;   /* 1: consume one rand() per UE served in the previous TTI, as the
+                                reference's PHY error model does on the shared libc stream
+                                (ref: src/phy/wideband-cqi-eesm-error-model.cpp:69)              */
+  int32_t threads_per_cell;  /* workgroup size, multiple of 64 in [64,1024]; 0 = default        */
+} rs_batch_config;
+
+rs_batch* rs_batch_create(const rs_batch_config* cfg);
+void rs_batch_destroy(rs_batch* b);
+
+/* per-cell libc-compatible rand() streams: srand(seed[c]) then rand_skip[c] values discarded
+ * (ref: src/scenarios/single-cell-with-interference.h:84-89, src/utility/seed.h:25-35) */
+int rs_batch_seed(rs_batch* b, const uint32_t* seed /* [n_cells] */, const int64_t* rand_skip /* [n_cells] or NULL */);
+
+/* CQI source A: explicit grids. h_cqi = [n_cells][n_epochs][U][R] (host); epoch e serves scheduled
+ * TTIs [e*cqi_refresh, (e+1)*cqi_refresh).  Copied to HBM once. */
+int rs_batch_upload_cqi_epochs(rs_batch* b, const uint8_t* h_cqi, int32_t n_epochs);
+/* CQI source B: i.i.d. grids drawn on the device from a CQI histogram (weights of CQI 1..15),
+ * counter-based generator keyed by (seed, cell, epoch, user, rbg).  Stays in HBM. */
+int rs_batch_synthesize_cqi(rs_batch* b, uint64_t seed, const double* cqi_weights /* [15] */, int32_t n_epochs);
+/* read back the grids of one cell (either source) for the parity tests: [n_epochs][U][R] */
+int rs_batch_download_cqi_epochs(rs_batch* b, int32_t cell, uint8_t* h_cqi);
+/* CQI source C: the reference's trace replay.  h_trace = [n_traces][n_rows][R]; user u of cell c
+ * replays trace h_user_trace[c*U+u]; refresh rule and row index exactly as
+ * cqi-manager.cpp:105-123 / enb-mac-entity.cc:189-191 ((int)(Now*1000/40) % row_modulus). */
+int rs_batch_set_trace(rs_batch* b, const uint8_t* h_trace, int32_t n_traces, int32_t n_rows,
+                       int32_t row_modulus, const int32_t* h_user_trace /* [n_cells][U] */);
+
+/* run n_ttis scheduled TTIs of every cell in ONE kernel launch on the batch's stream and wait */
+int rs_batch_run(rs_batch* b, int32_t n_ttis);
+/* same, not waiting (for overlap and hipEvent timing by the caller) */
+int rs_batch_run_async(rs_batch* b, int32_t n_ttis);
+int rs_batch_sync(rs_batch* b);
+/* same as rs_batch_run, also returning the per-TTI decisions of every cell (parity tests):
+ * h_rbg_to_user [n_cells][n_ttis][R] (int16, -1 = none), h_tbs_bits [n_cells][n_ttis][U] (int32),
+ * h_quota [n_cells][n_ttis][S] (int16); any may be NULL */
+int rs_batch_run_logged(rs_batch* b, int32_t n_ttis, int16_t* h_rbg_to_user, int32_t* h_tbs_bits,
+                        int16_t* h_quota);
+/* `launches` back-to-back launches of n_ttis each, timed with HIP events on the batch's stream;
+ * ms_per_launch[launches] receives each launch's duration */
+int rs_batch_run_timed(rs_batch* b, int32_t n_ttis, int32_t launches, float* ms_per_launch);
+
+/* per-bearer state after the runs so far; any pointer may be NULL.
+ * avg_rate [n_cells][U], cum_bytes/cum_rbs [n_cells][U] (RadioBearer::GetCumulateBytes/RBs),
+ * slice_state [n_cells][S] (slice_rbs_offset_, or slice_ewma_time_ for NVS) */
+int rs_batch_read_state(rs_batch* b, double* avg_rate, int64_t* cum_bytes, int64_t* cum_rbs,
+                        double* slice_state);
+/* per-slice cumulative bytes summed over the batch's cells, reduced on the device into
+ * d_out[S] (device pointer, uint64) on the batch's stream -- the vector the multi-GPU run
+ * all-reduces over RCCL (the reference's plot_throughput.py:26-56 sums it per slice post hoc) */
+int rs_batch_slice_bytes_device(rs_batch* b, uint64_t* d_out);
+int rs_batch_slice_bytes(rs_batch* b, uint64_t* h_out /* [S] */);
+/* scheduled TTIs completed per cell so far */
+int64_t rs_batch_ttis_done(rs_batch* b);
+/* the hipStream_t the batch launches on */
+void* rs_batch_stream(rs_batch* b);
+/* name of the dominant kernel (for matching rocprofv3 --kernel-trace rows) */
+const char* rs_batch_kernel_name(rs_batch* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADIOSABER_HIP_H_ */

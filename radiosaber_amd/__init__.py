@@ -1,0 +1,15 @@
+"""radiosaber_amd -- MI355X-native RadioSaber downlink RBG allocation path.
+
+Thin ctypes mirror of the C ABI in include/radiosaber_hip.h (libradiosaber_hip.so, hand-written
+HIP for gfx950).  There is no CPU fallback: creating a scheduler without a HIP device, or without the
+built library, raises.
+"""
+from .api import (  # noqa: F401
+    RS_SCHED_MAXCELL, RS_SCHED_NVS, RS_SCHED_PF, RS_SCHED_SEQUENTIAL, TRACE_CQI_HISTOGRAM,
+    BatchScheduler, RadioSaberError, SliceConfig, TtiResult, TtiScheduler, device_count, lib,
+    link_tables,
+)
+
+__all__ = ["RS_SCHED_PF", "RS_SCHED_NVS", "RS_SCHED_SEQUENTIAL", "RS_SCHED_MAXCELL", "SliceConfig",
+           "TtiScheduler", "TtiResult", "BatchScheduler", "RadioSaberError", "device_count", "lib",
+           "link_tables", "TRACE_CQI_HISTOGRAM"]

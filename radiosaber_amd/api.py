@@ -1,0 +1,370 @@
+"""ctypes binding of include/radiosaber_hip.h.
+
+The classes keep the reference's vocabulary (slices, UEs, RBGs, TTIs):
+
+  SliceConfig      what the reference scheduler constructors read from the JSON config
+                   (downlink-transport-scheduler.cpp:55-97): ues_per_slice + per-slice
+                   weight / algo_alpha / algo_beta / algo_epsilon / algo_psi
+  TtiScheduler     drop-in mode, one RBsAllocation() per call            (rs_create / rs_schedule_tti)
+  BatchScheduler   many device-resident cells, whole DoSchedule() loops  (rs_batch_*)
+"""
+import ctypes as C
+import json
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+RS_SCHED_PF, RS_SCHED_NVS, RS_SCHED_SEQUENTIAL, RS_SCHED_MAXCELL = 1, 7, 8, 9
+
+# CQI histogram (CQI 1..15) of the reference's whole cqi-traces-noise0 corpus (158 traces x 475 rows
+# x 512 PRBs; SURVEY.md 8d, re-counted by tools/make_trace_fixture.py)
+TRACE_CQI_HISTOGRAM = (152600, 56656, 270880, 2088792, 3509504, 1595568, 4145392, 5295816, 1903424,
+                       6890232, 4770864, 2842552, 3579624, 96000, 1227696)
+
+_PKG = Path(__file__).resolve().parent
+_LIB_PATH = _PKG / "libradiosaber_hip.so"
+
+
+class RadioSaberError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"radiosaber_hip error {code}: {msg}")
+        self.code = code
+
+
+class _Config(C.Structure):
+    _fields_ = [("n_slices", C.c_int32), ("n_users", C.c_int32), ("n_rbgs", C.c_int32),
+                ("rbg_size", C.c_int32), ("sched", C.c_int32), ("device", C.c_int32),
+                ("slice_weight", C.POINTER(C.c_double)), ("algo_alpha", C.POINTER(C.c_int32)),
+                ("algo_beta", C.POINTER(C.c_int32)), ("algo_epsilon", C.POINTER(C.c_int32)),
+                ("algo_psi", C.POINTER(C.c_int32)), ("user_to_slice", C.POINTER(C.c_int32)),
+                ("stream", C.c_void_p)]
+
+
+class _BatchConfig(C.Structure):
+    _fields_ = [("cell", _Config), ("n_cells", C.c_int32), ("first_tti", C.c_int32),
+                ("cqi_refresh", C.c_int32), ("phy_error_draws", C.c_int32),
+                ("threads_per_cell", C.c_int32)]
+
+
+class _TtiIn(C.Structure):
+    _fields_ = [("n_users", C.c_int32), ("user_id", C.POINTER(C.c_int32)),
+                ("cqi", C.POINTER(C.c_uint8)), ("avg_rate", C.POINTER(C.c_double)),
+                ("rand0", C.c_int32), ("rand1", C.c_int32)]
+
+
+class _TtiOut(C.Structure):
+    _fields_ = [("target_rbs", C.POINTER(C.c_int32)), ("quota_rbgs", C.POINTER(C.c_int32)),
+                ("rbg_to_user", C.POINTER(C.c_int32)), ("user_nprb", C.POINTER(C.c_int32)),
+                ("user_final_cqi", C.POINTER(C.c_int32)), ("user_mcs", C.POINTER(C.c_int32)),
+                ("user_tbs_bits", C.POINTER(C.c_int32))]
+
+
+# every symbol include/radiosaber_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "rs_last_error", "rs_abi_version", "rs_device_count", "rs_link_tables",
+    "rs_create", "rs_destroy", "rs_schedule_tti", "rs_get_slice_offset", "rs_set_slice_offset",
+    "rs_batch_create", "rs_batch_destroy", "rs_batch_seed", "rs_batch_upload_cqi_epochs",
+    "rs_batch_synthesize_cqi", "rs_batch_download_cqi_epochs", "rs_batch_set_trace",
+    "rs_batch_run", "rs_batch_run_async", "rs_batch_sync", "rs_batch_run_logged",
+    "rs_batch_run_timed", "rs_batch_read_state", "rs_batch_slice_bytes_device",
+    "rs_batch_slice_bytes", "rs_batch_ttis_done", "rs_batch_stream", "rs_batch_kernel_name",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libradiosaber_hip.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise RadioSaberError(-100, f"{_LIB_PATH} is missing: run `python -m radiosaber_amd.build` "
+                                    "(there is no CPU fallback)")
+    L = C.CDLL(str(_LIB_PATH))
+    L.rs_last_error.restype = C.c_char_p
+    L.rs_link_tables.argtypes = [C.POINTER(C.c_double)] * 4
+    L.rs_create.restype = C.c_void_p
+    L.rs_create.argtypes = [C.POINTER(_Config)]
+    L.rs_destroy.argtypes = [C.c_void_p]
+    L.rs_schedule_tti.argtypes = [C.c_void_p, C.POINTER(_TtiIn), C.POINTER(_TtiOut)]
+    L.rs_get_slice_offset.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.rs_set_slice_offset.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.rs_batch_create.restype = C.c_void_p
+    L.rs_batch_create.argtypes = [C.POINTER(_BatchConfig)]
+    L.rs_batch_destroy.argtypes = [C.c_void_p]
+    L.rs_batch_seed.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
+    L.rs_batch_upload_cqi_epochs.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32]
+    L.rs_batch_synthesize_cqi.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.c_int32]
+    L.rs_batch_download_cqi_epochs.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint8)]
+    L.rs_batch_set_trace.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32,
+                                     C.POINTER(C.c_int32)]
+    L.rs_batch_run.argtypes = [C.c_void_p, C.c_int32]
+    L.rs_batch_run_async.argtypes = [C.c_void_p, C.c_int32]
+    L.rs_batch_sync.argtypes = [C.c_void_p]
+    L.rs_batch_run_logged.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int16), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int16)]
+    L.rs_batch_run_timed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+    L.rs_batch_read_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    L.rs_batch_slice_bytes_device.argtypes = [C.c_void_p, C.c_void_p]
+    L.rs_batch_slice_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.rs_batch_ttis_done.restype = C.c_int64
+    L.rs_batch_ttis_done.argtypes = [C.c_void_p]
+    L.rs_batch_stream.restype = C.c_void_p
+    L.rs_batch_stream.argtypes = [C.c_void_p]
+    L.rs_batch_kernel_name.restype = C.c_char_p
+    L.rs_batch_kernel_name.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RadioSaberError(rc, lib().rs_last_error().decode())
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def device_count():
+    return lib().rs_device_count()
+
+
+def link_tables():
+    """Host-libm link adaptation tables (no GPU needed): dict of eff/kbps/E/X, each float64[16]."""
+    out = [np.zeros(16, np.float64) for _ in range(4)]
+    _check(lib().rs_link_tables(*[_p(a, C.c_double) for a in out]))
+    return dict(zip(("eff", "kbps", "eesm_e", "eesm_x"), out))
+
+
+@dataclass
+class SliceConfig:
+    """The reference's JSON scheduler config (downlink-transport-scheduler.cpp:65-88;
+    single-cell-with-interference.h:220-248): `slices` groups expand in order."""
+    ues_per_slice: List[int]
+    weight: List[float] = field(default_factory=list)
+    algo_alpha: List[int] = field(default_factory=list)
+    algo_beta: List[int] = field(default_factory=list)
+    algo_epsilon: List[int] = field(default_factory=list)
+    algo_psi: List[int] = field(default_factory=list)
+
+    def __post_init__(self):
+        S = len(self.ues_per_slice)
+        if not self.weight:
+            self.weight = [1.0 / S] * S
+        for name, default in (("algo_alpha", 0), ("algo_beta", 0), ("algo_epsilon", 1), ("algo_psi", 1)):
+            if not getattr(self, name):
+                setattr(self, name, [default] * S)
+        for name in ("weight", "algo_alpha", "algo_beta", "algo_epsilon", "algo_psi"):
+            if len(getattr(self, name)) != S:
+                raise ValueError(f"{name} has {len(getattr(self, name))} entries for {S} slices")
+
+    @classmethod
+    def from_json(cls, path_or_dict):
+        obj = path_or_dict if isinstance(path_or_dict, dict) else json.loads(Path(path_or_dict).read_text())
+        ues = [int(x) for x in obj["ues_per_slice"]]
+        w, a, b, e, p = [], [], [], [], []
+        for grp in obj["slices"]:
+            for _ in range(int(grp["n_slices"])):
+                w.append(float(grp["weight"]))
+                a.append(int(grp.get("algo_alpha", 0)))
+                b.append(int(grp.get("algo_beta", 0)))
+                e.append(int(grp.get("algo_epsilon", 0)))
+                p.append(int(grp.get("algo_psi", 0)))
+        return cls(ues, w, a, b, e, p)
+
+    @property
+    def n_slices(self):
+        return len(self.ues_per_slice)
+
+    @property
+    def n_users(self):
+        return int(sum(self.ues_per_slice))
+
+    @property
+    def user_to_slice(self):
+        return np.repeat(np.arange(self.n_slices, dtype=np.int32), self.ues_per_slice).astype(np.int32)
+
+
+class _CfgHolder:
+    """Keeps the numpy arrays a C rs_config points at alive."""
+
+    def __init__(self, slices: SliceConfig, n_rbgs, rbg_size, sched, device, stream):
+        self.w = np.ascontiguousarray(slices.weight, np.float64)
+        self.a = np.ascontiguousarray(slices.algo_alpha, np.int32)
+        self.b = np.ascontiguousarray(slices.algo_beta, np.int32)
+        self.e = np.ascontiguousarray(slices.algo_epsilon, np.int32)
+        self.p = np.ascontiguousarray(slices.algo_psi, np.int32)
+        self.u2s = np.ascontiguousarray(slices.user_to_slice, np.int32)
+        self.c = _Config(slices.n_slices, slices.n_users, n_rbgs, rbg_size, sched, device,
+                         _p(self.w, C.c_double), _p(self.a, C.c_int32), _p(self.b, C.c_int32),
+                         _p(self.e, C.c_int32), _p(self.p, C.c_int32), _p(self.u2s, C.c_int32),
+                         C.c_void_p(stream or 0))
+
+
+@dataclass
+class TtiResult:
+    target_rbs: np.ndarray
+    quota_rbgs: np.ndarray
+    rbg_to_user: np.ndarray
+    user_nprb: np.ndarray
+    user_final_cqi: np.ndarray
+    user_mcs: np.ndarray
+    user_tbs_bits: np.ndarray
+
+
+class TtiScheduler:
+    """Drop-in mode: RBsAllocation() of one TTI on the GPU (rs_create / rs_schedule_tti)."""
+
+    def __init__(self, slices: SliceConfig, n_rbgs: int, rbg_size: int, sched: int = RS_SCHED_MAXCELL,
+                 device: int = 0, stream: Optional[int] = None):
+        self.slices, self.R, self.rbg_size, self.sched = slices, n_rbgs, rbg_size, sched
+        self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream)
+        self._h = lib().rs_create(C.byref(self._cfg.c))
+        if not self._h:
+            raise RadioSaberError(-1, lib().rs_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rs_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def schedule_tti(self, cqi, avg_rate, rand0=0, rand1=0, user_id: Optional[Sequence[int]] = None) -> TtiResult:
+        cqi = np.ascontiguousarray(cqi, np.uint8)
+        n = cqi.shape[0]
+        assert cqi.shape == (n, self.R)
+        avg = np.ascontiguousarray(avg_rate, np.float64)
+        assert avg.shape == (n,)
+        uid = None if user_id is None else np.ascontiguousarray(user_id, np.int32)
+        S = self.slices.n_slices
+        res = TtiResult(np.zeros(S, np.int32), np.zeros(S, np.int32), np.zeros(self.R, np.int32),
+                        np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32))
+        tin = _TtiIn(n, _p(uid, C.c_int32) if uid is not None else None, _p(cqi, C.c_uint8),
+                     _p(avg, C.c_double), rand0, rand1)
+        tout = _TtiOut(_p(res.target_rbs, C.c_int32), _p(res.quota_rbgs, C.c_int32),
+                       _p(res.rbg_to_user, C.c_int32), _p(res.user_nprb, C.c_int32),
+                       _p(res.user_final_cqi, C.c_int32), _p(res.user_mcs, C.c_int32),
+                       _p(res.user_tbs_bits, C.c_int32))
+        _check(lib().rs_schedule_tti(self._h, C.byref(tin), C.byref(tout)))
+        return res
+
+    @property
+    def slice_offset(self):
+        out = np.zeros(self.slices.n_slices, np.float64)
+        _check(lib().rs_get_slice_offset(self._h, _p(out, C.c_double)))
+        return out
+
+    @slice_offset.setter
+    def slice_offset(self, v):
+        a = np.ascontiguousarray(v, np.float64)
+        _check(lib().rs_set_slice_offset(self._h, _p(a, C.c_double)))
+
+
+class BatchScheduler:
+    """Many independent cells resident on one MI355X (rs_batch_*)."""
+
+    def __init__(self, slices: SliceConfig, n_rbgs: int, rbg_size: int, n_cells: int,
+                 sched: int = RS_SCHED_MAXCELL, device: int = 0, first_tti: int = 100, cqi_refresh: int = 40,
+                 phy_error_draws: bool = False, threads_per_cell: int = 0, stream: Optional[int] = None):
+        self.slices, self.R, self.rbg_size, self.sched, self.n_cells = slices, n_rbgs, rbg_size, sched, n_cells
+        self.S, self.U = slices.n_slices, slices.n_users
+        self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream)
+        bc = _BatchConfig(self._cfg.c, n_cells, first_tti, cqi_refresh, int(phy_error_draws), threads_per_cell)
+        self._h = lib().rs_batch_create(C.byref(bc))
+        if not self._h:
+            raise RadioSaberError(-1, lib().rs_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rs_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def seed(self, seeds, rand_skip=None):
+        s = np.ascontiguousarray(seeds, np.uint32)
+        assert s.shape == (self.n_cells,)
+        k = None if rand_skip is None else np.ascontiguousarray(rand_skip, np.int64)
+        _check(lib().rs_batch_seed(self._h, _p(s, C.c_uint32), _p(k, C.c_int64) if k is not None else None))
+
+    def upload_cqi_epochs(self, cqi):
+        a = np.ascontiguousarray(cqi, np.uint8)
+        assert a.ndim == 4 and a.shape[0] == self.n_cells and a.shape[2:] == (self.U, self.R), a.shape
+        _check(lib().rs_batch_upload_cqi_epochs(self._h, _p(a, C.c_uint8), a.shape[1]))
+        self.n_epochs = a.shape[1]
+
+    def synthesize_cqi(self, seed, n_epochs, weights=TRACE_CQI_HISTOGRAM):
+        w = np.ascontiguousarray(weights, np.float64)
+        assert w.shape == (15,)
+        _check(lib().rs_batch_synthesize_cqi(self._h, seed, _p(w, C.c_double), n_epochs))
+        self.n_epochs = n_epochs
+
+    def download_cqi_epochs(self, cell):
+        out = np.zeros((self.n_epochs, self.U, self.R), np.uint8)
+        _check(lib().rs_batch_download_cqi_epochs(self._h, cell, _p(out, C.c_uint8)))
+        return out
+
+    def set_trace(self, trace, user_trace, row_modulus=475):
+        t = np.ascontiguousarray(trace, np.uint8)
+        assert t.ndim == 3 and t.shape[2] == self.R
+        ut = np.ascontiguousarray(user_trace, np.int32)
+        assert ut.shape == (self.n_cells, self.U)
+        _check(lib().rs_batch_set_trace(self._h, _p(t, C.c_uint8), t.shape[0], t.shape[1], row_modulus,
+                                        _p(ut, C.c_int32)))
+
+    def run(self, n_ttis):
+        _check(lib().rs_batch_run(self._h, n_ttis))
+
+    def run_async(self, n_ttis):
+        _check(lib().rs_batch_run_async(self._h, n_ttis))
+
+    def sync(self):
+        _check(lib().rs_batch_sync(self._h))
+
+    def run_logged(self, n_ttis):
+        m = np.zeros((self.n_cells, n_ttis, self.R), np.int16)
+        tb = np.zeros((self.n_cells, n_ttis, self.U), np.int32)
+        q = np.zeros((self.n_cells, n_ttis, self.S), np.int16)
+        _check(lib().rs_batch_run_logged(self._h, n_ttis, _p(m, C.c_int16), _p(tb, C.c_int32), _p(q, C.c_int16)))
+        return {"rbg_to_user": m, "tbs_bits": tb, "quota": q}
+
+    def run_timed(self, n_ttis, launches):
+        ms = np.zeros(launches, np.float32)
+        _check(lib().rs_batch_run_timed(self._h, n_ttis, launches, _p(ms, C.c_float)))
+        return ms
+
+    def state(self):
+        avg = np.zeros((self.n_cells, self.U), np.float64)
+        cb = np.zeros((self.n_cells, self.U), np.int64)
+        cr = np.zeros((self.n_cells, self.U), np.int64)
+        sl = np.zeros((self.n_cells, self.S), np.float64)
+        _check(lib().rs_batch_read_state(self._h, _p(avg, C.c_double), _p(cb, C.c_int64), _p(cr, C.c_int64),
+                                         _p(sl, C.c_double)))
+        return {"avg_rate": avg, "cum_bytes": cb, "cum_rbs": cr, "slice_state": sl}
+
+    def slice_bytes(self):
+        out = np.zeros(self.S, np.uint64)
+        _check(lib().rs_batch_slice_bytes(self._h, _p(out, C.c_uint64)))
+        return out
+
+    def slice_bytes_into(self, device_ptr):
+        """Reduce per-slice cumulative bytes into a device buffer (uint64[S]) on the batch's stream."""
+        _check(lib().rs_batch_slice_bytes_device(self._h, C.c_void_p(device_ptr)))
+
+    @property
+    def ttis_done(self):
+        return lib().rs_batch_ttis_done(self._h)
+
+    @property
+    def stream(self):
+        return lib().rs_batch_stream(self._h)
+
+    @property
+    def kernel_name(self):
+        return lib().rs_batch_kernel_name(self._h).decode()

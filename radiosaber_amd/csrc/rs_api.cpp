@@ -1,0 +1,706 @@
+/*
+ * rs_api.cpp -- host side of the C ABI declared in include/radiosaber_hip.h.
+ *
+ * Validates configurations, owns the device buffers (cell state, CQI grids, traces), evaluates the
+ * link-adaptation tables with the host libm (the only place transcendental functions run), seeds the
+ * per-cell libc-compatible rand() streams and launches the gfx950 kernels of rs_kernels.hip.
+ * There is no CPU implementation of the scheduling path here: without a HIP device every compute
+ * entry point fails with RS_ERR_NO_DEVICE.
+ *
+ * Build with -ffp-contract=off (the table arithmetic must round like the reference's -O0 SSE2 code).
+ */
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/radiosaber_hip.h"
+#include "rs_amc_tables.inc"
+#include "rs_device.h"
+
+extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_t stream);
+extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes);
+extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,
+                                      uint64_t seed, const uint32_t* cdf16, hipStream_t stream);
+extern "C" hipError_t rs_launch_slice_bytes(const int64_t* cum_bytes, const uint8_t* user_slice, int n_cells, int U,
+                                            int S, unsigned long long* d_out, hipStream_t stream);
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e__ = (expr);                                                                   \
+    if (e__ != hipSuccess) return fail(RS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__));   \
+  } while (0)
+
+const int kCqiToMcs[15] = {RS_AMC_CQI_TO_MCS};
+const double kSinrForCqi[15] = {RS_AMC_SINR_FOR_CQI};
+const int kMcsToItbs[29] = {RS_AMC_MCS_TO_ITBS};
+const int kTbs[110][27] = {RS_AMC_TBS_TABLE};
+
+/* the reference's effective-SINR expression on x = mean(exp(-sinr_lin))
+ * (src/utility/eesm-effective-sinr.h:43-44 with beta = 1) */
+double eesm_db_of_mean(double x) {
+  double beta = 1;
+  double eff = -beta * log(x);
+  eff = 10 * log10(eff);
+  return eff;
+}
+
+double from_bits(uint64_t b) {
+  double d;
+  memcpy(&d, &b, 8);
+  return d;
+}
+uint64_t to_bits(double d) {
+  uint64_t b;
+  memcpy(&b, &d, 8);
+  return b;
+}
+
+/* glibc TYPE_3 rand() (glibc 2.35 stdlib/random_r.c), host copy used to seed the device rings */
+struct HostRng {
+  uint32_t r[31];
+  int f, b;
+  void seed(unsigned s) {
+    if (s == 0) s = 1;
+    int32_t w = (int32_t)s;
+    r[0] = (uint32_t)w;
+    for (int i = 1; i < 31; i++) {
+      long hi = w / 127773, lo = w % 127773;
+      long word = 16807 * lo - 2836 * hi;
+      if (word < 0) word += 2147483647;
+      w = (int32_t)word;
+      r[i] = (uint32_t)w;
+    }
+    f = 3;
+    b = 0;
+    for (int i = 0; i < 310; i++) next();
+  }
+  int next() {
+    uint32_t v = r[f] += r[b];
+    if (++f >= 31) f = 0;
+    if (++b >= 31) b = 0;
+    return (int)(v >> 1);
+  }
+};
+
+int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+const char* rs_last_error(void) { return g_err; }
+int rs_abi_version(void) { return RS_ABI_VERSION; }
+
+int rs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rs_link_tables(double eff[16], double kbps[16], double eesm_e[16], double eesm_x[16]) {
+  eff[0] = kbps[0] = eesm_e[0] = eesm_x[0] = 0;
+  for (int c = 1; c <= 15; c++) {
+    int bits = kTbs[0][kMcsToItbs[kCqiToMcs[c - 1]]];
+    double e = (bits / 0.001) / 180000.; /* AMCModule.cpp:320-327 */
+    eff[c] = e;
+    kbps[c] = e * 180000 / 1000; /* downlink-transport-scheduler.cpp:688 */
+    double s = pow(10, kSinrForCqi[c - 1] / 10);
+    double beta = 1;
+    eesm_e[c] = exp(-s / beta); /* eesm-effective-sinr.h:38-40 */
+  }
+  eesm_x[14] = eesm_x[15] = 0;
+  for (int k = 1; k <= 13; k++) {
+    /* largest positive double x with eesm_db_of_mean(x) >= SINR[k] (the function decreases in x) */
+    const double thr = kSinrForCqi[k];
+    uint64_t lo = 1, hi = to_bits(1.0) - 1; /* smallest subnormal .. largest double below 1 */
+    if (!(eesm_db_of_mean(from_bits(lo)) >= thr)) return fail(RS_ERR_INVALID, "EESM threshold %d unreachable", k);
+    while (hi - lo > 1) {
+      uint64_t mid = lo + (hi - lo) / 2;
+      if (eesm_db_of_mean(from_bits(mid)) >= thr) lo = mid; else hi = mid;
+    }
+    if (eesm_db_of_mean(from_bits(hi)) >= thr) lo = hi;
+    /* the comparison on x is only equivalent to the reference's comparison in dB if the host
+     * libm composite is monotone around the threshold: check a +-4096 ulp neighbourhood */
+    for (int d = 1; d <= 4096; d++) {
+      if (!(eesm_db_of_mean(from_bits(lo - d)) >= thr) || (eesm_db_of_mean(from_bits(lo + d)) >= thr))
+        return fail(RS_ERR_INVALID, "host libm not monotone around EESM threshold %d (offset %d ulp)", k, d);
+    }
+    eesm_x[k] = from_bits(lo);
+  }
+  for (int k = 2; k <= 13; k++)
+    if (!(eesm_x[k] < eesm_x[k - 1])) return fail(RS_ERR_INVALID, "EESM thresholds not decreasing at %d", k);
+  return RS_OK;
+}
+
+}  // extern "C"
+
+/* ===================================================================================== */
+
+struct rs_batch {
+  rs_batch_config cfg;
+  std::vector<double> weight;
+  std::vector<int32_t> eps, psi, u2s;
+  int S, U, R, G, sched, n_cells, threads;
+  bool direct = false;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  /* device */
+  RsTables* d_tab = nullptr;
+  double* d_weight = nullptr;
+  int32_t *d_eps = nullptr, *d_psi = nullptr;
+  uint8_t* d_user_slice = nullptr;
+  double* d_avg = nullptr;
+  int32_t* d_tx = nullptr;
+  int64_t *d_cumb = nullptr, *d_cumr = nullptr;
+  double* d_sstate = nullptr;
+  RsCellScalars* d_scal = nullptr;
+  uint8_t* d_epochs = nullptr;
+  int64_t grid_stride = 0;
+  int32_t n_epochs = 0;
+  uint8_t* d_trace = nullptr;
+  int32_t n_traces = 0, n_rows = 0, row_mod = 0;
+  int32_t* d_user_trace = nullptr;
+  int32_t cqi_mode = RS_CQI_NONE;
+  int32_t* d_err = nullptr;
+  unsigned long long* d_slice_bytes = nullptr;
+  int64_t ttis_done = 0;
+  RsLaunch base{};
+};
+
+namespace {
+
+int validate(const rs_config* c) {
+  if (!c) return fail(RS_ERR_INVALID, "null config");
+  if (c->n_slices < 1 || c->n_slices > RS_MAX_SLICES) return fail(RS_ERR_INVALID, "n_slices %d outside 1..%d", c->n_slices, RS_MAX_SLICES);
+  if (c->n_users < 1 || c->n_users > RS_MAX_USERS) return fail(RS_ERR_INVALID, "n_users %d outside 1..%d", c->n_users, RS_MAX_USERS);
+  if (c->n_rbgs < 1 || c->n_rbgs > RS_MAX_RBGS) return fail(RS_ERR_INVALID, "n_rbgs %d outside 1..%d", c->n_rbgs, RS_MAX_RBGS);
+  if (c->rbg_size < 1 || c->rbg_size > 8) return fail(RS_ERR_INVALID, "rbg_size %d outside 1..8", c->rbg_size);
+  if (c->n_rbgs * c->rbg_size > 512) return fail(RS_ERR_INVALID, "more than 512 PRBs (reference get_rbg_size throws)");
+  if (c->sched != RS_SCHED_PF && c->sched != RS_SCHED_NVS && c->sched != RS_SCHED_SEQUENTIAL && c->sched != RS_SCHED_MAXCELL)
+    return fail(RS_ERR_INVALID, "sched %d not supported (1, 7, 8, 9)", c->sched);
+  if (!c->slice_weight || !c->algo_alpha || !c->algo_epsilon || !c->algo_psi || !c->user_to_slice)
+    return fail(RS_ERR_INVALID, "null slice/user array");
+  for (int s = 0; s < c->n_slices; s++) {
+    if (c->algo_alpha[s] != 0) return fail(RS_ERR_INVALID, "slice %d: algo_alpha != 0 is not supported", s);
+    if ((c->algo_epsilon[s] | 1) != 1 || (c->algo_psi[s] | 1) != 1)
+      return fail(RS_ERR_INVALID, "slice %d: algo_epsilon/algo_psi must be 0 or 1", s);
+  }
+  for (int u = 0; u < c->n_users; u++) {
+    int s = c->user_to_slice[u];
+    if (s < 0 || s >= c->n_slices) return fail(RS_ERR_INVALID, "user %d: slice %d out of range", u, s);
+    if (u && s < c->user_to_slice[u - 1]) return fail(RS_ERR_INVALID, "user_to_slice must be non-decreasing (user %d)", u);
+  }
+  return RS_OK;
+}
+
+void carve_lds(rs_batch* b, RsLaunch* L) {
+  const int U = b->U, R = b->R, S = b->S;
+  int n_seg = b->sched == RS_SCHED_PF ? (U + RS_PF_SEG - 1) / RS_PF_SEG : (b->sched == RS_SCHED_NVS ? 1 : S);
+  int n_items = R * n_seg;
+  int off = 0;
+  off += 8 * U;               /* avg */
+  L->off_avgk = off; off += 8 * U;
+  L->off_cumb = off; off += 8 * U;
+  L->off_tab = off; off += 8 * 48;
+  L->off_slice = off; off += 8 * 128;
+  L->off_tx = off; off += round_up(4 * U, 16);
+  L->off_cumr = off; off += round_up(4 * U, 16);
+  L->off_misc = off; off += round_up((68 + 64 * 6 + 96 + 4) * 4, 16);
+  L->off_elems = off; off += round_up(b->sched == RS_SCHED_PF ? 8 * n_items : 4 * R * S, 16);
+  L->off_sorted = off; off += round_up(4 * R * S, 16);
+  L->off_items = off; off += round_up(2 * n_items, 16);
+  L->off_cqi = off; off += round_up(U * R, 16);
+  L->lds_bytes = off;
+  L->n_seg = n_seg;
+  L->n_items = n_items;
+}
+
+int init_scalars(rs_batch* b, const uint32_t* seed, const int64_t* skip) {
+  std::vector<RsCellScalars> sc(b->n_cells);
+  double t = 0;
+  for (int k = 0; k < b->cfg.first_tti; k++) t += 0.001; /* simulator.cc:117-126 */
+  for (int c = 0; c < b->n_cells; c++) {
+    RsCellScalars& s = sc[c];
+    memset(&s, 0, sizeof s);
+    s.t = t;
+    s.last_update = 0.1; /* bearers are created by the application start event at 0.1 s */
+    HostRng g;
+    g.seed(seed ? seed[c] : 1u);
+    if (skip)
+      for (int64_t i = 0; i < skip[c]; i++) g.next();
+    memcpy(s.rng_r, g.r, sizeof g.r);
+    s.rng_f = g.f;
+    s.rng_b = g.b;
+  }
+  HIP_TRY(hipMemcpy(b->d_scal, sc.data(), sizeof(RsCellScalars) * b->n_cells, hipMemcpyHostToDevice));
+  return RS_OK;
+}
+
+int batch_alloc(rs_batch* b) {
+  const size_t cells = b->n_cells, U = b->U, S = b->S;
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  if (b->cfg.cell.stream) {
+    b->stream = (hipStream_t)b->cfg.cell.stream;
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    b->own_stream = true;
+  }
+  RsTables t;
+  memset(&t, 0, sizeof t);
+  double eff[16];
+  int rc = rs_link_tables(eff, t.kbps, t.eesm_e, t.eesm_x);
+  if (rc) return rc;
+  for (int c = 1; c <= 15; c++) {
+    t.pfnum[c] = eff[c] * 180000.; /* dl-pf-packet-scheduler.cpp:138 */
+    t.mcs_of_cqi[c] = kCqiToMcs[c - 1];
+    t.itbs_of_cqi[c] = kMcsToItbs[kCqiToMcs[c - 1]];
+  }
+  /* AMCModule.cpp:313-315 reads TransportBlockSizeTable[-1][itbs] when nbRBs > 110 and nbRBs % 5 == 0.
+   * In the as-shipped -O0 build McsToItbs[29] sits 128 bytes in front of the table, so
+   * T[-1][i] = McsToItbs[5+i] for i <= 23 and 0 (padding) beyond. */
+  for (int i = 0; i < 27; i++) t.tbs_row_m1[i] = i <= 23 ? kMcsToItbs[5 + i] : 0;
+  HIP_TRY(hipMalloc(&b->d_tab, sizeof t));
+  HIP_TRY(hipMemcpy(b->d_tab, &t, sizeof t, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&b->d_weight, 8 * S));
+  HIP_TRY(hipMemcpy(b->d_weight, b->weight.data(), 8 * S, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&b->d_eps, 4 * S));
+  HIP_TRY(hipMemcpy(b->d_eps, b->eps.data(), 4 * S, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&b->d_psi, 4 * S));
+  HIP_TRY(hipMemcpy(b->d_psi, b->psi.data(), 4 * S, hipMemcpyHostToDevice));
+  std::vector<uint8_t> us(U);
+  for (size_t u = 0; u < U; u++) us[u] = (uint8_t)b->u2s[u];
+  HIP_TRY(hipMalloc(&b->d_user_slice, U));
+  HIP_TRY(hipMemcpy(b->d_user_slice, us.data(), U, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&b->d_avg, 8 * cells * U));
+  HIP_TRY(hipMalloc(&b->d_tx, 4 * cells * U));
+  HIP_TRY(hipMalloc(&b->d_cumb, 8 * cells * U));
+  HIP_TRY(hipMalloc(&b->d_cumr, 8 * cells * U));
+  HIP_TRY(hipMalloc(&b->d_sstate, 8 * cells * S));
+  HIP_TRY(hipMalloc(&b->d_scal, sizeof(RsCellScalars) * cells));
+  HIP_TRY(hipMalloc(&b->d_err, 4));
+  HIP_TRY(hipMalloc(&b->d_slice_bytes, 8 * 64));
+  HIP_TRY(hipMemset(b->d_err, 0, 4));
+  std::vector<double> avg(cells * U, 100000.0); /* radio-bearer.cpp:54 */
+  HIP_TRY(hipMemcpy(b->d_avg, avg.data(), 8 * cells * U, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(b->d_tx, 0, 4 * cells * U));
+  HIP_TRY(hipMemset(b->d_cumb, 0, 8 * cells * U));
+  HIP_TRY(hipMemset(b->d_cumr, 0, 8 * cells * U));
+  HIP_TRY(hipMemset(b->d_sstate, 0, 8 * cells * S));
+  rc = init_scalars(b, nullptr, nullptr);
+  if (rc) return rc;
+
+  RsLaunch& L = b->base;
+  memset(&L, 0, sizeof L);
+  L.S = b->S; L.U = b->U; L.R = b->R; L.G = b->G;
+  L.sched = b->sched;
+  L.n_cells = b->n_cells;
+  L.refresh = b->cfg.cqi_refresh;
+  L.phy_draws = b->cfg.phy_error_draws;
+  L.tab = b->d_tab; L.weight = b->d_weight; L.eps = b->d_eps; L.psi = b->d_psi;
+  L.user_slice = b->d_user_slice;
+  L.avg = b->d_avg; L.tx_bytes = b->d_tx; L.cum_bytes = b->d_cumb; L.cum_rbs = b->d_cumr;
+  L.slice_state = b->d_sstate; L.scal = b->d_scal; L.err = b->d_err;
+  carve_lds(b, &L);
+  if (L.lds_bytes > 160 * 1024) return fail(RS_ERR_INVALID, "cell needs %d B of LDS (> 160 KiB)", L.lds_bytes);
+  HIP_TRY(rs_prepare_kernels(160 * 1024));
+  return RS_OK;
+}
+
+rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
+  if (!cfg) { fail(RS_ERR_INVALID, "null config"); return nullptr; }
+  if (validate(&cfg->cell)) return nullptr;
+  if (cfg->n_cells < 1) { fail(RS_ERR_INVALID, "n_cells %d < 1", cfg->n_cells); return nullptr; }
+  if (!direct && cfg->cqi_refresh < 1) { fail(RS_ERR_INVALID, "cqi_refresh %d < 1", cfg->cqi_refresh); return nullptr; }
+  if (cfg->first_tti < 0) { fail(RS_ERR_INVALID, "first_tti %d < 0", cfg->first_tti); return nullptr; }
+  int threads = cfg->threads_per_cell ? cfg->threads_per_cell : 256;
+  if (threads % 64 || threads < 64 || threads > 1024) { fail(RS_ERR_INVALID, "threads_per_cell %d", threads); return nullptr; }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { fail(RS_ERR_NO_DEVICE, "no HIP device"); return nullptr; }
+  if (cfg->cell.device < 0 || cfg->cell.device >= n) { fail(RS_ERR_NO_DEVICE, "device %d of %d", cfg->cell.device, n); return nullptr; }
+  rs_batch* b = new (std::nothrow) rs_batch();
+  if (!b) { fail(RS_ERR_INVALID, "out of memory"); return nullptr; }
+  b->cfg = *cfg;
+  const rs_config& c = cfg->cell;
+  b->S = c.n_slices; b->U = c.n_users; b->R = c.n_rbgs; b->G = c.rbg_size; b->sched = c.sched;
+  b->n_cells = cfg->n_cells;
+  b->threads = threads;
+  b->direct = direct;
+  b->weight.assign(c.slice_weight, c.slice_weight + b->S);
+  b->eps.assign(c.algo_epsilon, c.algo_epsilon + b->S);
+  b->psi.assign(c.algo_psi, c.algo_psi + b->S);
+  b->u2s.assign(c.user_to_slice, c.user_to_slice + b->U);
+  b->cfg.cell.slice_weight = nullptr; b->cfg.cell.algo_alpha = nullptr; b->cfg.cell.algo_beta = nullptr;
+  b->cfg.cell.algo_epsilon = nullptr; b->cfg.cell.algo_psi = nullptr; b->cfg.cell.user_to_slice = nullptr;
+  if (batch_alloc(b)) { rs_batch_destroy(b); return nullptr; }
+  return b;
+}
+
+int check_device_err(rs_batch* b) {
+  int e = 0;
+  HIP_TRY(hipMemcpy(&e, b->d_err, 4, hipMemcpyDeviceToHost));
+  if (e) {
+    HIP_TRY(hipMemset(b->d_err, 0, 4));
+    return fail(RS_ERR_RANGE, e == RS_CQI_EPOCHS ? "ran past the last CQI epoch" : "trace row outside the uploaded rows");
+  }
+  return RS_OK;
+}
+
+int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d_target, int32_t* d_tbs, int32_t* d_uinfo) {
+  if (n_ttis < 1) return fail(RS_ERR_INVALID, "n_ttis %d < 1", n_ttis);
+  if (b->cqi_mode == RS_CQI_NONE) return fail(RS_ERR_STATE, "no CQI source set");
+  RsLaunch L = b->base;
+  L.n_ttis = n_ttis;
+  L.cqi_mode = b->cqi_mode;
+  L.epochs = b->d_epochs; L.grid_stride = b->grid_stride; L.n_epochs = b->n_epochs;
+  L.trace = b->d_trace; L.n_traces = b->n_traces; L.n_rows = b->n_rows; L.row_mod = b->row_mod;
+  L.user_trace = b->d_user_trace;
+  L.log_map = d_map; L.log_quota = d_quota; L.log_target = d_target; L.log_tbs = d_tbs; L.log_uinfo = d_uinfo;
+  HIP_TRY(rs_launch_cells(&L, b->threads, b->stream));
+  b->ttis_done += n_ttis;
+  return RS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+rs_batch* rs_batch_create(const rs_batch_config* cfg) { return batch_new(cfg, false); }
+
+void rs_batch_destroy(rs_batch* b) {
+  if (!b) return;
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  void* ptrs[] = {b->d_tab, b->d_weight, b->d_eps, b->d_psi, b->d_user_slice, b->d_avg, b->d_tx, b->d_cumb, b->d_cumr,
+                  b->d_sstate, b->d_scal, b->d_epochs, b->d_trace, b->d_user_trace, b->d_err, b->d_slice_bytes};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+}
+
+int rs_batch_seed(rs_batch* b, const uint32_t* seed, const int64_t* rand_skip) {
+  if (!b || !seed) return fail(RS_ERR_INVALID, "null argument");
+  if (b->ttis_done) return fail(RS_ERR_STATE, "rs_batch_seed after TTIs were run");
+  return init_scalars(b, seed, rand_skip);
+}
+
+int rs_batch_upload_cqi_epochs(rs_batch* b, const uint8_t* h_cqi, int32_t n_epochs) {
+  if (!b || !h_cqi || n_epochs < 1) return fail(RS_ERR_INVALID, "bad argument");
+  const size_t grid = (size_t)b->U * b->R;
+  const size_t stride = round_up((int)grid, 16);
+  const size_t total = (size_t)b->n_cells * n_epochs;
+  for (size_t i = 0; i < total * grid; i++)
+    if (h_cqi[i] < 1 || h_cqi[i] > 15) return fail(RS_ERR_INVALID, "CQI %d at byte %zu outside 1..15", h_cqi[i], i);
+  std::vector<uint8_t> packed(total * stride, 0);
+  for (size_t g = 0; g < total; g++) memcpy(&packed[g * stride], h_cqi + g * grid, grid);
+  if (b->d_epochs) { HIP_TRY(hipFree(b->d_epochs)); b->d_epochs = nullptr; }
+  HIP_TRY(hipMalloc(&b->d_epochs, packed.size()));
+  HIP_TRY(hipMemcpy(b->d_epochs, packed.data(), packed.size(), hipMemcpyHostToDevice));
+  b->grid_stride = (int64_t)stride;
+  b->n_epochs = n_epochs;
+  b->cqi_mode = RS_CQI_EPOCHS;
+  return RS_OK;
+}
+
+int rs_batch_synthesize_cqi(rs_batch* b, uint64_t seed, const double* w, int32_t n_epochs) {
+  if (!b || !w || n_epochs < 1) return fail(RS_ERR_INVALID, "bad argument");
+  double tot = 0;
+  for (int i = 0; i < 15; i++) {
+    if (!(w[i] >= 0)) return fail(RS_ERR_INVALID, "negative CQI weight");
+    tot += w[i];
+  }
+  if (!(tot > 0)) return fail(RS_ERR_INVALID, "all CQI weights are zero");
+  uint32_t cdf[16];
+  double acc = 0;
+  for (int i = 0; i < 15; i++) {
+    acc += w[i];
+    double v = floor(acc / tot * 4294967296.0);
+    cdf[i] = v >= 4294967295.0 ? 4294967295u : (uint32_t)v;
+  }
+  cdf[14] = 4294967295u;
+  cdf[15] = 4294967295u;
+  const size_t stride = round_up(b->U * b->R, 16);
+  const size_t bytes = (size_t)b->n_cells * n_epochs * stride;
+  if (b->d_epochs) { HIP_TRY(hipFree(b->d_epochs)); b->d_epochs = nullptr; }
+  HIP_TRY(hipMalloc(&b->d_epochs, bytes));
+  HIP_TRY(rs_launch_synth(b->d_epochs, (int64_t)stride, b->n_cells, n_epochs, b->U, b->R, seed, cdf, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->grid_stride = (int64_t)stride;
+  b->n_epochs = n_epochs;
+  b->cqi_mode = RS_CQI_EPOCHS;
+  return RS_OK;
+}
+
+int rs_batch_download_cqi_epochs(rs_batch* b, int32_t cell, uint8_t* h_cqi) {
+  if (!b || !h_cqi || cell < 0 || cell >= b->n_cells) return fail(RS_ERR_INVALID, "bad argument");
+  if (b->cqi_mode != RS_CQI_EPOCHS) return fail(RS_ERR_STATE, "no epoch grids on the device");
+  const size_t grid = (size_t)b->U * b->R, stride = (size_t)b->grid_stride;
+  std::vector<uint8_t> tmp((size_t)b->n_epochs * stride);
+  HIP_TRY(hipMemcpy(tmp.data(), b->d_epochs + (size_t)cell * b->n_epochs * stride, tmp.size(), hipMemcpyDeviceToHost));
+  for (int e = 0; e < b->n_epochs; e++) memcpy(h_cqi + e * grid, &tmp[e * stride], grid);
+  return RS_OK;
+}
+
+int rs_batch_set_trace(rs_batch* b, const uint8_t* h_trace, int32_t n_traces, int32_t n_rows, int32_t row_modulus,
+                       const int32_t* h_user_trace) {
+  if (!b || !h_trace || !h_user_trace || n_traces < 1 || n_rows < 1 || row_modulus < 1)
+    return fail(RS_ERR_INVALID, "bad argument");
+  const size_t tb = (size_t)n_traces * n_rows * b->R;
+  for (size_t i = 0; i < tb; i++)
+    if (h_trace[i] < 1 || h_trace[i] > 15) return fail(RS_ERR_INVALID, "trace CQI %d outside 1..15", h_trace[i]);
+  const size_t nu = (size_t)b->n_cells * b->U;
+  for (size_t i = 0; i < nu; i++)
+    if (h_user_trace[i] < 0 || h_user_trace[i] >= n_traces) return fail(RS_ERR_INVALID, "trace id %d out of range", h_user_trace[i]);
+  if (b->d_trace) { HIP_TRY(hipFree(b->d_trace)); b->d_trace = nullptr; }
+  if (b->d_user_trace) { HIP_TRY(hipFree(b->d_user_trace)); b->d_user_trace = nullptr; }
+  HIP_TRY(hipMalloc(&b->d_trace, tb));
+  HIP_TRY(hipMemcpy(b->d_trace, h_trace, tb, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&b->d_user_trace, 4 * nu));
+  HIP_TRY(hipMemcpy(b->d_user_trace, h_user_trace, 4 * nu, hipMemcpyHostToDevice));
+  b->n_traces = n_traces; b->n_rows = n_rows; b->row_mod = row_modulus;
+  b->cqi_mode = RS_CQI_TRACE;
+  return RS_OK;
+}
+
+int rs_batch_run_async(rs_batch* b, int32_t n_ttis) {
+  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  return launch(b, n_ttis, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int rs_batch_sync(rs_batch* b) {
+  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return check_device_err(b);
+}
+
+int rs_batch_run(rs_batch* b, int32_t n_ttis) {
+  int rc = rs_batch_run_async(b, n_ttis);
+  if (rc) return rc;
+  return rs_batch_sync(b);
+}
+
+int rs_batch_run_logged(rs_batch* b, int32_t n_ttis, int16_t* h_map, int32_t* h_tbs, int16_t* h_quota) {
+  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  if (n_ttis < 1) return fail(RS_ERR_INVALID, "n_ttis %d < 1", n_ttis);
+  const size_t rows = (size_t)b->n_cells * n_ttis;
+  int16_t *d_map = nullptr, *d_quota = nullptr;
+  int32_t* d_tbs = nullptr;
+  HIP_TRY(hipMalloc(&d_map, 2 * rows * b->R));
+  HIP_TRY(hipMalloc(&d_quota, 2 * rows * b->S));
+  HIP_TRY(hipMalloc(&d_tbs, 4 * rows * b->U));
+  HIP_TRY(hipMemsetAsync(d_tbs, 0, 4 * rows * b->U, b->stream));
+  int rc = launch(b, n_ttis, d_map, d_quota, nullptr, d_tbs, nullptr);
+  if (!rc) rc = rs_batch_sync(b);
+  if (!rc) {
+    if (h_map) HIP_TRY(hipMemcpy(h_map, d_map, 2 * rows * b->R, hipMemcpyDeviceToHost));
+    if (h_quota) HIP_TRY(hipMemcpy(h_quota, d_quota, 2 * rows * b->S, hipMemcpyDeviceToHost));
+    if (h_tbs) HIP_TRY(hipMemcpy(h_tbs, d_tbs, 4 * rows * b->U, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d_map);
+  (void)hipFree(d_quota);
+  (void)hipFree(d_tbs);
+  return rc;
+}
+
+int rs_batch_run_timed(rs_batch* b, int32_t n_ttis, int32_t launches, float* ms) {
+  if (!b || !ms || launches < 1) return fail(RS_ERR_INVALID, "bad argument");
+  std::vector<hipEvent_t> ev(launches + 1);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  int rc = RS_OK;
+  HIP_TRY(hipEventRecord(ev[0], b->stream));
+  for (int i = 0; i < launches && !rc; i++) {
+    rc = launch(b, n_ttis, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (!rc) HIP_TRY(hipEventRecord(ev[i + 1], b->stream));
+  }
+  if (!rc) rc = rs_batch_sync(b);
+  if (!rc)
+    for (int i = 0; i < launches; i++) HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int rs_batch_read_state(rs_batch* b, double* avg, int64_t* cum_bytes, int64_t* cum_rbs, double* slice_state) {
+  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const size_t n = (size_t)b->n_cells * b->U;
+  if (avg) HIP_TRY(hipMemcpy(avg, b->d_avg, 8 * n, hipMemcpyDeviceToHost));
+  if (cum_bytes) HIP_TRY(hipMemcpy(cum_bytes, b->d_cumb, 8 * n, hipMemcpyDeviceToHost));
+  if (cum_rbs) HIP_TRY(hipMemcpy(cum_rbs, b->d_cumr, 8 * n, hipMemcpyDeviceToHost));
+  if (slice_state) HIP_TRY(hipMemcpy(slice_state, b->d_sstate, 8 * (size_t)b->n_cells * b->S, hipMemcpyDeviceToHost));
+  return RS_OK;
+}
+
+int rs_batch_slice_bytes_device(rs_batch* b, uint64_t* d_out) {
+  if (!b || !d_out) return fail(RS_ERR_INVALID, "null argument");
+  HIP_TRY(rs_launch_slice_bytes(b->d_cumb, b->d_user_slice, b->n_cells, b->U, b->S, (unsigned long long*)d_out, b->stream));
+  return RS_OK;
+}
+
+int rs_batch_slice_bytes(rs_batch* b, uint64_t* h_out) {
+  if (!b || !h_out) return fail(RS_ERR_INVALID, "null argument");
+  int rc = rs_batch_slice_bytes_device(b, (uint64_t*)b->d_slice_bytes);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(h_out, b->d_slice_bytes, 8 * b->S, hipMemcpyDeviceToHost));
+  return RS_OK;
+}
+
+int64_t rs_batch_ttis_done(rs_batch* b) { return b ? b->ttis_done : -1; }
+void* rs_batch_stream(rs_batch* b) { return b ? (void*)b->stream : nullptr; }
+const char* rs_batch_kernel_name(rs_batch* b) {
+  if (!b) return "";
+  switch (b->sched) {
+    case 1: return "rs_cell_kernel<1>";
+    case 7: return "rs_cell_kernel<7>";
+    case 8: return "rs_cell_kernel<8>";
+    default: return "rs_cell_kernel<9>";
+  }
+}
+
+}  // extern "C"
+
+/* ===================================================================================== */
+/* drop-in mode: one RBsAllocation() per call on a one-cell batch                        */
+
+struct rs_ctx {
+  rs_batch* b = nullptr;
+  int16_t *d_map = nullptr, *d_quota = nullptr, *d_target = nullptr;
+  int32_t *d_tbs = nullptr, *d_uinfo = nullptr;
+  uint8_t* d_grid = nullptr;
+  std::vector<uint8_t> h_grid, h_slice;
+  std::vector<int16_t> h_map, h_quota, h_target;
+  std::vector<int32_t> h_tbs, h_uinfo;
+};
+
+extern "C" {
+
+rs_ctx* rs_create(const rs_config* cfg) {
+  rs_batch_config bc;
+  memset(&bc, 0, sizeof bc);
+  if (!cfg) { fail(RS_ERR_INVALID, "null config"); return nullptr; }
+  bc.cell = *cfg;
+  bc.n_cells = 1;
+  bc.cqi_refresh = 1;
+  rs_batch* b = batch_new(&bc, true);
+  if (!b) return nullptr;
+  rs_ctx* c = new (std::nothrow) rs_ctx();
+  if (!c) { rs_batch_destroy(b); fail(RS_ERR_INVALID, "out of memory"); return nullptr; }
+  c->b = b;
+  const int U = b->U, R = b->R, S = b->S;
+  const size_t stride = round_up(U * R, 16);
+  bool ok = hipMalloc(&c->d_map, 2 * R) == hipSuccess && hipMalloc(&c->d_quota, 2 * S) == hipSuccess &&
+            hipMalloc(&c->d_target, 2 * S) == hipSuccess && hipMalloc(&c->d_tbs, 4 * U) == hipSuccess &&
+            hipMalloc(&c->d_uinfo, 4 * U) == hipSuccess && hipMalloc(&c->d_grid, stride) == hipSuccess;
+  if (!ok) { fail(RS_ERR_HIP, "hipMalloc failed"); rs_destroy(c); return nullptr; }
+  c->h_grid.resize(stride); c->h_slice.resize(U);
+  c->h_map.resize(R); c->h_quota.resize(S); c->h_target.resize(S); c->h_tbs.resize(U); c->h_uinfo.resize(U);
+  return c;
+}
+
+void rs_destroy(rs_ctx* c) {
+  if (!c) return;
+  void* ptrs[] = {c->d_map, c->d_quota, c->d_target, c->d_tbs, c->d_uinfo, c->d_grid};
+  if (c->b && c->b->stream) (void)hipStreamSynchronize(c->b->stream);
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  rs_batch_destroy(c->b);
+  delete c;
+}
+
+int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
+  if (!c || !in || !out) return fail(RS_ERR_INVALID, "null argument");
+  rs_batch* b = c->b;
+  const int n = in->n_users, R = b->R, S = b->S;
+  if (n < 1 || n > b->U) return fail(RS_ERR_INVALID, "n_users %d outside 1..%d", n, b->U);
+  if (!in->cqi || !in->avg_rate) return fail(RS_ERR_INVALID, "null cqi/avg_rate");
+  if (!out->rbg_to_user || !out->user_tbs_bits) return fail(RS_ERR_INVALID, "null output array");
+  for (int i = 0; i < n; i++) {
+    int id = in->user_id ? in->user_id[i] : i;
+    if (id < 0 || id >= b->U) return fail(RS_ERR_INVALID, "user id %d out of range", id);
+    if (i && in->user_id && in->user_id[i] <= in->user_id[i - 1]) return fail(RS_ERR_INVALID, "user_id must ascend");
+    c->h_slice[i] = (uint8_t)b->u2s[id];
+    if (b->sched == RS_SCHED_NVS && c->h_slice[i] != c->h_slice[0])
+      return fail(RS_ERR_INVALID, "RS_SCHED_NVS: pass only the users of the served slice");
+  }
+  for (int i = 0; i < n * R; i++)
+    if (in->cqi[i] < 1 || in->cqi[i] > 15) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", in->cqi[i]);
+  const size_t stride = round_up(n * R, 16);
+  memset(c->h_grid.data(), 0, stride);
+  memcpy(c->h_grid.data(), in->cqi, (size_t)n * R);
+  hipStream_t st = b->stream;
+  HIP_TRY(hipMemcpyAsync(c->d_grid, c->h_grid.data(), stride, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(b->d_user_slice, c->h_slice.data(), n, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(b->d_avg, in->avg_rate, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(c->d_tbs, 0, 4 * (size_t)n, st));
+  HIP_TRY(hipMemsetAsync(c->d_uinfo, 0, 4 * (size_t)n, st));
+  RsLaunch L = b->base;
+  L.U = n;
+  L.n_ttis = 1;
+  L.direct = 1;
+  L.rand0 = in->rand0;
+  L.rand1 = in->rand1;
+  L.cqi_mode = RS_CQI_EPOCHS;
+  L.refresh = 1;
+  L.epochs = c->d_grid;
+  L.grid_stride = (int64_t)stride;
+  L.n_epochs = 1 << 30; /* the single grid is re-read on every call */
+  if (b->sched == RS_SCHED_PF) { L.n_seg = (n + RS_PF_SEG - 1) / RS_PF_SEG; L.n_items = R * L.n_seg; }
+  L.log_map = c->d_map; L.log_quota = c->d_quota; L.log_target = c->d_target; L.log_tbs = c->d_tbs; L.log_uinfo = c->d_uinfo;
+  /* one grid only: epoch index must stay 0 -> run with n_done forced to 0 by the direct flag */
+  HIP_TRY(rs_launch_cells(&L, b->threads, st));
+  HIP_TRY(hipMemcpyAsync(c->h_map.data(), c->d_map, 2 * R, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(c->h_quota.data(), c->d_quota, 2 * S, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(c->h_target.data(), c->d_target, 2 * S, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(c->h_tbs.data(), c->d_tbs, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(c->h_uinfo.data(), c->d_uinfo, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int r = 0; r < R; r++) {
+    int o = c->h_map[r];
+    out->rbg_to_user[r] = o < 0 ? -1 : (in->user_id ? in->user_id[o] : o);
+  }
+  for (int s = 0; s < S; s++) {
+    if (out->target_rbs) out->target_rbs[s] = c->h_target[s];
+    if (out->quota_rbgs) out->quota_rbgs[s] = c->h_quota[s];
+  }
+  for (int i = 0; i < n; i++) {
+    int32_t ui = c->h_uinfo[i];
+    if (out->user_nprb) out->user_nprb[i] = ui & 0xFFFF;
+    if (out->user_final_cqi) out->user_final_cqi[i] = (ui >> 16) & 0xFF;
+    if (out->user_mcs) out->user_mcs[i] = (ui >> 24) & 0xFF;
+    out->user_tbs_bits[i] = c->h_tbs[i];
+  }
+  return RS_OK;
+}
+
+int rs_get_slice_offset(rs_ctx* c, double* offset) {
+  if (!c || !offset) return fail(RS_ERR_INVALID, "null argument");
+  HIP_TRY(hipStreamSynchronize(c->b->stream));
+  HIP_TRY(hipMemcpy(offset, c->b->d_sstate, 8 * c->b->S, hipMemcpyDeviceToHost));
+  return RS_OK;
+}
+
+int rs_set_slice_offset(rs_ctx* c, const double* offset) {
+  if (!c || !offset) return fail(RS_ERR_INVALID, "null argument");
+  HIP_TRY(hipStreamSynchronize(c->b->stream));
+  HIP_TRY(hipMemcpy(c->b->d_sstate, offset, 8 * c->b->S, hipMemcpyHostToDevice));
+  return RS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+/*
+ * rs_device.h -- data structures shared by the host side of the C ABI (rs_api.hip) and the
+ * gfx950 kernels (rs_kernels.hip).  Not part of the public interface.
+ */
+#ifndef RS_DEVICE_H_
+#define RS_DEVICE_H_
+
+#include <stdint.h>
+
+#define RS_WAVE 64
+#define RS_PF_SEG 32 /* sched 1: users are scanned in segments of this many for the per-RBG argmax */
+
+/* link-adaptation constants (host libm -> device), see rs_link_tables() in radiosaber_hip.h */
+struct RsTables {
+  double kbps[16];   /* metric numerator of sched 7/8/9: eff*180000/1000              */
+  double pfnum[16];  /* metric numerator of sched 1: eff*180000.                      */
+  double eesm_e[16]; /* E[c] = exp(-10^(SINR[c]/10))                                  */
+  double eesm_x[16]; /* decision thresholds X[1..13]                                  */
+  int32_t mcs_of_cqi[16];
+  int32_t itbs_of_cqi[16];
+  int32_t tbs_row_m1[28]; /* the reference's T[-1][itbs] at -O0 (see rs_kernels.hip)  */
+};
+
+/* per-cell scalar state that survives between launches */
+struct RsCellScalars {
+  double t;            /* simulated time of the next TTI                               */
+  double last_update;  /* RadioBearer::m_lastUpdate (same for every bearer of the cell) */
+  int64_t last_sent;   /* CqiManager::m_lastSent                                       */
+  int32_t reported;    /* first CQI report done                                        */
+  int32_t served_prev; /* UEs served in the previous TTI                               */
+  int64_t n_done;      /* scheduled TTIs so far                                        */
+  int32_t rng_f, rng_b;
+  uint32_t rng_r[32];  /* glibc TYPE_3 ring (31 words used)                            */
+};
+
+enum { RS_CQI_NONE = 0, RS_CQI_EPOCHS = 1, RS_CQI_TRACE = 2 };
+
+/* kernel argument block */
+struct RsLaunch {
+  /* geometry */
+  int32_t S, U, R, G;        /* slices, users, RBGs, PRBs per RBG */
+  int32_t sched;
+  int32_t n_cells, n_ttis;
+  int32_t refresh, phy_draws;
+  int32_t direct;            /* 1: rs_schedule_tti -- avg/rand given, no EWMA, no clock */
+  int32_t rand0, rand1;      /* direct mode */
+  /* configuration (device pointers) */
+  const RsTables* tab;
+  const double* weight;      /* [S] */
+  const int32_t* eps;        /* [S] */
+  const int32_t* psi;        /* [S] */
+  const uint8_t* user_slice; /* [U] */
+  /* state */
+  double* avg;               /* [cells][U] */
+  int32_t* tx_bytes;         /* [cells][U] */
+  int64_t* cum_bytes;        /* [cells][U] */
+  int64_t* cum_rbs;          /* [cells][U] */
+  double* slice_state;       /* [cells][S] slice_rbs_offset_ | slice_ewma_time_ */
+  RsCellScalars* scal;       /* [cells] */
+  /* CQI sources */
+  int32_t cqi_mode;
+  const uint8_t* epochs;     /* [cells][n_epochs][grid_stride] */
+  int64_t grid_stride;       /* bytes per grid, multiple of 16 */
+  int32_t n_epochs;
+  const uint8_t* trace;      /* [n_traces][n_rows][R] */
+  int32_t n_traces, n_rows, row_mod;
+  const int32_t* user_trace; /* [cells][U] */
+  /* optional per-TTI log */
+  int16_t* log_map;          /* [cells][n_ttis][R] */
+  int16_t* log_quota;        /* [cells][n_ttis][S] */
+  int16_t* log_target;       /* [cells][n_ttis][S] */
+  int32_t* log_tbs;          /* [cells][n_ttis][U], pre-zeroed */
+  int32_t* log_uinfo;        /* [cells][n_ttis][U], pre-zeroed: nprb | final_cqi<<16 | mcs<<24 */
+  int32_t* err;              /* device error word */
+  /* LDS carve (byte offsets from the dynamic LDS base) */
+  int32_t off_avgk, off_tx, off_cumb, off_cumr, off_tab, off_slice, off_items, off_elems,
+      off_sorted, off_misc, off_cqi, lds_bytes;
+  int32_t n_seg, n_items;    /* segments per RBG scan, R*n_seg */
+};
+
+#endif /* RS_DEVICE_H_ */

@@ -1,0 +1,185 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+
+Integer outputs (RBG->UE map, quotas, TBS bits, cumulative bytes/RBs) must be identical; the PF
+averages are FP64 and must be bitwise identical too (same IEEE operations in the same order).
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, synth_cqi
+
+pytestmark = pytest.mark.gpu
+
+HIST = (152600, 56656, 270880, 2088792, 3509504, 1595568, 4145392, 5295816, 1903424,
+        6890232, 4770864, 2842552, 3579624, 96000, 1227696)
+
+
+def _oracle_cells(oracle, ues, R, G, sched, weights, grids, seeds, n_ttis, eps=None, psi=None, phy=0):
+    out = []
+    for c in range(grids.shape[0]):
+        cell = oracle.Cell(ues, R, G, sched, weights=weights, epsilon=eps, psi=psi)
+        logs = cell.run_synth(grids[c], int(seeds[c]), n_ttis, phy_error_draws=phy)
+        out.append((logs, cell.state()))
+    return out
+
+
+def _check_batch(rs, oracle, sched, ues, R, G, n_cells, n_ttis, threads=0, eps=None, psi=None, phy=0, seed=1):
+    S = len(ues)
+    weights = [1.0 / S] * S
+    sc = rs.SliceConfig(ues, weight=weights, algo_epsilon=eps or [], algo_psi=psi or [])
+    U = sc.n_users
+    n_epochs = (n_ttis + 39) // 40
+    grids = synth_cqi(seed, (n_cells, n_epochs, U, R), HIST)
+    seeds = np.arange(n_cells, dtype=np.uint32) * 7919 + 805290992
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, phy_error_draws=bool(phy), threads_per_cell=threads)
+    b.seed(seeds)
+    b.upload_cqi_epochs(grids)
+    got = b.run_logged(n_ttis)
+    st = b.state()
+    ref = _oracle_cells(oracle, ues, R, G, sched, weights, grids, seeds, n_ttis, eps, psi, phy)
+    for c in range(n_cells):
+        logs, ost = ref[c]
+        np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"], err_msg=f"cell {c} RBG map")
+        np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"], err_msg=f"cell {c} TBS")
+        np.testing.assert_array_equal(st["cum_bytes"][c], ost["cum_bytes"])
+        np.testing.assert_array_equal(st["cum_rbs"][c], ost["cum_rbs"])
+        assert st["avg_rate"][c].tobytes() == ost["avg_rate"].tobytes(), f"cell {c} PF averages differ"
+        assert st["slice_state"][c].tobytes() == ost["slice_state"].tobytes(), f"cell {c} slice state differs"
+    b.close()
+
+
+@pytest.mark.parametrize("sched", [9, 8, 7, 1])
+def test_small_grid_all_schedulers(rs, oracle, sched):
+    _check_batch(rs, oracle, sched, [5] * 20, 25, 4, n_cells=3, n_ttis=90)
+
+
+@pytest.mark.parametrize("sched", [9, 8, 7, 1])
+def test_shipped_grid_64_rbgs(rs, oracle, sched):
+    _check_batch(rs, oracle, sched, [5] * 20, 64, 8, n_cells=2, n_ttis=85)
+
+
+def test_headline_shape_500_ues_25_rbgs(rs, oracle):
+    _check_batch(rs, oracle, 9, [25] * 20, 25, 4, n_cells=4, n_ttis=120)
+
+
+def test_500_ues_64_rbgs(rs, oracle):
+    _check_batch(rs, oracle, 9, [25] * 20, 64, 8, n_cells=2, n_ttis=60)
+
+
+def test_ragged_slices_and_empty_slice(rs, oracle):
+    # slice 2 has no UE at all, sizes differ
+    _check_batch(rs, oracle, 9, [3, 7, 0, 1, 12], 25, 4, n_cells=2, n_ttis=50)
+    _check_batch(rs, oracle, 8, [3, 7, 0, 1, 12], 25, 4, n_cells=2, n_ttis=50)
+
+
+def test_single_user_single_slice(rs, oracle):
+    _check_batch(rs, oracle, 9, [1], 12, 2, n_cells=1, n_ttis=45)
+
+
+def test_psi_zero_max_rate(rs, oracle):
+    S = 4
+    _check_batch(rs, oracle, 9, [6] * S, 25, 4, n_cells=2, n_ttis=50, eps=[1] * S, psi=[0, 1, 0, 1])
+
+
+def test_phy_error_draws_stream(rs, oracle):
+    _check_batch(rs, oracle, 9, [5] * 20, 64, 8, n_cells=2, n_ttis=60, phy=1)
+
+
+@pytest.mark.parametrize("threads", [64, 128, 512, 1024])
+def test_workgroup_sizes(rs, oracle, threads):
+    _check_batch(rs, oracle, 9, [5] * 20, 25, 4, n_cells=2, n_ttis=45, threads=threads)
+
+
+def test_trace_replay_appendix_a(rs, oracle, traces):
+    """The reference's own run: seed 0, 20x5 UEs, 64 RBGs, mapping0, sched 9."""
+    ka = json.loads((GOLDEN / "appendix_a.json").read_text())
+    cfg = ka["config"]
+    sc = rs.SliceConfig(cfg["ues_per_slice"], weight=[cfg["weight"]] * 20)
+    U = sc.n_users
+    b = rs.BatchScheduler(sc, 64, 8, 1, sched=9, phy_error_draws=True)
+    b.seed(np.array([cfg["seed"]], np.uint32), np.array([cfg["rand_skip"]], np.int64))
+    user_trace = traces["mapping"][0][np.arange(U) % 474][None, :]
+    b.set_trace(traces["cqi"], user_trace)
+    got = b.run_logged(200)
+    first = ka["first_tti"]
+    for s, (t, q) in first["quota"].items():
+        assert got["quota"][0, 0, int(s)] == q
+    for u, info in first["users"].items():
+        rb = np.nonzero(got["rbg_to_user"][0, 0] == int(u))[0].tolist()
+        assert rb == [x[0] for x in info["rbgs"]]
+    assert (got["tbs_bits"][0, 0] > 0).sum() == first["n_users_served"]
+    st = b.state()
+    for u, (cb, cr) in ka["after_200_ttis"]["cumu"].items():
+        assert st["cum_bytes"][0, int(u)] == cb and st["cum_rbs"][0, int(u)] == cr
+    # and the whole run against the oracle
+    cell = oracle.Cell(cfg["ues_per_slice"], 64, 8, 9, weights=[cfg["weight"]] * 20)
+    logs = cell.run_trace(traces["cqi"], traces["mapping"][0], cfg["seed"], cfg["rand_skip"], 200)
+    np.testing.assert_array_equal(got["rbg_to_user"][0], logs["rbg_to_user"])
+    np.testing.assert_array_equal(got["tbs_bits"][0], logs["tbs_bits"])
+    np.testing.assert_array_equal(got["quota"][0], logs["quota"])
+    b.close()
+
+
+def test_device_synth_grids_in_range_and_runs(rs, oracle):
+    ues, R, G = [25] * 20, 25, 4
+    sc = rs.SliceConfig(ues, weight=[0.05] * 20)
+    b = rs.BatchScheduler(sc, R, G, 8, sched=9)
+    seeds = np.arange(8, dtype=np.uint32) + 1
+    b.seed(seeds)
+    b.synthesize_cqi(12345, 3)
+    g = b.download_cqi_epochs(5)
+    assert g.min() >= 1 and g.max() <= 15
+    hist = np.bincount(g.ravel(), minlength=16)[1:] / g.size
+    p = np.asarray(HIST) / np.sum(HIST)
+    assert np.abs(hist - p).max() < 0.02
+    got = b.run_logged(100)
+    cell = oracle.Cell(ues, R, G, 9, weights=[0.05] * 20)
+    logs = cell.run_synth(g, int(seeds[5]), 100)
+    np.testing.assert_array_equal(got["rbg_to_user"][5], logs["rbg_to_user"])
+    np.testing.assert_array_equal(got["tbs_bits"][5], logs["tbs_bits"])
+    # per-slice byte reduction (the vector the multi-GPU run all-reduces)
+    st = b.state()
+    per_slice = np.add.reduceat(st["cum_bytes"].sum(0), np.arange(0, 500, 25))
+    np.testing.assert_array_equal(b.slice_bytes().astype(np.int64), per_slice)
+    b.close()
+
+
+@pytest.mark.parametrize("sched", [9, 8, 1, 7])
+def test_drop_in_single_tti(rs, oracle, sched):
+    """rs_schedule_tti == RBsAllocation() of the oracle, carrying slice_rbs_offset_ across calls."""
+    ues, R, G = [5] * 20, 64, 8
+    sc = rs.SliceConfig(ues, weight=[0.05] * 20)
+    U = sc.n_users
+    ts = rs.TtiScheduler(sc, R, G, sched=sched)
+    cell = oracle.Cell(ues, R, G, sched, weights=[0.05] * 20)
+    rng = np.random.default_rng(3)
+    for it in range(12):
+        cqi = synth_cqi(100 + it, (U, R), HIST)
+        avg = rng.uniform(1e3, 5e6, U)
+        if it % 3 == 0:
+            avg[:] = 98000.0  # exact ties everywhere
+        r0, r1 = int(rng.integers(0, 2**31 - 1)), int(rng.integers(0, 2**31 - 1))
+        if sched == 7:
+            sl = it % 20
+            ids = np.arange(sl * 5, sl * 5 + 5)
+            res = ts.schedule_tti(cqi[ids], avg[ids], user_id=ids)
+            # oracle: NVS allocation within a slice = per RBG first max of the slice metric
+            kb = rs.link_tables()["kbps"]
+            met = kb[cqi[ids]] / ((1 + avg[ids]) / 1000.0)[:, None]
+            exp = ids[np.argmax(met, axis=0)]
+            np.testing.assert_array_equal(res.rbg_to_user, exp)
+            continue
+        cell.set_cqi(cqi)
+        out = cell.new_out()
+        assert cell.allocate(avg, r0, r1, out) == 0
+        res = ts.schedule_tti(cqi, avg, r0, r1)
+        np.testing.assert_array_equal(res.rbg_to_user, out.rbg_to_user)
+        np.testing.assert_array_equal(res.target_rbs, out.target_rbs)
+        np.testing.assert_array_equal(res.quota_rbgs, out.quota_rbgs)
+        np.testing.assert_array_equal(res.user_nprb, out.user_nprb)
+        np.testing.assert_array_equal(res.user_final_cqi, out.user_final_cqi)
+        np.testing.assert_array_equal(res.user_mcs, out.user_mcs)
+        np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits)
+    ts.close()
