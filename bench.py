@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- scheduled TTIs/s of the RadioSaber downlink RBG allocation path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[3]/[4], the batched form of the metric's 20 x 500 x 25 grid):
+every GPU holds `--cells` (512) independent cells of 20 slices x 25 UEs (500 UEs) x 25 RBGs,
+scheduler 9 (RadioSaber / MaximizeCell), PF parameters epsilon=1 psi=1, weights 0.05, backlogged
+flows, synthetic per-RBG CQI drawn i.i.d. from the reference trace corpus' histogram and redrawn
+every 40 TTIs, one libc-compatible rand() stream per cell.  One STEP = one kernel launch that runs
+`--ttis` (400) complete DoSchedule() iterations of every cell; all inputs (the CQI grids of every
+epoch, the cell state) are resident in HBM before the timed region starts.
+
+value = cells_total * ttis * steps / wall time, wall time bracketed by barrier + device sync on
+both sides, max over ranks.  Cells are independent, so ranks share nothing during the run; the only
+collective is the final all-reduce (RCCL) of the per-slice cumulative byte counters uint64[S].
+
+The JSON line also carries
+  roofline     algorithmic bytes (B_TTI = U*R + 16U + 4U + 4R + 16S per cell-TTI) of
+               one launch / that launch's HIP-event duration, against the 8 TB/s HBM3E peak;
+  cpu_baseline the CPU oracle (oracle/, the bit-exact restatement of the reference) timed on this
+               box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes_per_tti(U, R, S):
+    """cqi u8 read + avg read/write + bytes out + rbg->user out + offset in/out."""
+    return U * R + 8 * U + 8 * U + 4 * U + 4 * R + 2 * S * 8
+
+
+def cpu_baseline(args, slices, seeds):
+    """Time the oracle on the host cores: one independent cell per thread (ctypes drops the GIL)."""
+    from oracle import oracle_py as O
+    O.lib()
+    cores = os.cpu_count() or 1
+    hist = np.asarray(args.hist, np.float64)
+    p = hist / hist.sum()
+    U, R = slices.n_users, args.rbgs
+
+    def one(i, n_ttis):
+        rng = np.random.default_rng(1000 + i)
+        grids = rng.choice(np.arange(1, 16, dtype=np.uint8), size=((n_ttis + 39) // 40, U, R), p=p).astype(np.uint8)
+        cell = O.Cell(slices.ues_per_slice, R, args.rbg_size, args.sched, weights=slices.weight)
+        t0 = time.perf_counter()
+        cell.run_synth(grids, int(seeds[i % len(seeds)]), n_ttis, log=False)
+        return time.perf_counter() - t0
+
+    probe = one(0, 200)  # calibrate: seconds per 200 TTIs on one core
+    n_ttis = int(max(200, min(20000, 12.0 / (probe / 200.0))))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda i: one(i, n_ttis), range(cores)))
+    wall = time.perf_counter() - t0
+    return {"value": cores * n_ttis / wall, "unit": "TTIs/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} independent cells x {n_ttis} TTIs of the same workload, one oracle "
+                      f"thread per host core; single core: {200.0 / probe:.0f} TTIs/s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cells", type=int, default=512, help="independent cells per GPU")
+    ap.add_argument("--ttis", type=int, default=400, help="TTIs per step (per launch)")
+    ap.add_argument("--slices", type=int, default=20)
+    ap.add_argument("--ues-per-slice", type=int, default=25)
+    ap.add_argument("--rbgs", type=int, default=25)
+    ap.add_argument("--rbg-size", type=int, default=4)
+    ap.add_argument("--sched", type=int, default=9)
+    ap.add_argument("--threads", type=int, default=0, help="workgroup size per cell (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import radiosaber_amd as rs
+
+    args.hist = rs.TRACE_CQI_HISTOGRAM
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    S, U, R = args.slices, args.slices * args.ues_per_slice, args.rbgs
+    slices = rs.SliceConfig([args.ues_per_slice] * S, weight=[1.0 / S] * S)
+    n_epochs = ((args.steps + args.warmup) * args.ttis + 39) // 40
+    batch = rs.BatchScheduler(slices, R, args.rbg_size, args.cells, sched=args.sched, device=local_rank,
+                              threads_per_cell=args.threads)
+    # cell ids are global: rank r owns cells [r*cells, (r+1)*cells)
+    gids = np.arange(args.cells, dtype=np.uint64) + rank * args.cells
+    seeds = ((gids * 2654435761 + 805290992) % (2**31 - 1)).astype(np.uint32)
+    batch.seed(seeds)
+    batch.synthesize_cqi(0x5AB3 + rank, n_epochs)  # grids generated on the device, stay in HBM
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run(args.ttis)
+    sync_all()
+    t0 = time.perf_counter()
+    ms = batch.run_timed(args.ttis, args.steps)  # K launches, HIP events on the launch stream
+    sync_all()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+
+    # final aggregation: per-slice cumulative bytes, reduced over the GPUs (RCCL over xGMI)
+    slice_bytes = torch.zeros(S, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    batch.slice_bytes_into(slice_bytes.data_ptr())
+    batch.sync()
+    if world > 1:
+        dist.all_reduce(slice_bytes, op=dist.ReduceOp.SUM)
+    total_bytes = int(slice_bytes.sum().item())
+
+    if rank == 0:
+        total_ttis = world * args.cells * args.ttis * args.steps
+        value = total_ttis / wall
+        launch_s = float(np.mean(ms)) / 1e3
+        b_tti = algorithmic_bytes_per_tti(U, R, S)
+        achieved = b_tti * args.cells * args.ttis / launch_s / 1e9
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            tj = json.loads(tfile.read_text())
+            key = f"sched{args.sched}_S{S}_U{U}_R{R}_cells{args.cells}_ttis{args.ttis}"
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "scheduled TTIs/sec (and us/TTI) at 20 slices x 500 UEs x 25 RBGs; HBM GB/s",
+            "value": value, "unit": "TTIs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"sched={args.sched} ({'RadioSaber/MaximizeCell' if args.sched == 9 else 'see --sched'}), "
+                                   f"{args.cells} independent cells per GPU x ({S} slices x {args.ues_per_slice} UEs "
+                                   f"= {U} UEs x {R} RBGs), {args.ttis} TTIs per step, CQI i.i.d. from the trace "
+                                   f"histogram redrawn every 40 TTIs (BASELINE.json configs[3]; configs[4] at 8 GPUs)",
+                       "cells_per_gpu": args.cells, "ttis_per_step": args.ttis, "slices": S, "ues": U, "rbgs": R,
+                       "sched": args.sched, "parallelism": f"cells sharded over {world} GPU(s), no data-path collective"},
+            "us_per_tti_per_cell": launch_s / args.ttis * 1e6,
+            "kernel": batch.kernel_name,
+            "kernel_ms_per_launch": [float(x) for x in ms],
+            "total_slice_bytes": total_bytes,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_cell_tti": b_tti},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, slices, seeds)
+        print(json.dumps(line), flush=True)
+    batch.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
