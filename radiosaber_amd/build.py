@@ -19,7 +19,7 @@ SOURCES = [CSRC / "rs_kernels.hip", CSRC / "rs_api.cpp"]
 DEPS = SOURCES + [CSRC / "rs_device.h", CSRC / "rs_sort_emul.h", CSRC / "rs_amc_tables.inc",
                   PKG.parent / "include" / "radiosaber_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+         "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-missing-braces"]
 
 
 def hipcc():

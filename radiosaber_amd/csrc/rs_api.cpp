@@ -223,7 +223,7 @@ void carve_lds(rs_batch* b, RsLaunch* L) {
   L->off_slice = off; off += 8 * 128;
   L->off_tx = off; off += round_up(4 * U, 16);
   L->off_cumr = off; off += round_up(4 * U, 16);
-  L->off_misc = off; off += round_up((68 + 64 * 6 + 96 + 4) * 4, 16);
+  L->off_misc = off; off += round_up((int)sizeof(RsMisc), 16);
   L->off_elems = off; off += round_up(b->sched == RS_SCHED_PF ? 8 * n_items : 4 * R * S, 16);
   L->off_sorted = off; off += round_up(4 * R * S, 16);
   L->off_items = off; off += round_up(2 * n_items, 16);

@@ -10,6 +10,26 @@
 #define RS_WAVE 64
 #define RS_PF_SEG 32 /* sched 1: users are scanned in segments of this many for the per-RBG argmax */
 
+/* per-cell scratch in LDS (host needs its size for the LDS carve) */
+#define RS_MAX_SEGS 104
+struct RsMisc {
+  int32_t seg_begin[68];
+  int32_t target[64];
+  int32_t quota[64];
+  int32_t got[64];
+  int32_t final_rbgs[64];
+  int32_t rbg_slice[64];
+  int32_t owner[64];
+  int32_t stack[96];             /* serial introsort emulation (debug path) */
+  int32_t n_level[48];           /* parallel introsort: segments queued per recursion level */
+  int16_t q_first[2][RS_MAX_SEGS];
+  int16_t q_last[2][RS_MAX_SEGS];
+  int16_t q_depth[2][RS_MAX_SEGS];
+  int32_t served;
+  int32_t nvs_slice;
+  int32_t pad[2];
+};
+
 /* link-adaptation constants (host libm -> device), see rs_link_tables() in radiosaber_hip.h */
 struct RsTables {
   double kbps[16];   /* metric numerator of sched 7/8/9: eff*180000/1000              */

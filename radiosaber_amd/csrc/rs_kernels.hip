@@ -33,19 +33,7 @@ __device__ const int32_t d_tbs_table[110 * 27] = {RS_AMC_TBS_TABLE};
 
 namespace {
 
-struct Misc {
-  int32_t seg_begin[68];
-  int32_t target[64];
-  int32_t quota[64];
-  int32_t got[64];
-  int32_t final_rbgs[64];
-  int32_t rbg_slice[64];
-  int32_t owner[64];
-  int32_t stack[96];
-  int32_t served;
-  int32_t nvs_slice;
-  int32_t pad[2];
-};
+typedef RsMisc Misc;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
@@ -108,6 +96,117 @@ struct LdsInt {
 };
 
 }  // namespace
+
+/*
+ * std::__introsort_loop, wave-parallel.  Every recursion level's sub-ranges are disjoint, so they
+ * are queued per level and each wave partitions whole sub-ranges; a partition is two passes over
+ * the sub-range in 64-element chunks:
+ *   pass 1  ballots of "left-scan stop" (key <= pivot) and "right-scan stop" (key >= pivot) on the
+ *           array before the partition; prefix popcounts turn them into the stop lists L (ascending)
+ *           and Rr (via posB, read backwards), kept in LDS scratch;
+ *   pass 2  the serial Hoare loop performs exactly the swaps (L[j], Rr[j]) for j < k, k = first j
+ *           with L[j] >= Rr[j], and returns L[0] if k == 0 else min(L[k], Rr[k-1])
+ *           (derivation: DESIGN.md; CPU model: tests/test_partition_model.py).
+ * The median-of-3 pivot move and the (never observed) heap-sort fallback at depth 0 run on one lane
+ * with the serial code of rs_sort_emul.h.  All waves of the workgroup must call this.
+ */
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ void introsort_loop_parallel(uint32_t* v, int N, uint16_t* posA, uint16_t* posB, Misc* m) {
+  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
+  if (threadIdx.x < 48) m->n_level[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0 && N > 16) {
+    m->n_level[0] = 1;
+    m->q_first[0][0] = 0;
+    m->q_last[0][0] = (int16_t)N;
+    m->q_depth[0][0] = (int16_t)(2 * rs_sort::floor_log2(N));
+  }
+  __syncthreads();
+  for (int level = 0; level < 47; ++level) {
+    const int par = level & 1;
+    const int n_cur = m->n_level[level];
+    if (n_cur == 0) break;
+    for (int i = wave; i < n_cur; i += nwaves) {
+      const int first = m->q_first[par][i], last = m->q_last[par][i];
+      int depth = m->q_depth[par][i];
+      if (depth == 0) {
+        if (lane == 0) {
+          LdsArr a{v};
+          rs_sort::heap_sort(a, first, last);
+        }
+        continue;
+      }
+      --depth;
+      if (lane == 0) {
+        LdsArr a{v};
+        rs_sort::median_to_first(a, first, first + 1, first + (last - first) / 2, last - 1);
+      }
+      wave_lds_sync();
+      const int pk = (int)(v[first] >> 16);
+      int cntA = 0, cntB = 0;
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      for (int base = first + 1; base < last; base += 64) {
+        const int x = base + lane;
+        const bool in = x < last;
+        const int k = in ? (int)(v[x] >> 16) : 0;
+        const bool isA = in && k <= pk;
+        const bool isB = in && k >= pk;
+        const unsigned long long mA = __ballot(isA), mB = __ballot(isB);
+        if (isA) posA[first + cntA + __popcll(mA & lt)] = (uint16_t)x;
+        if (isB) posB[first + cntB + __popcll(mB & lt)] = (uint16_t)x;
+        cntA += __popcll(mA);
+        cntB += __popcll(mB);
+      }
+      wave_lds_sync();
+      const int nmin = cntA < cntB ? cntA : cntB;
+      int k = 0;
+      for (int j0 = 0; j0 < nmin; j0 += 64) {
+        const int j = j0 + lane;
+        const bool valid = j < nmin;
+        const int l = valid ? (int)posA[first + j] : 0;
+        const int r = valid ? (int)posB[first + cntB - 1 - j] : 0;
+        const bool sw = valid && l < r;
+        const unsigned long long ms = __ballot(sw);
+        if (sw) {
+          const uint32_t a = v[l], b = v[r];
+          v[l] = b;
+          v[r] = a;
+        }
+        k += __popcll(ms);
+        if (ms != __ballot(valid)) break;
+      }
+      wave_lds_sync();
+      int cut;
+      if (k == 0) {
+        cut = posA[first];
+      } else {
+        const int lk = k < cntA ? (int)posA[first + k] : (1 << 30);
+        const int rk = (int)posB[first + cntB - k]; /* Rr[k-1] */
+        cut = lk < rk ? lk : rk;
+      }
+      if (lane == 0) {
+        if (cut - first > 16) {
+          int s = atomicAdd(&m->n_level[level + 1], 1);
+          m->q_first[par ^ 1][s] = (int16_t)first;
+          m->q_last[par ^ 1][s] = (int16_t)cut;
+          m->q_depth[par ^ 1][s] = (int16_t)depth;
+        }
+        if (last - cut > 16) {
+          int s = atomicAdd(&m->n_level[level + 1], 1);
+          m->q_first[par ^ 1][s] = (int16_t)cut;
+          m->q_last[par ^ 1][s] = (int16_t)last;
+          m->q_depth[par ^ 1][s] = (int16_t)depth;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
 
 template <int SCHED>
 __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
@@ -380,13 +479,17 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
       }
     } else if (SCHED == 9) {
       const int N = R * S;
-      /* std::sort emulation, step 1: the introsort loop (serial, one lane) */
+      /* std::sort emulation, step 1: the introsort loop */
+#ifdef RS_SERIAL_SORT
       if (tid == 0) {
         LdsArr a{s_elems};
         LdsInt st{m->stack};
         rs_sort::introsort_loop(a, N, st);
       }
       __syncthreads();
+#else
+      introsort_loop_parallel(s_elems, N, (uint16_t*)s_sorted, (uint16_t*)s_sorted + N, m);
+#endif
       /* step 2: final insertion sort == stable counting sort by descending key (wave 0) */
       if (wave == 0) {
         int base = 0; /* lane q (< 16): output offset of key q */
