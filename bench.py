@@ -52,19 +52,25 @@ def cpu_baseline(args, slices, seeds):
     p = hist / hist.sum()
     U, R = slices.n_users, args.rbgs
 
-    def one(i, n_ttis):
-        rng = np.random.default_rng(1000 + i)
-        grids = rng.choice(np.arange(1, 16, dtype=np.uint8), size=((n_ttis + 39) // 40, U, R), p=p).astype(np.uint8)
+    rng = np.random.default_rng(1000)
+
+    def grids_for(n_ttis):
+        return rng.choice(np.arange(1, 16, dtype=np.uint8), size=((n_ttis + 39) // 40, U, R), p=p).astype(np.uint8)
+
+    def one(i, grids, n_ttis):
+        # cells differ by their rand() stream; the (read-only) CQI grids are shared between threads
         cell = O.Cell(slices.ues_per_slice, R, args.rbg_size, args.sched, weights=slices.weight)
         t0 = time.perf_counter()
         cell.run_synth(grids, int(seeds[i % len(seeds)]), n_ttis, log=False)
         return time.perf_counter() - t0
 
-    probe = one(0, 200)  # calibrate: seconds per 200 TTIs on one core
-    n_ttis = int(max(200, min(20000, 12.0 / (probe / 200.0))))
+    probe = one(0, grids_for(200), 200)  # calibrate: seconds per 200 TTIs on one core
+    n_ttis = int(max(200, min(40000, 12.0 / (probe / 200.0))))
+    grids = grids_for(n_ttis)
+    cells = [O.Cell(slices.ues_per_slice, R, args.rbg_size, args.sched, weights=slices.weight) for _ in range(cores)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda i: one(i, n_ttis), range(cores)))
+        list(ex.map(lambda i: cells[i].run_synth(grids, int(seeds[i % len(seeds)]), n_ttis, log=False), range(cores)))
     wall = time.perf_counter() - t0
     return {"value": cores * n_ttis / wall, "unit": "TTIs/s", "cores": cores, "kind": "port",
             "sample": f"{cores} independent cells x {n_ttis} TTIs of the same workload, one oracle "
@@ -91,6 +97,7 @@ def main():
     import torch.distributed as dist
 
     import radiosaber_amd as rs
+    from radiosaber_amd import sharding
 
     args.hist = rs.TRACE_CQI_HISTOGRAM
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,10 +120,9 @@ def main():
     batch = rs.BatchScheduler(slices, R, args.rbg_size, args.cells, sched=args.sched, device=local_rank,
                               threads_per_cell=args.threads)
     # cell ids are global: rank r owns cells [r*cells, (r+1)*cells)
-    gids = np.arange(args.cells, dtype=np.uint64) + rank * args.cells
-    seeds = ((gids * 2654435761 + 805290992) % (2**31 - 1)).astype(np.uint32)
+    seeds = sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, args.cells))
     batch.seed(seeds)
-    batch.synthesize_cqi(0x5AB3 + rank, n_epochs)  # grids generated on the device, stay in HBM
+    batch.synthesize_cqi(sharding.cqi_seed_for_cell_block(0x5AB3, rank), n_epochs)  # generated on the device, stay in HBM
 
     def sync_all():
         torch.cuda.synchronize()
@@ -141,8 +147,7 @@ def main():
     torch.cuda.synchronize()
     batch.slice_bytes_into(slice_bytes.data_ptr())
     batch.sync()
-    if world > 1:
-        dist.all_reduce(slice_bytes, op=dist.ReduceOp.SUM)
+    sharding.all_reduce_slice_bytes(slice_bytes, dist if world > 1 else None)
     total_bytes = int(slice_bytes.sum().item())
 
     if rank == 0:

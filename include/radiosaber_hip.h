@@ -193,6 +193,9 @@ int rs_batch_read_state(rs_batch* b, double* avg_rate, int64_t* cum_bytes, int64
  * all-reduces over RCCL (the reference's plot_throughput.py:26-56 sums it per slice post hoc) */
 int rs_batch_slice_bytes_device(rs_batch* b, uint64_t* d_out);
 int rs_batch_slice_bytes(rs_batch* b, uint64_t* h_out /* [S] */);
+/* diagnostics: cycles per kernel phase of one cell's first thread, summed over the last launch;
+ * only in the separate -DRS_STAMPS build (RS_ERR_STATE in the product library) */
+int rs_batch_debug_stamps(rs_batch* b, int32_t cell, uint64_t* out12);
 /* scheduled TTIs completed per cell so far */
 int64_t rs_batch_ttis_done(rs_batch* b);
 /* the hipStream_t the batch launches on */

@@ -10,6 +10,7 @@ The classes keep the reference's vocabulary (slices, UEs, RBGs, TTIs):
 """
 import ctypes as C
 import json
+import os
 from dataclasses import dataclass, field
 from pathlib import Path
 from typing import List, Optional, Sequence
@@ -24,7 +25,7 @@ TRACE_CQI_HISTOGRAM = (152600, 56656, 270880, 2088792, 3509504, 1595568, 4145392
                        6890232, 4770864, 2842552, 3579624, 96000, 1227696)
 
 _PKG = Path(__file__).resolve().parent
-_LIB_PATH = _PKG / "libradiosaber_hip.so"
+_LIB_PATH = Path(os.environ.get("RS_HIP_LIB", _PKG / "libradiosaber_hip.so"))
 
 
 class RadioSaberError(RuntimeError):
@@ -69,7 +70,7 @@ ABI_SYMBOLS = [
     "rs_batch_synthesize_cqi", "rs_batch_download_cqi_epochs", "rs_batch_set_trace",
     "rs_batch_run", "rs_batch_run_async", "rs_batch_sync", "rs_batch_run_logged",
     "rs_batch_run_timed", "rs_batch_read_state", "rs_batch_slice_bytes_device",
-    "rs_batch_slice_bytes", "rs_batch_ttis_done", "rs_batch_stream", "rs_batch_kernel_name",
+    "rs_batch_slice_bytes", "rs_batch_debug_stamps", "rs_batch_ttis_done", "rs_batch_stream", "rs_batch_kernel_name",
 ]
 
 _lib = None
@@ -111,6 +112,7 @@ def lib():
                                       C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.rs_batch_slice_bytes_device.argtypes = [C.c_void_p, C.c_void_p]
     L.rs_batch_slice_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.rs_batch_debug_stamps.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]
     L.rs_batch_ttis_done.restype = C.c_int64
     L.rs_batch_ttis_done.argtypes = [C.c_void_p]
     L.rs_batch_stream.restype = C.c_void_p
@@ -356,6 +358,11 @@ class BatchScheduler:
     def slice_bytes_into(self, device_ptr):
         """Reduce per-slice cumulative bytes into a device buffer (uint64[S]) on the batch's stream."""
         _check(lib().rs_batch_slice_bytes_device(self._h, C.c_void_p(device_ptr)))
+
+    def debug_stamps(self, cell=0):
+        out = np.zeros(12, np.uint64)
+        _check(lib().rs_batch_debug_stamps(self._h, cell, _p(out, C.c_uint64)))
+        return out
 
     @property
     def ttis_done(self):

@@ -36,6 +36,16 @@ def needs_build():
     return any(d.stat().st_mtime > t for d in DEPS)
 
 
+def build_variant(name, defines):
+    """Diagnostic variants (e.g. name='stamps', defines=['-DRS_STAMPS']); never the product library."""
+    out = PKG / f"libradiosaber_hip_{name}.so"
+    cmd = [hipcc()] + FLAGS + list(defines) + [str(s) for s in SOURCES] + ["-o", str(out)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB

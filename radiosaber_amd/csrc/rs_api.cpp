@@ -181,6 +181,7 @@ struct rs_batch {
   int32_t cqi_mode = RS_CQI_NONE;
   int32_t* d_err = nullptr;
   unsigned long long* d_slice_bytes = nullptr;
+  unsigned long long* d_stamps = nullptr;
   int64_t ttis_done = 0;
   RsLaunch base{};
 };
@@ -298,6 +299,10 @@ int batch_alloc(rs_batch* b) {
   HIP_TRY(hipMalloc(&b->d_err, 4));
   HIP_TRY(hipMalloc(&b->d_slice_bytes, 8 * 64));
   HIP_TRY(hipMemset(b->d_err, 0, 4));
+#ifdef RS_STAMPS
+  HIP_TRY(hipMalloc(&b->d_stamps, 8 * 12 * (size_t)b->n_cells));
+  HIP_TRY(hipMemset(b->d_stamps, 0, 8 * 12 * (size_t)b->n_cells));
+#endif
   std::vector<double> avg(cells * U, 100000.0); /* radio-bearer.cpp:54 */
   HIP_TRY(hipMemcpy(b->d_avg, avg.data(), 8 * cells * U, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(b->d_tx, 0, 4 * cells * U));
@@ -317,7 +322,7 @@ int batch_alloc(rs_batch* b) {
   L.tab = b->d_tab; L.weight = b->d_weight; L.eps = b->d_eps; L.psi = b->d_psi;
   L.user_slice = b->d_user_slice;
   L.avg = b->d_avg; L.tx_bytes = b->d_tx; L.cum_bytes = b->d_cumb; L.cum_rbs = b->d_cumr;
-  L.slice_state = b->d_sstate; L.scal = b->d_scal; L.err = b->d_err;
+  L.slice_state = b->d_sstate; L.scal = b->d_scal; L.err = b->d_err; L.stamps = b->d_stamps;
   carve_lds(b, &L);
   if (L.lds_bytes > 160 * 1024) return fail(RS_ERR_INVALID, "cell needs %d B of LDS (> 160 KiB)", L.lds_bytes);
   HIP_TRY(rs_prepare_kernels(160 * 1024));
@@ -358,6 +363,10 @@ int check_device_err(rs_batch* b) {
   HIP_TRY(hipMemcpy(&e, b->d_err, 4, hipMemcpyDeviceToHost));
   if (e) {
     HIP_TRY(hipMemset(b->d_err, 0, 4));
+#ifdef RS_STAMPS
+  HIP_TRY(hipMalloc(&b->d_stamps, 8 * 12 * (size_t)b->n_cells));
+  HIP_TRY(hipMemset(b->d_stamps, 0, 8 * 12 * (size_t)b->n_cells));
+#endif
     return fail(RS_ERR_RANGE, e == RS_CQI_EPOCHS ? "ran past the last CQI epoch" : "trace row outside the uploaded rows");
   }
   return RS_OK;
@@ -388,7 +397,7 @@ void rs_batch_destroy(rs_batch* b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   void* ptrs[] = {b->d_tab, b->d_weight, b->d_eps, b->d_psi, b->d_user_slice, b->d_avg, b->d_tx, b->d_cumb, b->d_cumr,
-                  b->d_sstate, b->d_scal, b->d_epochs, b->d_trace, b->d_user_trace, b->d_err, b->d_slice_bytes};
+                  b->d_sstate, b->d_scal, b->d_epochs, b->d_trace, b->d_user_trace, b->d_err, b->d_slice_bytes, b->d_stamps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -559,6 +568,14 @@ int rs_batch_slice_bytes(rs_batch* b, uint64_t* h_out) {
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(b->stream));
   HIP_TRY(hipMemcpy(h_out, b->d_slice_bytes, 8 * b->S, hipMemcpyDeviceToHost));
+  return RS_OK;
+}
+
+int rs_batch_debug_stamps(rs_batch* b, int32_t cell, uint64_t* out12) {
+  if (!b || !out12 || cell < 0 || cell >= b->n_cells) return fail(RS_ERR_INVALID, "bad argument");
+  if (!b->d_stamps) return fail(RS_ERR_STATE, "not a diagnostic (-DRS_STAMPS) build");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(out12, b->d_stamps + (size_t)cell * 12, 8 * 12, hipMemcpyDeviceToHost));
   return RS_OK;
 }
 

@@ -92,6 +92,7 @@ struct RsLaunch {
   int32_t* log_tbs;          /* [cells][n_ttis][U], pre-zeroed */
   int32_t* log_uinfo;        /* [cells][n_ttis][U], pre-zeroed: nprb | final_cqi<<16 | mcs<<24 */
   int32_t* err;              /* device error word */
+  unsigned long long* stamps; /* diagnostic build (-DRS_STAMPS): [cells][12] phase cycles, else unused */
   /* LDS carve (byte offsets from the dynamic LDS base) */
   int32_t off_avgk, off_tx, off_cumb, off_cumr, off_tab, off_slice, off_items, off_elems,
       off_sorted, off_misc, off_cqi, lds_bytes;

@@ -208,6 +208,21 @@ __device__ void introsort_loop_parallel(uint32_t* v, int N, uint16_t* posA, uint
   }
 }
 
+#ifdef RS_STAMPS
+/* diagnostic build only: cycles per phase of thread 0, accumulated over the launch (never in the
+ * product library; the values go to a buffer nothing else reads) */
+#define RS_STAMP(i)                                                \
+  do {                                                             \
+    if (tid == 0) {                                                \
+      unsigned long long now_ = __builtin_readcyclecounter();      \
+      stamp_acc[i] += now_ - stamp_prev;                           \
+      stamp_prev = now_;                                           \
+    }                                                              \
+  } while (0)
+#else
+#define RS_STAMP(i) do { } while (0)
+#endif
+
 template <int SCHED>
 __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
   extern __shared__ __align__(16) unsigned char lds[];
@@ -283,7 +298,12 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
   int local_err = 0;
   __syncthreads();
 
+#ifdef RS_STAMPS
+  unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_prev = __builtin_readcyclecounter();
+#endif
   for (int tti = 0; tti < p.n_ttis; ++tti) {
+    RS_STAMP(11);
     /* ---------------- P0: CQI refresh ---------------- */
     if (p.cqi_mode == RS_CQI_EPOCHS) {
       if (p.direct || n_done % p.refresh == 0) {
@@ -332,6 +352,7 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
         s_avgk[u] = a;
       }
     }
+    RS_STAMP(0);
     int seg_lo = 0; /* NVS: the served slice */
     /* ---------------- P2: quotas / slice choice (wave 0, lanes = slices) ---------------- */
     if (wave == 0) {
@@ -415,6 +436,7 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
       }
     }
     __syncthreads();
+    RS_STAMP(1);
     if (SCHED == 7) seg_lo = p.direct ? 0 : m->nvs_slice;
 
     /* ---------------- P3: best user of every (RBG, segment) ---------------- */
@@ -459,6 +481,7 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
       (void)n_seg;
     }
     __syncthreads();
+    RS_STAMP(2);
 
     /* ---------------- P4: inter-slice assignment ---------------- */
     if (SCHED == 8) {
@@ -490,6 +513,7 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
 #else
       introsort_loop_parallel(s_elems, N, (uint16_t*)s_sorted, (uint16_t*)s_sorted + N, m);
 #endif
+      RS_STAMP(3);
       /* step 2: final insertion sort == stable counting sort by descending key (wave 0) */
       if (wave == 0) {
         int base = 0; /* lane q (< 16): output offset of key q */
@@ -527,6 +551,7 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
           }
           if (i < N) s_sorted[my_base + rank] = e;
         }
+        RS_STAMP(4);
         /* MaximizeCell greedy scan, ref: :362-369 */
         unsigned long long taken = 0;
         int assigned = 0;
@@ -570,7 +595,9 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
         }
       }
     }
+    RS_STAMP(5);
     __syncthreads();
+    RS_STAMP(6);
 
     /* ---------------- P5: apply, link adaptation, accounting (wave 0, lanes = RBGs) ---------------- */
     if (wave == 0) {
@@ -645,7 +672,9 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
         }
       }
     }
+    RS_STAMP(7);
     __syncthreads();
+    RS_STAMP(8);
     served_prev = m->served;
     n_done += 1;
     if (!p.direct) t += 0.001; /* ref: src/core/eventScheduler/simulator.cc:117-126 */
@@ -670,6 +699,10 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
     scal->rng_f = rng.f;
     scal->rng_b = rng.b;
     if (local_err) atomicExch(p.err, local_err);
+#ifdef RS_STAMPS
+    if (p.stamps)
+      for (int i = 0; i < 12; ++i) p.stamps[(size_t)cell * 12 + i] = stamp_acc[i];
+#endif
   }
 }
 

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of the cell kernel (needs the -DRS_STAMPS build + a GPU).
+
+    RS_HIP_LIB=radiosaber_amd/libradiosaber_hip_stamps.so python tools/phase_stamps.py [--rbgs 25 --rbg-size 4 --sched 9 --threads 256]
+"""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import radiosaber_amd as rs  # noqa: E402
+
+NAMES = ["P0+P1 refresh/EWMA", "P2 quotas (+barrier)", "P3 best user (+barrier)", "P4a introsort loop",
+         "P4b counting sort", "P4c greedy / other P4", "barrier after P4", "P5 apply+link adapt", "barrier after P5",
+         "-", "-", "loop head"]
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cells", type=int, default=512)
+ap.add_argument("--ttis", type=int, default=400)
+ap.add_argument("--rbgs", type=int, default=25)
+ap.add_argument("--rbg-size", type=int, default=4)
+ap.add_argument("--sched", type=int, default=9)
+ap.add_argument("--threads", type=int, default=0)
+ap.add_argument("--ues-per-slice", type=int, default=25)
+a = ap.parse_args()
+sc = rs.SliceConfig([a.ues_per_slice] * 20, weight=[0.05] * 20)
+b = rs.BatchScheduler(sc, a.rbgs, a.rbg_size, a.cells, sched=a.sched, threads_per_cell=a.threads)
+b.seed(np.arange(a.cells, dtype=np.uint32) + 1)
+b.synthesize_cqi(1, (2 * a.ttis + 39) // 40)
+b.run(a.ttis)
+ms = b.run_timed(a.ttis, 1)
+st = np.stack([b.debug_stamps(c) for c in (0, a.cells // 2, a.cells - 1)]).astype(np.float64)
+tot = st.sum(1)
+print(f"launch {ms[0]:.3f} ms, {ms[0] * 1e3 / a.ttis:.2f} us/TTI/cell; cycles/TTI (thread 0): {tot / a.ttis}")
+for i, n in enumerate(NAMES):
+    if n != "-":
+        print(f"  {n:28s} " + "  ".join(f"{st[c, i] / a.ttis:9.0f} ({100 * st[c, i] / tot[c]:4.1f}%)" for c in range(3)))
