@@ -1,0 +1,219 @@
+/*
+ * radiosaber_scheduler.hpp -- C++ host mirror of the reference scheduler's call surface on top of
+ * the C ABI (radiosaber_hip.h).  Header-only; link with -lradiosaber_hip.
+ *
+ * The reference's seam is a class with
+ *     DoSchedule()  { UpdateAverageTransmissionRate(); SelectFlowsToSchedule();
+ *                     if (users) RBsAllocation(); StopSchedule(); }          (downlink-transport-scheduler.cpp:152-168)
+ * operating on LTE-Sim's object graph (RadioBearer, UserToSchedule, PdcchMapIdealControlMessage).
+ * This mirror keeps the method names, their order and their arithmetic but holds the bearers as flat
+ * records, so it compiles without the LTE-Sim tree; INTEGRATION.md shows the thin subclass that
+ * marshals LTE-Sim's objects into it inside the reference tree.
+ *
+ * Errors follow the reference's behaviour: construction problems throw std::runtime_error (the
+ * reference throws on a missing config file, downlink-transport-scheduler.cpp:58-60); per-TTI
+ * failures of the GPU path also throw (the reference asserts).  Single-threaded, non-reentrant,
+ * like the reference.
+ */
+#ifndef RADIOSABER_SCHEDULER_HPP_
+#define RADIOSABER_SCHEDULER_HPP_
+
+#include <cstdint>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "radiosaber_hip.h"
+
+namespace radiosaber {
+
+/* RadioBearer fields the path reads and writes (src/flows/radio-bearer.h:81-85) */
+struct BearerState {
+  double average_transmission_rate = 100000; /* radio-bearer.cpp:54 */
+  int transmitted_bytes = 0;
+  double last_update = 0;
+  unsigned long cumulative_bytes = 0;
+  unsigned long cumulative_rbs = 0;
+  bool has_packets = true; /* InfiniteBuffer: always backlogged */
+};
+
+/* One PDCCH record group: what RBsAllocation() hands to the PHY per scheduled user
+ * (downlink-transport-scheduler.cpp:661-668) */
+struct Allocation {
+  int user_id;
+  std::vector<int> prbs; /* GetListOfAllocatedRBs(), RBG-ascending */
+  int final_cqi, mcs, tbs_bits;
+};
+
+class GpuDownlinkScheduler {
+ public:
+  /* mirrors DownlinkTransportScheduler(config_fname, interslice_algo) after JSON parsing:
+   * ues_per_slice + per-slice weight/alpha/beta/epsilon/psi; sched = RS_SCHED_* */
+  GpuDownlinkScheduler(const std::vector<int>& ues_per_slice, const std::vector<double>& weight,
+                       const std::vector<int>& alpha, const std::vector<int>& beta,
+                       const std::vector<int>& epsilon, const std::vector<int>& psi, int nb_rbs, int rbg_size,
+                       int sched, int device = 0)
+      : num_slices_((int)ues_per_slice.size()), rbg_size_(rbg_size), sched_(sched), weight_(weight),
+        alpha_(alpha), beta_(beta), eps_(epsilon), psi_(psi) {
+    for (int s = 0; s < num_slices_; ++s)
+      for (int j = 0; j < ues_per_slice[s]; ++j) user_to_slice_.push_back(s);
+    nb_rbs_ = nb_rbs - (nb_rbs % rbg_size); /* :460 */
+    nb_rbgs_ = nb_rbs_ / rbg_size;
+    bearers_.resize(user_to_slice_.size());
+    cqi_.assign(user_to_slice_.size() * (size_t)nb_rbgs_, 10); /* ENodeB.cpp:212-217 */
+    slice_ewma_time_.assign(num_slices_, 0.0);
+    rs_config c{};
+    c.n_slices = num_slices_;
+    c.n_users = (int)user_to_slice_.size();
+    c.n_rbgs = nb_rbgs_;
+    c.rbg_size = rbg_size;
+    c.sched = sched;
+    c.device = device;
+    c.slice_weight = weight_.data();
+    c.algo_alpha = alpha_.data();
+    c.algo_beta = beta_.data();
+    c.algo_epsilon = eps_.data();
+    c.algo_psi = psi_.data();
+    c.user_to_slice = user_to_slice_.data();
+    ctx_ = rs_create(&c);
+    if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
+  }
+  ~GpuDownlinkScheduler() { rs_destroy(ctx_); }
+  GpuDownlinkScheduler(const GpuDownlinkScheduler&) = delete;
+  GpuDownlinkScheduler& operator=(const GpuDownlinkScheduler&) = delete;
+
+  /* ENodeB::UserEquipmentRecord::SetCQI at RBG granularity (enb-mac-entity.cc:189-191) */
+  void SetCQI(int user_id, const uint8_t* cqi_per_rbg) {
+    for (int r = 0; r < nb_rbgs_; ++r) cqi_[(size_t)user_id * nb_rbgs_ + r] = cqi_per_rbg[r];
+  }
+  BearerState& Bearer(int user_id) { return bearers_[user_id]; }
+  unsigned long GetTimeStamp() const { return ts_; }
+  const std::vector<Allocation>& LastAllocations() const { return allocations_; }
+  const std::vector<int>& SliceTargetRbs() const { return target_; }
+  const std::vector<int>& SliceQuotaRbgs() const { return quota_; }
+
+  /* PacketScheduler::Schedule() -> DoSchedule()  (packet-scheduler.cpp:72-90);
+   * now = Simulator::Init()->Now() */
+  void DoSchedule(double now) {
+    int slice_serve = -1;
+    if (sched_ == RS_SCHED_NVS) slice_serve = SelectSliceToServe(); /* before the EWMA update (nvs :207-208) */
+    UpdateAverageTransmissionRate(now);
+    SelectFlowsToSchedule(slice_serve);
+    allocations_.clear();
+    if (!users_.empty()) RBsAllocation();
+    DoStopSchedule();
+  }
+
+  /* radio-bearer.cpp:139-164 for every bearer (downlink-transport-scheduler.cpp:715-727) */
+  void UpdateAverageTransmissionRate(double now) {
+    for (BearerState& b : bearers_) {
+      if (now == b.last_update) continue;
+      double rate = (b.transmitted_bytes * 8) / (now - b.last_update);
+      double beta = 0.02;
+      b.average_transmission_rate = ((1 - beta) * b.average_transmission_rate) + (beta * rate);
+      if (b.average_transmission_rate < 1) b.average_transmission_rate = 1;
+      b.transmitted_bytes = 0;
+      b.last_update = now;
+    }
+  }
+
+  /* downlink-nvs-scheduler.cpp:94-142 */
+  int SelectSliceToServe() {
+    std::vector<bool> with_queue(num_slices_, false);
+    for (size_t u = 0; u < bearers_.size(); ++u)
+      if (bearers_[u].has_packets) with_queue[user_to_slice_[u]] = true;
+    int slice_id = 0;
+    double max_score = 0;
+    for (int i = 0; i < num_slices_; ++i) {
+      if (!with_queue[i]) continue;
+      if (slice_ewma_time_[i] == 0) { slice_id = i; break; }
+      double score = weight_[i] / slice_ewma_time_[i];
+      if (score >= max_score) { max_score = score; slice_id = i; }
+    }
+    const double beta = 0.01;
+    for (int i = 0; i < num_slices_; ++i) {
+      if (!with_queue[i]) continue;
+      slice_ewma_time_[i] = (1 - beta) * slice_ewma_time_[i];
+      if (i == slice_id) slice_ewma_time_[i] += beta * 1;
+    }
+    return slice_id;
+  }
+
+  /* downlink-transport-scheduler.cpp:105-150: users with queued data, first-seen (= id) order */
+  void SelectFlowsToSchedule(int slice_serve = -1) {
+    users_.clear();
+    for (size_t u = 0; u < bearers_.size(); ++u) {
+      if (!bearers_[u].has_packets) continue;
+      if (slice_serve >= 0 && user_to_slice_[u] != slice_serve) continue;
+      users_.push_back((int)u);
+    }
+  }
+
+  /* downlink-transport-scheduler.cpp:453-675 -- on the GPU through the C ABI.
+   * Draws the two rand() values exactly where the reference does (:490, :511). */
+  void RBsAllocation() {
+    const int n = (int)users_.size();
+    in_cqi_.resize((size_t)n * nb_rbgs_);
+    in_avg_.resize(n);
+    for (int i = 0; i < n; ++i) {
+      const int u = users_[i];
+      for (int r = 0; r < nb_rbgs_; ++r) in_cqi_[(size_t)i * nb_rbgs_ + r] = cqi_[(size_t)u * nb_rbgs_ + r];
+      in_avg_[i] = bearers_[u].average_transmission_rate;
+    }
+    rs_tti_in in{};
+    in.n_users = n;
+    in.user_id = users_.data();
+    in.cqi = in_cqi_.data();
+    in.avg_rate = in_avg_.data();
+    if (sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL) {
+      in.rand0 = rand();
+      in.rand1 = rand();
+    }
+    target_.assign(num_slices_, 0);
+    quota_.assign(num_slices_, 0);
+    rbg_to_user_.assign(nb_rbgs_, -1);
+    nprb_.assign(n, 0); fcqi_.assign(n, 0); mcs_.assign(n, 0); tbs_.assign(n, 0);
+    rs_tti_out out{target_.data(), quota_.data(), rbg_to_user_.data(), nprb_.data(), fcqi_.data(), mcs_.data(), tbs_.data()};
+    if (rs_schedule_tti(ctx_, &in, &out) != RS_OK) throw std::runtime_error(std::string("rs_schedule_tti: ") + rs_last_error());
+    for (int i = 0; i < n; ++i) {
+      if (nprb_[i] == 0) continue;
+      Allocation a{users_[i], {}, fcqi_[i], mcs_[i], tbs_[i]};
+      for (int r = 0; r < nb_rbgs_; ++r)
+        if (rbg_to_user_[r] == users_[i])
+          for (int k = r * rbg_size_; k < (r + 1) * rbg_size_; ++k) a.prbs.push_back(k);
+      allocations_.push_back(a);
+    }
+  }
+
+  /* downlink-transport-scheduler.cpp:170-221 (one InfiniteBuffer bearer per user: dataToTransmit = 1e8) */
+  void DoStopSchedule() {
+    for (const Allocation& a : allocations_) {
+      int available = a.tbs_bits / 8;
+      if (available <= 0) continue;
+      int sent = available < 100000000 ? available : 100000000;
+      BearerState& b = bearers_[a.user_id];
+      b.transmitted_bytes += sent;
+      b.cumulative_bytes += sent;
+      b.cumulative_rbs += a.prbs.size();
+    }
+    ts_++;
+  }
+
+ private:
+  int num_slices_, rbg_size_, sched_, nb_rbs_ = 0, nb_rbgs_ = 0;
+  std::vector<double> weight_;
+  std::vector<int> alpha_, beta_, eps_, psi_, user_to_slice_;
+  std::vector<double> slice_ewma_time_;
+  std::vector<BearerState> bearers_;
+  std::vector<uint8_t> cqi_, in_cqi_;
+  std::vector<double> in_avg_;
+  std::vector<int> users_, target_, quota_, rbg_to_user_, nprb_, fcqi_, mcs_, tbs_;
+  std::vector<Allocation> allocations_;
+  unsigned long ts_ = 0;
+  rs_ctx* ctx_ = nullptr;
+};
+
+}  // namespace radiosaber
+
+#endif /* RADIOSABER_SCHEDULER_HPP_ */

@@ -1,0 +1,45 @@
+"""The C++ adapter with the reference's method names (include/radiosaber_scheduler.hpp)."""
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _build(tmp_path, rs):
+    exe = tmp_path / "adapter_check"
+    lib_dir = ROOT / "radiosaber_amd"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-o", str(exe),
+                    str(ROOT / "tests" / "csrc" / "adapter_check.cpp"), f"-L{lib_dir}", "-lradiosaber_hip",
+                    f"-Wl,-rpath,{lib_dir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def test_adapter_compiles_and_links_against_the_c_abi(tmp_path, rs):
+    assert _build(tmp_path, rs).exists()
+
+
+@pytest.mark.gpu
+def test_adapter_replays_the_reference_run(tmp_path, rs, traces):
+    """Drop-in mode, one rs_schedule_tti per TTI, real libc rand(): SURVEY.md Appendix A values."""
+    ka = json.loads((GOLDEN / "appendix_a.json").read_text())
+    exe = _build(tmp_path, rs)
+    per_user = traces["cqi"][traces["mapping"][0][np.arange(100) % 474]]  # [100][40][64]
+    tf = tmp_path / "trace.bin"
+    tf.write_bytes(np.ascontiguousarray(per_user, np.uint8).tobytes())
+    out = subprocess.run([str(exe), str(tf), "40", str(ka["config"]["rand_skip"]), "200"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().split("\n")
+    assert "first 1 final_cqi 15 rbgs 57" in lines
+    assert "first 4 final_cqi 15 rbgs 14 32" in lines
+    assert "first 47 final_cqi 8 rbgs 42 45" in lines
+    assert "served 34 quota16 37 4" in lines
+    for u, (cb, cr) in ka["after_200_ttis"]["cumu"].items():
+        assert f"cumu {u} {cb} {cr}" in lines
+    assert "ts 200" in lines
