@@ -167,6 +167,7 @@ struct rs_batch {
   double* d_weight = nullptr;
   int32_t *d_eps = nullptr, *d_psi = nullptr;
   uint8_t* d_user_slice = nullptr;
+  int32_t* d_tbs_eff = nullptr;
   double* d_avg = nullptr;
   int32_t* d_tx = nullptr;
   int64_t *d_cumb = nullptr, *d_cumr = nullptr;
@@ -219,12 +220,14 @@ void carve_lds(rs_batch* b, RsLaunch* L) {
   int off = 0;
   off += 8 * U;               /* avg */
   L->off_avgk = off; off += 8 * U;
+  L->off_rcp = off; off += round_up(4 * U, 16);
   L->off_cumb = off; off += 8 * U;
-  L->off_tab = off; off += 8 * 48;
+  L->off_tab = off; off += 8 * 48 + 64;
   L->off_slice = off; off += 8 * 128;
   L->off_tx = off; off += round_up(4 * U, 16);
   L->off_cumr = off; off += round_up(4 * U, 16);
   L->off_misc = off; off += round_up((int)sizeof(RsMisc), 16);
+  L->off_tbs = off; off += round_up(4 * 27 * (R + 1), 16);
   L->off_elems = off; off += round_up(b->sched == RS_SCHED_PF ? 8 * n_items : 4 * R * S, 16);
   L->off_sorted = off; off += round_up(4 * R * S, 16);
   L->off_items = off; off += round_up(2 * n_items, 16);
@@ -290,6 +293,20 @@ int batch_alloc(rs_batch* b) {
   for (size_t u = 0; u < U; u++) us[u] = (uint8_t)b->u2s[u];
   HIP_TRY(hipMalloc(&b->d_user_slice, U));
   HIP_TRY(hipMemcpy(b->d_user_slice, us.data(), U, hipMemcpyHostToDevice));
+  {
+    /* TBS bits of n RBGs = n*G PRBs per itbs (AMCModule.cpp:306-317); row 0 unused */
+    std::vector<int32_t> te((size_t)(b->R + 1) * 27, 0);
+    for (int n = 1; n <= b->R; n++)
+      for (int i = 0; i < 27; i++) {
+        const int nprb = n * b->G;
+        int v;
+        if (nprb <= 110) v = kTbs[nprb - 1][i];
+        else v = 5 * kTbs[nprb / 5 - 1][i] + (nprb % 5 == 0 ? t.tbs_row_m1[i] : kTbs[nprb % 5 - 1][i]);
+        te[(size_t)n * 27 + i] = v;
+      }
+    HIP_TRY(hipMalloc(&b->d_tbs_eff, 4 * te.size()));
+    HIP_TRY(hipMemcpy(b->d_tbs_eff, te.data(), 4 * te.size(), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMalloc(&b->d_avg, 8 * cells * U));
   HIP_TRY(hipMalloc(&b->d_tx, 4 * cells * U));
   HIP_TRY(hipMalloc(&b->d_cumb, 8 * cells * U));
@@ -321,6 +338,7 @@ int batch_alloc(rs_batch* b) {
   L.phy_draws = b->cfg.phy_error_draws;
   L.tab = b->d_tab; L.weight = b->d_weight; L.eps = b->d_eps; L.psi = b->d_psi;
   L.user_slice = b->d_user_slice;
+  L.tbs_eff = b->d_tbs_eff;
   L.avg = b->d_avg; L.tx_bytes = b->d_tx; L.cum_bytes = b->d_cumb; L.cum_rbs = b->d_cumr;
   L.slice_state = b->d_sstate; L.scal = b->d_scal; L.err = b->d_err; L.stamps = b->d_stamps;
   carve_lds(b, &L);
@@ -396,7 +414,7 @@ rs_batch* rs_batch_create(const rs_batch_config* cfg) { return batch_new(cfg, fa
 void rs_batch_destroy(rs_batch* b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void* ptrs[] = {b->d_tab, b->d_weight, b->d_eps, b->d_psi, b->d_user_slice, b->d_avg, b->d_tx, b->d_cumb, b->d_cumr,
+  void* ptrs[] = {b->d_tab, b->d_weight, b->d_eps, b->d_psi, b->d_user_slice, b->d_tbs_eff, b->d_avg, b->d_tx, b->d_cumb, b->d_cumr,
                   b->d_sstate, b->d_scal, b->d_epochs, b->d_trace, b->d_user_trace, b->d_err, b->d_slice_bytes, b->d_stamps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

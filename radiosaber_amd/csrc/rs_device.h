@@ -11,7 +11,7 @@
 #define RS_PF_SEG 32 /* sched 1: users are scanned in segments of this many for the per-RBG argmax */
 
 /* per-cell scratch in LDS (host needs its size for the LDS carve) */
-#define RS_MAX_SEGS 104
+#define RS_MAX_SEGS 256 /* > 4096/17 sub-ranges longer than 16 on one recursion level */
 struct RsMisc {
   int32_t seg_begin[68];
   int32_t target[64];
@@ -25,6 +25,9 @@ struct RsMisc {
   int16_t q_first[2][RS_MAX_SEGS];
   int16_t q_last[2][RS_MAX_SEGS];
   int16_t q_depth[2][RS_MAX_SEGS];
+  uint16_t hist[64 * 16];        /* counting sort: per 64-element chunk, per key */
+  int32_t mcs_of_cqi[16];
+  int32_t itbs_of_cqi[16];
   int32_t served;
   int32_t nvs_slice;
   int32_t pad[2];
@@ -70,6 +73,7 @@ struct RsLaunch {
   const int32_t* eps;        /* [S] */
   const int32_t* psi;        /* [S] */
   const uint8_t* user_slice; /* [U] */
+  const int32_t* tbs_eff;    /* [R+1][27] TBS bits of n RBGs (n*G PRBs) at itbs, incl. the >110-PRB rule */
   /* state */
   double* avg;               /* [cells][U] */
   int32_t* tx_bytes;         /* [cells][U] */
@@ -94,8 +98,8 @@ struct RsLaunch {
   int32_t* err;              /* device error word */
   unsigned long long* stamps; /* diagnostic build (-DRS_STAMPS): [cells][12] phase cycles, else unused */
   /* LDS carve (byte offsets from the dynamic LDS base) */
-  int32_t off_avgk, off_tx, off_cumb, off_cumr, off_tab, off_slice, off_items, off_elems,
-      off_sorted, off_misc, off_cqi, lds_bytes;
+  int32_t off_avgk, off_rcp, off_tx, off_cumb, off_cumr, off_tab, off_slice, off_items, off_elems,
+      off_sorted, off_misc, off_tbs, off_cqi, lds_bytes;
   int32_t n_seg, n_items;    /* segments per RBG scan, R*n_seg */
 };
 

@@ -23,13 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "rs_amc_tables.inc"
 #include "rs_device.h"
 #include "rs_sort_emul.h"
-
-/* 3GPP TS 36.213 Table 7.1.7.2.1-1 (110 x 27 ints, 11.9 KB): read through the vector cache, a few
- * lookups per TTI */
-__device__ const int32_t d_tbs_table[110 * 27] = {RS_AMC_TBS_TABLE};
 
 namespace {
 
@@ -38,29 +33,47 @@ typedef RsMisc Misc;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    int w = __shfl_xor(v, o, 64);
-    v = w > v ? w : v;
+/* wave64 reductions on the DPP network (row_shr 1/2/4/8 inside rows of 16, then row_bcast15 and
+ * row_bcast31 across rows); the total lands in lane 63 and is broadcast with v_readlane.
+ * A lane masked off by the bank/row mask contributes the identity. */
+#define RS_DPP_STEP(OP, ctrl, rmask, bmask) \
+  v = OP(v, __builtin_amdgcn_update_dpp(identity, v, ctrl, rmask, bmask, false))
+__device__ __forceinline__ int op_add(int a, int b) { return a + b; }
+__device__ __forceinline__ int op_max(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int op_min(int a, int b) { return a < b ? a : b; }
+#define RS_DEFINE_WAVE_REDUCE(NAME, OP, IDENT)                 \
+  __device__ __forceinline__ int NAME(int v) {                 \
+    const int identity = IDENT;                                \
+    RS_DPP_STEP(OP, 0x111, 0xf, 0xf); /* row_shr:1 */          \
+    RS_DPP_STEP(OP, 0x112, 0xf, 0xf); /* row_shr:2 */          \
+    RS_DPP_STEP(OP, 0x114, 0xf, 0xe); /* row_shr:4 */          \
+    RS_DPP_STEP(OP, 0x118, 0xf, 0xc); /* row_shr:8 */          \
+    RS_DPP_STEP(OP, 0x142, 0xa, 0xf); /* row_bcast:15 */       \
+    RS_DPP_STEP(OP, 0x143, 0xc, 0xf); /* row_bcast:31 */       \
+    return __builtin_amdgcn_readlane(v, 63);                   \
   }
-  return v;
-}
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    int w = __shfl_xor(v, o, 64);
-    v = w < v ? w : v;
-  }
-  return v;
-}
+RS_DEFINE_WAVE_REDUCE(wave_sum, op_add, 0)
+RS_DEFINE_WAVE_REDUCE(wave_max, op_max, (int)0x80000000)
+RS_DEFINE_WAVE_REDUCE(wave_min, op_min, 0x7fffffff)
 
-/* glibc TYPE_3 rand(): ring of 31 words held one per lane of wave 0 (lane l = r[l]); f, b uniform.
+/* lanes that hold the same BITS-bit value as this lane (valid lanes only): one ballot per bit */
+template <int BITS>
+struct BitBallots {
+  unsigned long long valid, b[BITS];
+  __device__ __forceinline__ void gather(int v, bool is_valid) {
+    valid = __ballot(is_valid);
+#pragma unroll
+    for (int i = 0; i < BITS; ++i) b[i] = __ballot(((v >> i) & 1) != 0);
+  }
+  __device__ __forceinline__ unsigned long long lanes_with(int v) const {
+    unsigned long long mk = valid;
+#pragma unroll
+    for (int i = 0; i < BITS; ++i) mk &= ((v >> i) & 1) ? b[i] : ~b[i];
+    return mk;
+  }
+};
+
+/* glibc TYPE_3 rand(): ring of 31 words held one per lane of one wave (lane l = r[l]); f, b uniform.
  * (glibc 2.35 stdlib/random_r.c __random_r; the reference draws from libc rand():
  *  downlink-transport-scheduler.cpp:490,511) */
 struct WaveRng {
@@ -76,15 +89,6 @@ struct WaveRng {
     return (int)(v >> 1);
   }
 };
-
-/* ref: src/protocolStack/mac/AMCModule.cpp:306-317 incl. the as-shipped -O0 out-of-bounds rule
- * T[-1][i], carried in tab->tbs_row_m1 */
-__device__ __forceinline__ int tbs_bits(int itbs, int nprb, const int32_t* row_m1) {
-  if (nprb <= 110) return d_tbs_table[(nprb - 1) * 27 + itbs];
-  int sub = nprb / 5, rest = nprb % 5;
-  int tail = rest == 0 ? row_m1[itbs] : d_tbs_table[(rest - 1) * 27 + itbs];
-  return 5 * d_tbs_table[(sub - 1) * 27 + itbs] + tail;
-}
 
 struct LdsArr {
   uint32_t* p;
@@ -208,6 +212,56 @@ __device__ void introsort_loop_parallel(uint32_t* v, int N, uint16_t* posA, uint
   }
 }
 
+/*
+ * std::__final_insertion_sort == stable sort of the array the introsort loop leaves (a stable order
+ * is unique): 16-bucket stable counting sort by DESCENDING key, all waves.
+ *   A  every wave, for its 64-element chunks: per-key counts (lane q holds key q) -> hist[chunk][q]
+ *   B  wave 0: hist[chunk][q] <- first output slot of key q in that chunk
+ *   C  every wave: slot = hist[chunk][key] + (same-key lanes below me); scatter to `out`
+ */
+__device__ void counting_sort_desc(const uint32_t* v, uint32_t* out, int N, Misc* m) {
+  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
+  const int n_chunks = (N + 63) >> 6;
+  for (int c = wave; c < n_chunks; c += nwaves) {
+    const int i = (c << 6) + lane;
+    const int k = i < N ? (int)(v[i] >> 16) : 0;
+    BitBallots<4> bb;
+    bb.gather(k, i < N);
+    if (lane < 16) m->hist[c * 16 + lane] = (uint16_t)__popcll(bb.lanes_with(lane));
+  }
+  __syncthreads();
+  if (wave == 0) {
+    int total = 0;
+    if (lane < 16)
+      for (int c = 0; c < n_chunks; ++c) total += m->hist[c * 16 + lane];
+    int run = 0, acc = 0;
+#pragma unroll
+    for (int q = 15; q >= 0; --q) {
+      int tq = __builtin_amdgcn_readlane(total, q);
+      if (lane == q) run = acc;
+      acc += tq;
+    }
+    if (lane < 16)
+      for (int c = 0; c < n_chunks; ++c) {
+        int h = m->hist[c * 16 + lane];
+        m->hist[c * 16 + lane] = (uint16_t)run;
+        run += h;
+      }
+  }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int c = wave; c < n_chunks; c += nwaves) {
+    const int i = (c << 6) + lane;
+    const uint32_t e = i < N ? v[i] : 0;
+    const int k = (int)(e >> 16);
+    BitBallots<4> bb;
+    bb.gather(k, i < N);
+    const int rank = __popcll(bb.lanes_with(k) & lt);
+    if (i < N) out[m->hist[c * 16 + k] + rank] = e;
+  }
+  __syncthreads();
+}
+
 #ifdef RS_STAMPS
 /* diagnostic build only: cycles per phase of thread 0, accumulated over the launch (never in the
  * product library; the values go to a buffer nothing else reads) */
@@ -228,18 +282,21 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
   extern __shared__ __align__(16) unsigned char lds[];
   const int cell = blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int lane = lane_id(), wave = wave_id();
+  const int lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
   const int S = p.S, U = p.U, R = p.R, G = p.G;
   constexpr bool kTransport = (SCHED == 8 || SCHED == 9);
+  const int quota_wave = nwaves - 1; /* P2 runs on the last wave, beside the other waves' P3 */
 
   double* s_avg = (double*)lds;
   double* s_avgk = (double*)(lds + p.off_avgk);
+  float* s_rcp32 = (float*)(lds + p.off_rcp);
   int32_t* s_tx = (int32_t*)(lds + p.off_tx);
   int64_t* s_cumb = (int64_t*)(lds + p.off_cumb);
   int32_t* s_cumr = (int32_t*)(lds + p.off_cumr);
   double* s_num = (double*)(lds + p.off_tab); /* metric numerator per CQI */
   double* s_e = s_num + 16;
   double* s_x = s_e + 16;
+  float* s_num32 = (float*)(s_x + 16);
   double* s_w = (double*)(lds + p.off_slice);
   double* s_sstate = s_w + 64;
   uint16_t* s_best_user = (uint16_t*)(lds + p.off_items);
@@ -247,6 +304,7 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
   uint32_t* s_elems = (uint32_t*)(lds + p.off_elems);
   uint32_t* s_sorted = (uint32_t*)(lds + p.off_sorted);
   Misc* m = (Misc*)(lds + p.off_misc);
+  int32_t* s_tbs = (int32_t*)(lds + p.off_tbs); /* [R+1][27] TBS bits of n RBGs at itbs */
   uint8_t* s_cqi = lds + p.off_cqi;
 
   const RsTables* tab = p.tab;
@@ -259,10 +317,14 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
     s_cumb[u] = 0;
     s_cumr[u] = 0;
   }
+  for (int i = tid; i < (R + 1) * 27; i += nt) s_tbs[i] = p.tbs_eff[i];
   if (tid < 16) {
     s_num[tid] = SCHED == 1 ? tab->pfnum[tid] : tab->kbps[tid];
     s_e[tid] = tab->eesm_e[tid];
     s_x[tid] = tab->eesm_x[tid];
+    s_num32[tid] = (float)(SCHED == 1 ? tab->pfnum[tid] : tab->kbps[tid]);
+    m->mcs_of_cqi[tid] = tab->mcs_of_cqi[tid];
+    m->itbs_of_cqi[tid] = tab->itbs_of_cqi[tid];
   }
   if (tid < S) {
     s_w[tid] = p.weight[tid];
@@ -293,7 +355,7 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
   rng.r = 0;
   rng.f = scal->rng_f;
   rng.b = scal->rng_b;
-  if (wave == 0 && lane < 31) rng.r = scal->rng_r[lane];
+  if (wave == quota_wave && lane < 31) rng.r = scal->rng_r[lane];
   const int nb_rbs = R * G;
   int local_err = 0;
   __syncthreads();
@@ -331,41 +393,48 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
       }
     }
     /* ---------------- P1: PF EWMA (ref: src/flows/radio-bearer.cpp:139-164) ---------------- */
-    if (!p.direct && !(t == last_update)) {
+    {
+      const bool do_ewma = !p.direct && !(t == last_update);
       const double dt = t - last_update;
       for (int u = tid; u < U; u += nt) {
-        double rate = (double)(s_tx[u] * 8) / dt;
-        const double beta = 0.02;
-        double a = ((1 - beta) * s_avg[u]) + (beta * rate);
-        if (a < 1) a = 1;
-        s_avg[u] = a;
-        s_tx[u] = 0;
+        double a = s_avg[u];
+        if (do_ewma) {
+          double rate = (double)(s_tx[u] * 8) / dt;
+          const double beta = 0.02;
+          a = ((1 - beta) * a) + (beta * rate);
+          if (a < 1) a = 1;
+          s_avg[u] = a;
+          s_tx[u] = 0;
+        }
+        if (SCHED != 1) {
+          /* ref: :685-689  averageRate = 1 + sum(avg); averageRate /= 1000.0 */
+          double k = 1;
+          k += a;
+          k /= 1000.0;
+          s_avgk[u] = k;
+          s_rcp32[u] = (float)(1.0 / k); /* stage-1 ranking only, never part of a result */
+        } else {
+          s_rcp32[u] = (float)(1.0 / a);
+        }
       }
+      if (!p.direct) last_update = t;
     }
-    if (!p.direct) last_update = t;
-    if (SCHED != 1) {
-      /* ref: :685-689  averageRate = 1 + sum(avg); averageRate /= 1000.0 */
-      for (int u = tid; u < U; u += nt) {
-        double a = 1;
-        a += s_avg[u];
-        a /= 1000.0;
-        s_avgk[u] = a;
-      }
-    }
+    __syncthreads();
     RS_STAMP(0);
-    int seg_lo = 0; /* NVS: the served slice */
-    /* ---------------- P2: quotas / slice choice (wave 0, lanes = slices) ---------------- */
-    if (wave == 0) {
+
+    /* ---------------- P2: quotas / slice choice (one wave, lanes = slices) ---------------- */
+    if (wave == quota_wave) {
       int r0 = p.rand0, r1 = p.rand1;
-      if (!p.direct && kTransport) {
+      if (!p.direct) {
         if (p.phy_draws)
           for (int i = 0; i < served_prev; i++) (void)rng.next();
-        r0 = rng.next();
-        r1 = rng.next();
-      } else if (!p.direct && p.phy_draws) {
-        for (int i = 0; i < served_prev; i++) (void)rng.next();
+        if (kTransport) {
+          r0 = rng.next();
+          r1 = rng.next();
+        }
       }
       if (kTransport) {
+        /* ref: :463-521 */
         const bool in = lane < S;
         const bool has = in && (m->seg_begin[lane + 1] > m->seg_begin[lane]);
         const int nonempty = __popcll(__ballot(has));
@@ -387,12 +456,8 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
           quota += extra_g / nonempty;
           if (pos1 == first1) quota += extra_g % nonempty;
         }
-        if (lane < 64) {
-          m->target[lane] = target;
-          m->quota[lane] = quota;
-          m->got[lane] = 0;
-          m->final_rbgs[lane] = 0;
-        }
+        m->target[lane] = target;
+        m->quota[lane] = quota;
       } else if (SCHED == 7) {
         /* SelectSliceToServe, ref: downlink-nvs-scheduler.cpp:94-142 */
         int pick;
@@ -404,15 +469,11 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
           double ew = in ? s_sstate[lane] : 1.0;
           unsigned long long zero = __ballot(has && ew == 0);
           unsigned long long hasm = __ballot(has);
-          int first_zero = zero ? __ffsll((long long)zero) - 1 : 64;
-          /* scan order: slices before the first zero-ewma slice compete with '>=' (last max wins),
-           * but a zero-ewma slice ends the scan and wins outright */
+          /* a zero-ewma slice ends the scan and wins outright; otherwise '>=' keeps the LAST maximum */
           if (zero) {
-            pick = first_zero;
+            pick = __ffsll((long long)zero) - 1;
           } else {
-            double score = has ? s_w[lane] / ew : -1.0;
-            /* argmax, ties -> highest lane */
-            double best = score;
+            double best = has ? s_w[lane] / ew : -1.0;
             int bl = has ? lane : -1;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
@@ -430,19 +491,23 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
           }
         }
         if (lane == 0) m->nvs_slice = pick;
-        if (lane < 64) { m->target[lane] = 0; m->quota[lane] = 0; }
+        m->target[lane] = 0;
+        m->quota[lane] = 0;
       } else {
-        if (lane < 64) { m->target[lane] = 0; m->quota[lane] = 0; }
+        m->target[lane] = 0;
+        m->quota[lane] = 0;
       }
     }
-    __syncthreads();
+    int seg_lo = 0; /* NVS: the served slice */
+    if (SCHED == 7) {
+      __syncthreads(); /* P3 scans the slice P2 picked */
+      seg_lo = p.direct ? 0 : m->nvs_slice;
+    }
     RS_STAMP(1);
-    if (SCHED == 7) seg_lo = p.direct ? 0 : m->nvs_slice;
 
     /* ---------------- P3: best user of every (RBG, segment) ---------------- */
     {
       const int n_items = p.n_items;
-      const int n_seg = p.n_seg;
       for (int it = tid; it < n_items; it += nt) {
         int sg = it / R, r = it - sg * R; /* r fastest: neighbouring lanes read neighbouring CQI bytes */
         int seg = SCHED == 7 ? seg_lo : sg;
@@ -456,19 +521,47 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
           sl_eps = p.eps[sl];
           sl_psi = p.psi[sl];
         }
-        for (int u = ub; u < ue; ++u) {
-          int c = s_cqi[u * R + r];
-          double metric;
-          if (SCHED == 1) {
-            /* ref: dl-pf-packet-scheduler.cpp:128-140  (se*180000.)/avg */
-            metric = s_num[c] / s_avg[u];
-          } else {
-            /* ref: :688-693  pow(se_kbps, eps) / pow(avg_kbps, psi), eps, psi in {0,1} */
-            double num = sl_eps ? s_num[c] : 1.0;
-            double den = sl_psi ? s_avgk[u] : 1.0;
-            metric = num / den;
+        const uint8_t* cq = s_cqi + r;
+        /* Exact two-stage argmax.  Stage 1 ranks the segment's users by the cheap
+         * FP32 product a~ = fl32(num) * fl32(fl(1/den)), which is within 2^-22 (relative) of the
+         * reference's rounded FP64 quotient q = fl(num/den); a user whose a~ is below (1 - 2^-19) of
+         * the largest a~ has a strictly smaller q and can neither win nor tie.  Stage 2 evaluates
+         * the survivors with the real IEEE FP64 division, ascending user order, strict '>'. */
+        const float kTol = 0x1.ffffcp-1f; /* 1 - 2^-19 */
+        for (int blk = ub; blk < ue; blk += 32) {
+          const int len = (ue - blk) < 32 ? (ue - blk) : 32;
+          float best_a = -3.0e38f, tol_a = -3.0e38f;
+          uint32_t cand = 0;
+          const uint8_t* pc = cq + blk * R;
+          for (int j = 0; j < len; ++j, pc += R) {
+            const int c = *pc;
+            const float num = (SCHED == 1 || sl_eps) ? s_num32[c] : 1.0f;
+            const float rcp = (SCHED == 1 || sl_psi) ? s_rcp32[blk + j] : 1.0f;
+            const float a = num * rcp;
+            const float ta = a * kTol;
+            const bool gt = a > best_a;
+            const bool reset = gt && (best_a < ta);
+            const bool add = gt || (a >= tol_a);
+            cand = reset ? 0u : cand;
+            cand |= add ? (1u << j) : 0u;
+            best_a = gt ? a : best_a;
+            tol_a = gt ? ta : tol_a;
           }
-          if (metric > best) { best = metric; bu = u; bkey = c; }
+          while (cand) {
+            const int j = __ffs((int)cand) - 1;
+            cand &= cand - 1;
+            const int u = blk + j;
+            const int c = cq[u * R];
+            double metric;
+            if (SCHED == 1) {
+              /* ref: dl-pf-packet-scheduler.cpp:128-140  (se*180000.)/avg */
+              metric = s_num[c] / s_avg[u];
+            } else {
+              /* ref: :688-693  pow(se_kbps, eps) / pow(avg_kbps, psi), eps, psi in {0,1} */
+              metric = (sl_eps ? s_num[c] : 1.0) / (sl_psi ? s_avgk[u] : 1.0);
+            }
+            if (metric > best) { best = metric; bu = u; bkey = c; }
+          }
         }
         s_best_user[it] = (uint16_t)bu;
         if (kTransport) {
@@ -478,31 +571,14 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
           s_best_metric[it] = best;
         }
       }
-      (void)n_seg;
     }
     __syncthreads();
     RS_STAMP(2);
 
     /* ---------------- P4: inter-slice assignment ---------------- */
-    if (SCHED == 8) {
-      /* GreedyByRow, ref: :249-272 -- RBG ascending, argmax eff over slices under quota, first max
-       * wins.  eff is strictly increasing in CQI (0 for an empty slice), so integer keys compare alike. */
-      if (wave == 0) {
-        int got = 0;
-        const int quota = lane < S ? m->quota[lane] : 0;
-        for (int r = 0; r < R; ++r) {
-          int key = lane < S ? (int)(s_elems[r * S + lane] >> 16) : -1;
-          bool ok = lane < S && got < quota;
-          int packed = ok ? (key << 6) | (63 - lane) : -1;
-          int bestp = wave_max(packed);
-          int sl = bestp < 0 ? -1 : 63 - (bestp & 63);
-          if (lane == sl) got++;
-          if (lane == 0) m->rbg_slice[r] = sl;
-        }
-      }
-    } else if (SCHED == 9) {
+    if (SCHED == 9) {
       const int N = R * S;
-      /* std::sort emulation, step 1: the introsort loop */
+      /* std::sort emulation (:361): introsort loop, then the final insertion sort */
 #ifdef RS_SERIAL_SORT
       if (tid == 0) {
         LdsArr a{s_elems};
@@ -514,149 +590,128 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
       introsort_loop_parallel(s_elems, N, (uint16_t*)s_sorted, (uint16_t*)s_sorted + N, m);
 #endif
       RS_STAMP(3);
-      /* step 2: final insertion sort == stable counting sort by descending key (wave 0) */
-      if (wave == 0) {
-        int base = 0; /* lane q (< 16): output offset of key q */
-        {
-          int cnt = 0;
-          for (int c0 = 0; c0 < N; c0 += 64) {
-            int i = c0 + lane;
-            int k = i < N ? (int)(s_elems[i] >> 16) : -1;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              unsigned long long mk = __ballot(k == q);
-              if (lane == q) cnt += __popcll(mk);
-            }
-          }
-          /* descending: offset(q) = sum of counts of keys > q */
-          int tot = 0;
-#pragma unroll
-          for (int q = 15; q >= 0; --q) {
-            int cq = __shfl(cnt, q, 64);
-            if (lane == q) base = tot;
-            tot += cq;
-          }
-        }
-        for (int c0 = 0; c0 < N; c0 += 64) {
-          int i = c0 + lane;
-          uint32_t e = i < N ? s_elems[i] : 0;
-          int k = i < N ? (int)(e >> 16) : -1;
-          int my_base = __shfl(base, k < 0 ? 0 : k, 64);
-          int rank = 0;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            unsigned long long mk = __ballot(k == q);
-            if (k == q) rank = __popcll(mk & ((1ull << lane) - 1ull));
-            if (lane == q) base += __popcll(mk);
-          }
-          if (i < N) s_sorted[my_base + rank] = e;
-        }
-        RS_STAMP(4);
-        /* MaximizeCell greedy scan, ref: :362-369 */
-        unsigned long long taken = 0;
-        int assigned = 0;
-        if (lane < R) m->rbg_slice[lane] = -1;
-        for (int c0 = 0; c0 < N && assigned < R; c0 += 64) {
-          int i = c0 + lane;
-          uint32_t e = i < N ? s_sorted[i] : 0;
-          int rbg = (e >> 8) & 63, sl = e & 63;
-          while (true) {
-            bool ok = i < N && !((taken >> rbg) & 1ull) && m->got[sl] < m->quota[sl];
-            unsigned long long mk = __ballot(ok);
-            if (!mk) break;
-            int f = __ffsll((long long)mk) - 1;
-            int frbg = __shfl(rbg, f, 64);
-            if (lane == f) {
-              m->rbg_slice[rbg] = sl;
-              m->got[sl] += 1;
-            }
-            taken |= 1ull << frbg;
-            assigned++;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          }
-        }
-      }
-    } else {
-      /* sched 1 / 7: per RBG, first maximum over the segments in ascending order */
-      if (tid < R) {
-        const int r = tid;
-        if (SCHED == 1) {
-          double best = 0.0;
-          int bu = -1;
-          for (int sg = 0; sg < p.n_seg; ++sg) {
-            double v = s_best_metric[sg * R + r];
-            int u = s_best_user[sg * R + r];
-            if (u != 0xFFFF && v > best) { best = v; bu = u; }
-          }
-          m->owner[r] = bu;
-        } else {
-          int u = s_best_user[r];
-          m->owner[r] = u == 0xFFFF ? -1 : u;
-        }
-      }
+      counting_sort_desc(s_elems, s_sorted, N, m);
+      RS_STAMP(4);
     }
-    RS_STAMP(5);
-    __syncthreads();
-    RS_STAMP(6);
-
-    /* ---------------- P5: apply, link adaptation, accounting (wave 0, lanes = RBGs) ---------------- */
+    /* the rest of the TTI runs on wave 0: lanes = slices for the quota counters, lanes = RBGs for
+     * the allocation; the RBG->slice map stays in registers */
     if (wave == 0) {
       int owner = -1;
-      if (lane < R) {
-        if (kTransport) {
-          int sl = m->rbg_slice[lane];
-          if (sl >= 0) {
-            int u = s_best_user[sl * R + lane];
-            owner = u == 0xFFFF ? -1 : u;
-            if (owner >= 0) atomicAdd(&m->final_rbgs[sl], 1);
-          }
-        } else {
-          owner = m->owner[lane];
+      int got = 0; /* lane s: RBGs granted to slice s */
+      if (SCHED == 8) {
+        /* GreedyByRow, ref: :249-272 -- RBG ascending, argmax eff over slices under quota, first max
+         * wins.  eff is strictly increasing in CQI (0 for an empty slice), so integer keys compare alike. */
+        const int quota = lane < S ? m->quota[lane] : 0;
+        int my_slice = -1;
+        for (int r = 0; r < R; ++r) {
+          int key = lane < S ? (int)(s_elems[r * S + lane] >> 16) : -1;
+          bool ok = lane < S && got < quota;
+          int packed = ok ? (key << 6) | (63 - lane) : -1;
+          int bestp = wave_max(packed);
+          int sl = bestp < 0 ? -1 : 63 - (bestp & 63);
+          if (lane == sl) got++;
+          if (lane == r) my_slice = sl;
         }
-        m->owner[lane] = owner;
+        if (lane < R && my_slice >= 0) {
+          int u = s_best_user[my_slice * R + lane];
+          owner = u == 0xFFFF ? -1 : u;
+        }
+      } else if (SCHED == 9) {
+        /* MaximizeCell greedy scan, ref: :362-369: sorted records in order, take the RBG if it is
+         * free and the slice is under quota */
+        const int N = R * S;
+        int left = lane < S ? m->quota[lane] : 0; /* lane s: quota[s] - granted[s] */
+        int my_slice = -1;                        /* lane r: slice that got RBG r */
+        unsigned long long taken = 0;
+        int assigned = 0;
+        for (int c0 = 0; c0 < N && assigned < R; c0 += 64) {
+          const int i = c0 + lane;
+          const uint32_t e = i < N ? s_sorted[i] : 0;
+          const int rbg = (e >> 8) & 63, sl = e & 63;
+          int my_left = __shfl(left, sl, 64);
+          while (true) {
+            const bool ok = i < N && !((taken >> rbg) & 1ull) && my_left > 0;
+            const unsigned long long mk = __ballot(ok);
+            if (!mk) break;
+            const int f = __ffsll((long long)mk) - 1;
+            const int frbg = __builtin_amdgcn_readlane(rbg, f);
+            const int fsl = __builtin_amdgcn_readlane(sl, f);
+            if (lane == frbg) my_slice = fsl;
+            if (sl == fsl) my_left--;
+            if (lane == fsl) left--;
+            taken |= 1ull << frbg;
+            assigned++;
+          }
+        }
+        if (lane < S) got = m->quota[lane] - left;
+        if (lane < R && my_slice >= 0) {
+          int u = s_best_user[my_slice * R + lane];
+          owner = u == 0xFFFF ? -1 : u;
+        }
+      } else if (SCHED == 1) {
+        /* ref: downlink-packet-scheduler.cpp:221-237 -- per RBG the first maximum over all flows,
+         * here over the segment winners in ascending segment order */
+        if (lane < R) {
+          double best = 0.0;
+          for (int sg = 0; sg < p.n_seg; ++sg) {
+            double v = s_best_metric[sg * R + lane];
+            int u = s_best_user[sg * R + lane];
+            if (u != 0xFFFF && v > best) { best = v; owner = u; }
+          }
+        }
+      } else {
+        if (lane < R) {
+          int u = s_best_user[lane];
+          owner = u == 0xFFFF ? -1 : u;
+        }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      /* leader = lowest RBG of each served user */
-      bool leader = owner >= 0;
-      for (int r2 = 0; r2 < R; ++r2) {
-        int o2 = __shfl(owner, r2, 64);
-        if (r2 < lane && o2 == owner) leader = false;
-      }
-      unsigned long long lead_mask = __ballot(leader);
+      RS_STAMP(5);
+
+      /* ---------------- P5: link adaptation + DoStopSchedule counters (lanes = RBGs) ---------------- */
+      /* lanes holding the same user; the lowest one (leader) handles the user */
+      BitBallots<11> ob;
+      ob.gather(owner + 1, lane < R && owner >= 0);
+      const unsigned long long same = owner >= 0 ? ob.lanes_with(owner + 1) : 0ull;
+      const bool leader = owner >= 0 && (same & ((1ull << lane) - 1ull)) == 0;
+      const unsigned long long lead_mask = __ballot(leader);
       int tbs = 0, nprb = 0, fcqi = 0, mcs = 0;
-      if (leader) {
+      {
         /* ref: :638-651 -- PRBs in RBG-ascending order, G identical adds per RBG
          * (src/utility/eesm-effective-sinr.h:33-46 with the exp() values tabulated by the host) */
+        unsigned long long mm = leader ? same : 0ull;
         double sum = 0;
-        for (int r2 = lane; r2 < R; ++r2) {
-          if (m->owner[r2] == owner) {
-            double ev = s_e[s_cqi[owner * R + r2]];
-            for (int k = 0; k < G; ++k) sum += ev;
-            nprb += G;
-          }
+        const uint8_t* row = s_cqi + (owner < 0 ? 0 : owner) * R;
+        while (mm) {
+          const int r2 = __ffsll((long long)mm) - 1;
+          mm &= mm - 1;
+          const double ev = s_e[row[r2]];
+          for (int k = 0; k < G; ++k) sum += ev;
+          nprb += G;
         }
-        double x = sum / (double)nprb;
-        if (x == 0) {
-          fcqi = 15;
-        } else {
-          fcqi = 1;
+        if (leader) {
+          const double x = sum / (double)nprb;
+          if (x == 0) {
+            fcqi = 15;
+          } else {
+            fcqi = 1;
 #pragma unroll
-          for (int k = 1; k <= 13; ++k) fcqi += (x <= s_x[k]) ? 1 : 0;
-        }
-        mcs = tab->mcs_of_cqi[fcqi];
-        tbs = tbs_bits(tab->itbs_of_cqi[fcqi], nprb, tab->tbs_row_m1);
-        /* DoStopSchedule, ref: :170-221 (bytes = bits/8, capped by dataToTransmit = 1e8) */
-        int bytes = tbs / 8;
-        if (bytes > 100000000) bytes = 100000000;
-        if (bytes > 0) {
-          s_tx[owner] += bytes;
-          s_cumb[owner] += bytes;
-          s_cumr[owner] += nprb;
+            for (int k = 1; k <= 13; ++k) fcqi += (x <= s_x[k]) ? 1 : 0;
+          }
+          mcs = m->mcs_of_cqi[fcqi];
+          tbs = s_tbs[(nprb / G) * 27 + m->itbs_of_cqi[fcqi]];
+          /* DoStopSchedule, ref: :170-221 (bytes = bits/8, capped by dataToTransmit = 1e8) */
+          int bytes = tbs / 8;
+          if (bytes > 100000000) bytes = 100000000;
+          if (bytes > 0) {
+            s_tx[owner] += bytes;
+            s_cumb[owner] += bytes;
+            s_cumr[owner] += nprb;
+          }
         }
       }
       served_prev = __popcll(lead_mask);
       /* ref: :618-620 slice_rbs_offset_ = target - final_rbgs*rbg_size */
-      if (kTransport && lane < S) s_sstate[lane] = (double)(m->target[lane] - m->final_rbgs[lane] * G);
+      if (kTransport && lane < S) s_sstate[lane] = (double)(m->target[lane] - got * G);
       if (lane == 0) m->served = served_prev;
       /* optional log */
       if (p.log_map) {
@@ -688,7 +743,7 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
     p.cum_rbs[(size_t)cell * U + u] += s_cumr[u];
   }
   if (tid < S) p.slice_state[(size_t)cell * S + tid] = s_sstate[tid];
-  if (wave == 0 && lane < 31) scal->rng_r[lane] = rng.r;
+  if (wave == quota_wave && lane < 31) scal->rng_r[lane] = rng.r;
   if (tid == 0) {
     scal->t = t;
     scal->last_update = last_update;
@@ -696,13 +751,15 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
     scal->reported = reported;
     scal->served_prev = served_prev;
     scal->n_done = n_done;
-    scal->rng_f = rng.f;
-    scal->rng_b = rng.b;
     if (local_err) atomicExch(p.err, local_err);
 #ifdef RS_STAMPS
     if (p.stamps)
       for (int i = 0; i < 12; ++i) p.stamps[(size_t)cell * 12 + i] = stamp_acc[i];
 #endif
+  }
+  if (wave == quota_wave && lane == 0) {
+    scal->rng_f = rng.f;
+    scal->rng_b = rng.b;
   }
 }
 

@@ -12,8 +12,8 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import radiosaber_amd as rs  # noqa: E402
 
-NAMES = ["P0+P1 refresh/EWMA", "P2 quotas (+barrier)", "P3 best user (+barrier)", "P4a introsort loop",
-         "P4b counting sort", "P4c greedy / other P4", "barrier after P4", "P5 apply+link adapt", "barrier after P5",
+NAMES = ["P0+P1 refresh/EWMA (+barrier)", "P2 quotas (if wave 0)", "P3 best user (+barrier)", "P4a introsort loop",
+         "P4b counting sort", "P4c greedy (wave 0)", "-", "P5 link adapt + counters", "barrier end of TTI",
          "-", "-", "loop head"]
 
 ap = argparse.ArgumentParser()
