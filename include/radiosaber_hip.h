@@ -145,7 +145,7 @@ typedef struct rs_batch_config {
   int32_t phy_error_draws;   /* 1: consume one rand() per UE served in the previous TTI, as the
                                 reference's PHY error model does on the shared libc stream
                                 (ref: src/phy/wideband-cqi-eesm-error-model.cpp:69)              */
-  int32_t threads_per_cell;  /* workgroup size, multiple of 64 in [64,1024]; 0 = default        */
+  int32_t threads_per_cell;  /* workgroup size, multiple of 64 in [64,512]; 0 = default        */
 } rs_batch_config;
 
 rs_batch* rs_batch_create(const rs_batch_config* cfg);
@@ -195,7 +195,7 @@ int rs_batch_slice_bytes_device(rs_batch* b, uint64_t* d_out);
 int rs_batch_slice_bytes(rs_batch* b, uint64_t* h_out /* [S] */);
 /* diagnostics: cycles per kernel phase of one cell's first thread, summed over the last launch;
  * only in the separate -DRS_STAMPS build (RS_ERR_STATE in the product library) */
-int rs_batch_debug_stamps(rs_batch* b, int32_t cell, uint64_t* out12);
+int rs_batch_debug_stamps(rs_batch* b, int32_t cell, uint64_t* out20);
 /* scheduled TTIs completed per cell so far */
 int64_t rs_batch_ttis_done(rs_batch* b);
 /* the hipStream_t the batch launches on */

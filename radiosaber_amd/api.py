@@ -360,7 +360,7 @@ class BatchScheduler:
         _check(lib().rs_batch_slice_bytes_device(self._h, C.c_void_p(device_ptr)))
 
     def debug_stamps(self, cell=0):
-        out = np.zeros(12, np.uint64)
+        out = np.zeros(20, np.uint64)
         _check(lib().rs_batch_debug_stamps(self._h, cell, _p(out, C.c_uint64)))
         return out
 

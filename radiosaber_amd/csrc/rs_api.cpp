@@ -221,16 +221,19 @@ void carve_lds(rs_batch* b, RsLaunch* L) {
   off += 8 * U;               /* avg */
   L->off_avgk = off; off += 8 * U;
   L->off_rcp = off; off += round_up(4 * U, 16);
-  L->off_cumb = off; off += 8 * U;
   L->off_tab = off; off += 8 * 48 + 64;
   L->off_slice = off; off += 8 * 128;
   L->off_tx = off; off += round_up(4 * U, 16);
-  L->off_cumr = off; off += round_up(4 * U, 16);
   L->off_misc = off; off += round_up((int)sizeof(RsMisc), 16);
   L->off_tbs = off; off += round_up(4 * 27 * (R + 1), 16);
   L->off_elems = off; off += round_up(b->sched == RS_SCHED_PF ? 8 * n_items : 4 * R * S, 16);
   L->off_sorted = off; off += round_up(4 * R * S, 16);
   L->off_items = off; off += round_up(2 * n_items, 16);
+  {
+    /* level-synchronous introsort scratch: cut per sub-range (+ bounds/pivots when the state lives in LDS) */
+    const int ept = (R * S + b->threads - 1) / b->threads;
+    L->off_sortx = off; off += b->sched == RS_SCHED_MAXCELL ? round_up((ept <= 4 ? 2 : 8) * R * S, 16) : 0;
+  }
   L->off_cqi = off; off += round_up(U * R, 16);
   L->lds_bytes = off;
   L->n_seg = n_seg;
@@ -317,8 +320,8 @@ int batch_alloc(rs_batch* b) {
   HIP_TRY(hipMalloc(&b->d_slice_bytes, 8 * 64));
   HIP_TRY(hipMemset(b->d_err, 0, 4));
 #ifdef RS_STAMPS
-  HIP_TRY(hipMalloc(&b->d_stamps, 8 * 12 * (size_t)b->n_cells));
-  HIP_TRY(hipMemset(b->d_stamps, 0, 8 * 12 * (size_t)b->n_cells));
+  HIP_TRY(hipMalloc(&b->d_stamps, 8 * 20 * (size_t)b->n_cells));
+  HIP_TRY(hipMemset(b->d_stamps, 0, 8 * 20 * (size_t)b->n_cells));
 #endif
   std::vector<double> avg(cells * U, 100000.0); /* radio-bearer.cpp:54 */
   HIP_TRY(hipMemcpy(b->d_avg, avg.data(), 8 * cells * U, hipMemcpyHostToDevice));
@@ -354,7 +357,7 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   if (!direct && cfg->cqi_refresh < 1) { fail(RS_ERR_INVALID, "cqi_refresh %d < 1", cfg->cqi_refresh); return nullptr; }
   if (cfg->first_tti < 0) { fail(RS_ERR_INVALID, "first_tti %d < 0", cfg->first_tti); return nullptr; }
   int threads = cfg->threads_per_cell ? cfg->threads_per_cell : 256;
-  if (threads % 64 || threads < 64 || threads > 1024) { fail(RS_ERR_INVALID, "threads_per_cell %d", threads); return nullptr; }
+  if (threads % 64 || threads < 64 || threads > 512) { fail(RS_ERR_INVALID, "threads_per_cell %d", threads); return nullptr; }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { fail(RS_ERR_NO_DEVICE, "no HIP device"); return nullptr; }
   if (cfg->cell.device < 0 || cfg->cell.device >= n) { fail(RS_ERR_NO_DEVICE, "device %d of %d", cfg->cell.device, n); return nullptr; }
@@ -382,8 +385,8 @@ int check_device_err(rs_batch* b) {
   if (e) {
     HIP_TRY(hipMemset(b->d_err, 0, 4));
 #ifdef RS_STAMPS
-  HIP_TRY(hipMalloc(&b->d_stamps, 8 * 12 * (size_t)b->n_cells));
-  HIP_TRY(hipMemset(b->d_stamps, 0, 8 * 12 * (size_t)b->n_cells));
+  HIP_TRY(hipMalloc(&b->d_stamps, 8 * 20 * (size_t)b->n_cells));
+  HIP_TRY(hipMemset(b->d_stamps, 0, 8 * 20 * (size_t)b->n_cells));
 #endif
     return fail(RS_ERR_RANGE, e == RS_CQI_EPOCHS ? "ran past the last CQI epoch" : "trace row outside the uploaded rows");
   }
@@ -589,11 +592,11 @@ int rs_batch_slice_bytes(rs_batch* b, uint64_t* h_out) {
   return RS_OK;
 }
 
-int rs_batch_debug_stamps(rs_batch* b, int32_t cell, uint64_t* out12) {
-  if (!b || !out12 || cell < 0 || cell >= b->n_cells) return fail(RS_ERR_INVALID, "bad argument");
+int rs_batch_debug_stamps(rs_batch* b, int32_t cell, uint64_t* out20) {
+  if (!b || !out20 || cell < 0 || cell >= b->n_cells) return fail(RS_ERR_INVALID, "bad argument");
   if (!b->d_stamps) return fail(RS_ERR_STATE, "not a diagnostic (-DRS_STAMPS) build");
   HIP_TRY(hipStreamSynchronize(b->stream));
-  HIP_TRY(hipMemcpy(out12, b->d_stamps + (size_t)cell * 12, 8 * 12, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out20, b->d_stamps + (size_t)cell * 20, 8 * 20, hipMemcpyDeviceToHost));
   return RS_OK;
 }
 
@@ -602,10 +605,13 @@ void* rs_batch_stream(rs_batch* b) { return b ? (void*)b->stream : nullptr; }
 const char* rs_batch_kernel_name(rs_batch* b) {
   if (!b) return "";
   switch (b->sched) {
-    case 1: return "rs_cell_kernel<1>";
-    case 7: return "rs_cell_kernel<7>";
-    case 8: return "rs_cell_kernel<8>";
-    default: return "rs_cell_kernel<9>";
+    case 1: return "rs_cell_kernel<1, 0>";
+    case 7: return "rs_cell_kernel<7, 0>";
+    case 8: return "rs_cell_kernel<8, 0>";
+    default: {
+      const int ept = (b->R * b->S + b->threads - 1) / b->threads;
+      return ept <= 1 ? "rs_cell_kernel<9, 1>" : ept <= 2 ? "rs_cell_kernel<9, 2>" : ept <= 4 ? "rs_cell_kernel<9, 4>" : "rs_cell_kernel<9, 0>";
+    }
   }
 }
 

@@ -13,6 +13,7 @@
 /* per-cell scratch in LDS (host needs its size for the LDS carve) */
 #define RS_MAX_SEGS 256 /* > 4096/17 sub-ranges longer than 16 on one recursion level */
 struct RsMisc {
+  unsigned long long maskA[64], maskB[64]; /* level-synchronous introsort: stop ballots per chunk */
   int32_t seg_begin[68];
   int32_t target[64];
   int32_t quota[64];
@@ -21,10 +22,7 @@ struct RsMisc {
   int32_t rbg_slice[64];
   int32_t owner[64];
   int32_t stack[96];             /* serial introsort emulation (debug path) */
-  int32_t n_level[48];           /* parallel introsort: segments queued per recursion level */
-  int16_t q_first[2][RS_MAX_SEGS];
-  int16_t q_last[2][RS_MAX_SEGS];
-  int16_t q_depth[2][RS_MAX_SEGS];
+  int32_t n_level[48];           /* level-synchronous introsort: live sub-ranges per recursion level */
   uint16_t hist[64 * 16];        /* counting sort: per 64-element chunk, per key */
   int32_t mcs_of_cqi[16];
   int32_t itbs_of_cqi[16];
@@ -96,10 +94,10 @@ struct RsLaunch {
   int32_t* log_tbs;          /* [cells][n_ttis][U], pre-zeroed */
   int32_t* log_uinfo;        /* [cells][n_ttis][U], pre-zeroed: nprb | final_cqi<<16 | mcs<<24 */
   int32_t* err;              /* device error word */
-  unsigned long long* stamps; /* diagnostic build (-DRS_STAMPS): [cells][12] phase cycles, else unused */
+  unsigned long long* stamps; /* diagnostic build (-DRS_STAMPS): [cells][20] phase cycles, else unused */
   /* LDS carve (byte offsets from the dynamic LDS base) */
-  int32_t off_avgk, off_rcp, off_tx, off_cumb, off_cumr, off_tab, off_slice, off_items, off_elems,
-      off_sorted, off_misc, off_tbs, off_cqi, lds_bytes;
+  int32_t off_avgk, off_rcp, off_tx, off_tab, off_slice, off_items, off_elems,
+      off_sorted, off_sortx, off_misc, off_tbs, off_cqi, lds_bytes;
   int32_t n_seg, n_items;    /* segments per RBG scan, R*n_seg */
 };
 

@@ -102,113 +102,302 @@ struct LdsInt {
 }  // namespace
 
 /*
- * std::__introsort_loop, wave-parallel.  Every recursion level's sub-ranges are disjoint, so they
- * are queued per level and each wave partitions whole sub-ranges; a partition is two passes over
- * the sub-range in 64-element chunks:
- *   pass 1  ballots of "left-scan stop" (key <= pivot) and "right-scan stop" (key >= pivot) on the
- *           array before the partition; prefix popcounts turn them into the stop lists L (ascending)
- *           and Rr (via posB, read backwards), kept in LDS scratch;
- *   pass 2  the serial Hoare loop performs exactly the swaps (L[j], Rr[j]) for j < k, k = first j
- *           with L[j] >= Rr[j], and returns L[0] if k == 0 else min(L[k], Rr[k-1])
- *           (derivation: DESIGN.md; CPU model: tests/test_partition_model.py).
- * The median-of-3 pivot move and the (never observed) heap-sort fallback at depth 0 run on one lane
- * with the serial code of rs_sort_emul.h.  All waves of the workgroup must call this.
+ * std::__introsort_loop, level-synchronous over the whole workgroup (the default path).
+ * All sub-ranges of one recursion level are partitioned at once, one array position per lane:
+ *   M  the lane sitting on a sub-range's first position moves the median of 3 there and publishes
+ *      the pivot key (depth 0: it heap-sorts the sub-range instead, as the library does)
+ *   F  every position compares with ITS sub-range's pivot; per 64-position chunk two ballots
+ *      ("left-scan stop" key <= pivot, "right-scan stop" key >= pivot) go to LDS
+ *   R  popcounts over the chunk masks give each stop its rank inside its sub-range:
+ *      posA[first + rank from the left] / posB[first + rank from the right]  (= L and Rr)
+ *   S  lane j of a sub-range swaps (L[j], Rr[j]) while L[j] < Rr[j]; the lane at the boundary
+ *      publishes the cut  L[0] | min(L[k], Rr[k-1])
+ *   U  every position moves to its child sub-range [first,cut) or [cut,last); children of at
+ *      most 16 elements retire
+ * Four workgroup barriers per level, no queue, cost independent of the number of sub-ranges.
  */
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+__device__ __forceinline__ int count_bits_in(const unsigned long long* masks, int lo, int hi) {
+  /* number of set mask bits at positions [lo, hi) */
+  if (hi <= lo) return 0;
+  const int c0 = lo >> 6, c1 = (hi - 1) >> 6;
+  int total = 0;
+  for (int c = c0; c <= c1; ++c) {
+    unsigned long long mk = masks[c];
+    if (c == c0) mk &= ~0ull << (lo & 63);
+    if (c == c1) {
+      const int h = ((hi - 1) & 63) + 1;
+      if (h < 64) mk &= (1ull << h) - 1ull;
+    }
+    total += __popcll(mk);
+  }
+  return total;
 }
 
-__device__ void introsort_loop_parallel(uint32_t* v, int N, uint16_t* posA, uint16_t* posB, Misc* m) {
-  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
-  if (threadIdx.x < 48) m->n_level[threadIdx.x] = 0;
-  __syncthreads();
-  if (threadIdx.x == 0 && N > 16) {
-    m->n_level[0] = 1;
-    m->q_first[0][0] = 0;
-    m->q_last[0][0] = (int16_t)N;
-    m->q_depth[0][0] = (int16_t)(2 * rs_sort::floor_log2(N));
+__device__ void introsort_loop_levels(uint32_t* v, int N, uint16_t* posA, uint16_t* posB, uint16_t* segF,
+                                      uint16_t* segL, uint16_t* pkbuf, uint16_t* cutbuf, Misc* m) {
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+  const int n_chunks = (N + 63) >> 6;
+  for (int x = tid; x < N; x += nt) {
+    segF[x] = 0;
+    segL[x] = (uint16_t)(N > 16 ? N : 0);
   }
-  __syncthreads();
-  for (int level = 0; level < 47; ++level) {
-    const int par = level & 1;
-    const int n_cur = m->n_level[level];
-    if (n_cur == 0) break;
-    for (int i = wave; i < n_cur; i += nwaves) {
-      const int first = m->q_first[par][i], last = m->q_last[par][i];
-      int depth = m->q_depth[par][i];
-      if (depth == 0) {
-        if (lane == 0) {
-          LdsArr a{v};
-          rs_sort::heap_sort(a, first, last);
-        }
-        continue;
-      }
-      --depth;
-      if (lane == 0) {
+  if (tid < 48) m->n_level[tid] = (tid == 0 && N > 16) ? 1 : 0;
+  int depth = 2 * rs_sort::floor_log2(N > 1 ? N : 1);
+  for (int level = 0; level < 47; ++level, --depth) {
+    /* M */
+    for (int x = tid; x < N; x += nt) {
+      const int L = segL[x];
+      if (L != 0 && segF[x] == x) {
         LdsArr a{v};
-        rs_sort::median_to_first(a, first, first + 1, first + (last - first) / 2, last - 1);
-      }
-      wave_lds_sync();
-      const int pk = (int)(v[first] >> 16);
-      int cntA = 0, cntB = 0;
-      const unsigned long long lt = (1ull << lane) - 1ull;
-      for (int base = first + 1; base < last; base += 64) {
-        const int x = base + lane;
-        const bool in = x < last;
-        const int k = in ? (int)(v[x] >> 16) : 0;
-        const bool isA = in && k <= pk;
-        const bool isB = in && k >= pk;
-        const unsigned long long mA = __ballot(isA), mB = __ballot(isB);
-        if (isA) posA[first + cntA + __popcll(mA & lt)] = (uint16_t)x;
-        if (isB) posB[first + cntB + __popcll(mB & lt)] = (uint16_t)x;
-        cntA += __popcll(mA);
-        cntB += __popcll(mB);
-      }
-      wave_lds_sync();
-      const int nmin = cntA < cntB ? cntA : cntB;
-      int k = 0;
-      for (int j0 = 0; j0 < nmin; j0 += 64) {
-        const int j = j0 + lane;
-        const bool valid = j < nmin;
-        const int l = valid ? (int)posA[first + j] : 0;
-        const int r = valid ? (int)posB[first + cntB - 1 - j] : 0;
-        const bool sw = valid && l < r;
-        const unsigned long long ms = __ballot(sw);
-        if (sw) {
-          const uint32_t a = v[l], b = v[r];
-          v[l] = b;
-          v[r] = a;
-        }
-        k += __popcll(ms);
-        if (ms != __ballot(valid)) break;
-      }
-      wave_lds_sync();
-      int cut;
-      if (k == 0) {
-        cut = posA[first];
-      } else {
-        const int lk = k < cntA ? (int)posA[first + k] : (1 << 30);
-        const int rk = (int)posB[first + cntB - k]; /* Rr[k-1] */
-        cut = lk < rk ? lk : rk;
-      }
-      if (lane == 0) {
-        if (cut - first > 16) {
-          int s = atomicAdd(&m->n_level[level + 1], 1);
-          m->q_first[par ^ 1][s] = (int16_t)first;
-          m->q_last[par ^ 1][s] = (int16_t)cut;
-          m->q_depth[par ^ 1][s] = (int16_t)depth;
-        }
-        if (last - cut > 16) {
-          int s = atomicAdd(&m->n_level[level + 1], 1);
-          m->q_first[par ^ 1][s] = (int16_t)cut;
-          m->q_last[par ^ 1][s] = (int16_t)last;
-          m->q_depth[par ^ 1][s] = (int16_t)depth;
+        if (depth == 0) {
+          rs_sort::heap_sort(a, x, L);
+        } else {
+          rs_sort::median_to_first(a, x, x + 1, x + (L - x) / 2, L - 1);
+          pkbuf[x] = (uint16_t)(v[x] >> 16);
         }
       }
     }
     __syncthreads();
+    if (m->n_level[level] == 0 || depth == 0) break;
+    /* F */
+    for (int c = wave; c < n_chunks; c += nwaves) {
+      const int x = (c << 6) + lane;
+      const int L = x < N ? (int)segL[x] : 0;
+      const int F = x < N ? (int)segF[x] : 0;
+      const int k = x < N ? (int)(v[x] >> 16) : 0;
+      const bool in = L != 0 && x > F;
+      const int pk = in ? (int)pkbuf[F] : 0;
+      const unsigned long long mA = __ballot(in && k <= pk), mB = __ballot(in && k >= pk);
+      if (lane == 0) {
+        m->maskA[c] = mA;
+        m->maskB[c] = mB;
+      }
+      if (x < N) {
+        posA[x] = 0xFFFF;
+        posB[x] = 0xFFFF;
+      }
+    }
+    __syncthreads();
+    /* R */
+    for (int c = wave; c < n_chunks; c += nwaves) {
+      const int x = (c << 6) + lane;
+      const int L = x < N ? (int)segL[x] : 0;
+      const int F = x < N ? (int)segF[x] : 0;
+      const int k = x < N ? (int)(v[x] >> 16) : 0;
+      const bool in = L != 0 && x > F;
+      const int pk = in ? (int)pkbuf[F] : 0;
+      if (in && k <= pk) posA[F + count_bits_in(m->maskA, F + 1, x)] = (uint16_t)x;
+      if (in && k >= pk) posB[F + count_bits_in(m->maskB, x + 1, L)] = (uint16_t)x;
+    }
+    __syncthreads();
+    /* S */
+    for (int x = tid; x < N; x += nt) {
+      const int L = segL[x], F = segF[x];
+      if (L != 0 && x > F) {
+        const int j = x - F - 1;
+        const int l = posA[F + j], r = posB[F + j];
+        const int l1 = posA[F + j + 1], r1 = posB[F + j + 1]; /* index <= L-1: inside the sub-range */
+        const bool sw = l != 0xFFFF && r != 0xFFFF && l < r;
+        const bool sw1 = l1 != 0xFFFF && r1 != 0xFFFF && l1 < r1;
+        if (sw) {
+          const uint32_t a = v[l], b = v[r];
+          v[l] = b;
+          v[r] = a;
+          if (!sw1) cutbuf[F] = (uint16_t)((l1 != 0xFFFF && l1 < r) ? l1 : r);
+        } else if (j == 0) {
+          cutbuf[F] = (uint16_t)l;
+        }
+      }
+    }
+    __syncthreads();
+    /* U */
+    bool any = false;
+    for (int x = tid; x < N; x += nt) {
+      const int L = segL[x];
+      if (L != 0) {
+        const int F = segF[x];
+        const int cut = cutbuf[F];
+        const int nF = x < cut ? F : cut;
+        int nL = x < cut ? cut : L;
+        if (nL - nF <= 16) nL = 0;
+        segF[x] = (uint16_t)nF;
+        segL[x] = (uint16_t)nL;
+        any |= nL != 0;
+      }
+    }
+    if (__ballot(any) && lane == 0) atomicAdd(&m->n_level[level + 1], 1);
+  }
+}
+
+/*
+ * The same level-synchronous loop with the per-position state (element, sub-range bounds) held in
+ * registers: EPT positions per thread, position x = i*blockDim + tid (so a wave still covers one
+ * 64-position chunk per i).  Every lane of a sub-range reads the three median samples itself, so
+ * the pivot is known without a publishing step; three workgroup barriers per level.
+ */
+__device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
+  /* bits [lo, hi) of a 64-bit mask, 0 <= lo, hi <= 64 */
+  if (hi <= lo) return 0ull;
+  const unsigned long long upto_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+  return upto_hi & (~0ull << lo);
+}
+
+#ifdef RS_STAMPS
+#define RS_SUBSTAMP(i)                                            \
+  do {                                                            \
+    if (tid == 0) {                                               \
+      unsigned long long now_ = __builtin_readcyclecounter();     \
+      sub[i] += now_ - sub_prev;                                  \
+      sub_prev = now_;                                            \
+    }                                                             \
+  } while (0)
+#else
+#define RS_SUBSTAMP(i) do { } while (0)
+#endif
+
+template <int EPT>
+__device__ void introsort_levels_reg(uint32_t* v, int N, uint16_t* posA, uint16_t* posB, uint16_t* cutbuf, Misc* m,
+                                     unsigned long long* sub) {
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+#ifdef RS_STAMPS
+  unsigned long long sub_prev = __builtin_readcyclecounter();
+#endif
+  const int n_chunks = (N + 63) >> 6;
+  uint32_t e[EPT];
+  int F[EPT], L[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int x = i * nt + tid;
+    e[i] = x < N ? v[x] : 0u;
+    F[i] = 0;
+    L[i] = (x < N && N > 16) ? N : 0;
+  }
+  if (tid < 48) m->n_level[tid] = (tid == 0 && N > 16) ? 1 : 0;
+  int depth = 2 * rs_sort::floor_log2(N > 1 ? N : 1);
+  __syncthreads();
+  for (int level = 0; level < 47; ++level, --depth) {
+    if (depth == 0) {
+      /* std::__partial_sort fallback for every sub-range still longer than 16 */
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int x = i * nt + tid;
+        if (L[i] != 0 && F[i] == x) {
+          LdsArr a{v};
+          rs_sort::heap_sort(a, x, L[i]);
+        }
+      }
+      __syncthreads();
+      break;
+    }
+    /* F: pivot of my sub-range (median of 3, std::__move_median_to_first), stop ballots */
+    unsigned long long mAi[EPT], mBi[EPT];
+    bool isA[EPT], isB[EPT], moved[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int x = i * nt + tid;
+      const int c = i * nwaves + wave;
+      const bool active = L[i] != 0;
+      int pk = 0;
+      moved[i] = false;
+      if (active) {
+        const int f = F[i], l = L[i];
+        const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
+        const uint32_t s0 = v[f], sa = v[ia], sb = v[ib], sc = v[ic];
+        int pick;
+        uint32_t sp;
+        if (rs_sort::before(sa, sb)) {
+          if (rs_sort::before(sb, sc)) { pick = ib; sp = sb; }
+          else if (rs_sort::before(sa, sc)) { pick = ic; sp = sc; }
+          else { pick = ia; sp = sa; }
+        } else if (rs_sort::before(sa, sc)) { pick = ia; sp = sa; }
+        else if (rs_sort::before(sb, sc)) { pick = ic; sp = sc; }
+        else { pick = ib; sp = sb; }
+        pk = (int)(sp >> 16);
+        if (x == f) { e[i] = sp; moved[i] = true; }
+        else if (x == pick) { e[i] = s0; moved[i] = true; }
+      }
+      const int k = (int)(e[i] >> 16);
+      const bool in = active && x > F[i];
+      isA[i] = in && k <= pk;
+      isB[i] = in && k >= pk;
+      mAi[i] = __ballot(isA[i]);
+      mBi[i] = __ballot(isB[i]);
+      if (lane == 0 && c < n_chunks) {
+        m->maskA[c] = mAi[i];
+        m->maskB[c] = mBi[i];
+      }
+      if (x < N) {
+        posA[x] = 0xFFFF;
+        posB[x] = 0xFFFF;
+      }
+    }
+    RS_SUBSTAMP(0);
+    __syncthreads();
+    RS_SUBSTAMP(1);
+    if (m->n_level[level] == 0) break;
+    /* R: rank of every stop inside its sub-range; the swapped pivot/median go back to LDS */
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int x = i * nt + tid;
+      const int c = i * nwaves + wave;
+      if (moved[i]) v[x] = e[i];
+      if (isA[i]) {
+        const int lo = F[i] + 1;
+        const int a = (lo >> 6) == c ? __popcll(mAi[i] & bit_range(lo & 63, lane)) : count_bits_in(m->maskA, lo, x);
+        posA[F[i] + a] = (uint16_t)x;
+      }
+      if (isB[i]) {
+        const int hi = L[i];
+        const int b = ((hi - 1) >> 6) == c ? __popcll(mBi[i] & bit_range(lane + 1, ((hi - 1) & 63) + 1))
+                                           : count_bits_in(m->maskB, x + 1, hi);
+        posB[F[i] + b] = (uint16_t)x;
+      }
+    }
+    RS_SUBSTAMP(2);
+    __syncthreads();
+    RS_SUBSTAMP(3);
+    /* S: the Hoare swaps (L[j], Rr[j]) and the cut */
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int x = i * nt + tid;
+      if (L[i] != 0 && x > F[i]) {
+        const int f = F[i];
+        const int j = x - f - 1;
+        const int l = posA[f + j], r = posB[f + j];
+        const int l1 = posA[f + j + 1], r1 = posB[f + j + 1];
+        const bool sw = l != 0xFFFF && r != 0xFFFF && l < r;
+        const bool sw1 = l1 != 0xFFFF && r1 != 0xFFFF && l1 < r1;
+        if (sw) {
+          const uint32_t a = v[l], b = v[r];
+          v[l] = b;
+          v[r] = a;
+          if (!sw1) cutbuf[f] = (uint16_t)((l1 != 0xFFFF && l1 < r) ? l1 : r);
+        } else if (j == 0) {
+          cutbuf[f] = (uint16_t)l;
+        }
+      }
+    }
+    RS_SUBSTAMP(4);
+    __syncthreads();
+    RS_SUBSTAMP(5);
+    /* U: move to the child sub-range; sub-ranges of at most 16 retire */
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int x = i * nt + tid;
+      if (L[i] != 0) {
+        const int cut = cutbuf[F[i]];
+        e[i] = v[x];
+        if (x < cut) L[i] = cut; else F[i] = cut;
+        if (L[i] - F[i] <= 16) L[i] = 0;
+        any |= L[i] != 0;
+      }
+    }
+    if (__ballot(any) && lane == 0) atomicAdd(&m->n_level[level + 1], 1);
+    RS_SUBSTAMP(6);
+#ifdef RS_STAMPS
+    if (tid == 0) sub[7] += 1;
+#endif
   }
 }
 
@@ -277,8 +466,8 @@ __device__ void counting_sort_desc(const uint32_t* v, uint32_t* out, int N, Misc
 #define RS_STAMP(i) do { } while (0)
 #endif
 
-template <int SCHED>
-__global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
+template <int SCHED, int EPT>
+__global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
   extern __shared__ __align__(16) unsigned char lds[];
   const int cell = blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -291,8 +480,6 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
   double* s_avgk = (double*)(lds + p.off_avgk);
   float* s_rcp32 = (float*)(lds + p.off_rcp);
   int32_t* s_tx = (int32_t*)(lds + p.off_tx);
-  int64_t* s_cumb = (int64_t*)(lds + p.off_cumb);
-  int32_t* s_cumr = (int32_t*)(lds + p.off_cumr);
   double* s_num = (double*)(lds + p.off_tab); /* metric numerator per CQI */
   double* s_e = s_num + 16;
   double* s_x = s_e + 16;
@@ -314,8 +501,6 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
   for (int u = tid; u < U; u += nt) {
     s_avg[u] = p.avg[(size_t)cell * U + u];
     s_tx[u] = p.tx_bytes[(size_t)cell * U + u];
-    s_cumb[u] = 0;
-    s_cumr[u] = 0;
   }
   for (int i = tid; i < (R + 1) * 27; i += nt) s_tbs[i] = p.tbs_eff[i];
   if (tid < 16) {
@@ -360,8 +545,13 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
   int local_err = 0;
   __syncthreads();
 
+#ifndef RS_STAMPS
+  unsigned long long* sort_sub = nullptr;
+#endif
 #ifdef RS_STAMPS
   unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long sort_sub_store[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long* sort_sub = sort_sub_store;
   unsigned long long stamp_prev = __builtin_readcyclecounter();
 #endif
   for (int tti = 0; tti < p.n_ttis; ++tti) {
@@ -587,7 +777,13 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
       }
       __syncthreads();
 #else
-      introsort_loop_parallel(s_elems, N, (uint16_t*)s_sorted, (uint16_t*)s_sorted + N, m);
+      {
+        uint16_t* sx = (uint16_t*)(lds + p.off_sortx);
+        uint16_t* pa = (uint16_t*)s_sorted;
+        /* EPT = array positions per thread, picked by the host (0: any size, state in LDS) */
+        if constexpr (EPT > 0) introsort_levels_reg<EPT>(s_elems, N, pa, pa + N, sx, m, sort_sub);
+        else introsort_loop_levels(s_elems, N, pa, pa + N, sx, sx + N, sx + 2 * N, sx + 3 * N, m);
+      }
 #endif
       RS_STAMP(3);
       counting_sort_desc(s_elems, s_sorted, N, m);
@@ -704,8 +900,9 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
           if (bytes > 100000000) bytes = 100000000;
           if (bytes > 0) {
             s_tx[owner] += bytes;
-            s_cumb[owner] += bytes;
-            s_cumr[owner] += nprb;
+            /* RadioBearer::m_cumulativeBytes / m_cumulativeRBs live in HBM: fire-and-forget atomics */
+            atomicAdd((unsigned long long*)&p.cum_bytes[(size_t)cell * U + owner], (unsigned long long)bytes);
+            atomicAdd((unsigned long long*)&p.cum_rbs[(size_t)cell * U + owner], (unsigned long long)nprb);
           }
         }
       }
@@ -739,8 +936,6 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
   for (int u = tid; u < U; u += nt) {
     p.avg[(size_t)cell * U + u] = s_avg[u];
     p.tx_bytes[(size_t)cell * U + u] = s_tx[u];
-    p.cum_bytes[(size_t)cell * U + u] += s_cumb[u];
-    p.cum_rbs[(size_t)cell * U + u] += s_cumr[u];
   }
   if (tid < S) p.slice_state[(size_t)cell * S + tid] = s_sstate[tid];
   if (wave == quota_wave && lane < 31) scal->rng_r[lane] = rng.r;
@@ -753,8 +948,10 @@ __global__ void __launch_bounds__(1024) rs_cell_kernel(RsLaunch p) {
     scal->n_done = n_done;
     if (local_err) atomicExch(p.err, local_err);
 #ifdef RS_STAMPS
-    if (p.stamps)
-      for (int i = 0; i < 12; ++i) p.stamps[(size_t)cell * 12 + i] = stamp_acc[i];
+    if (p.stamps) {
+      for (int i = 0; i < 12; ++i) p.stamps[(size_t)cell * 20 + i] = stamp_acc[i];
+      for (int i = 0; i < 8; ++i) p.stamps[(size_t)cell * 20 + 12 + i] = sort_sub[i];
+    }
 #endif
   }
   if (wave == quota_wave && lane == 0) {
@@ -823,26 +1020,32 @@ __global__ void rs_slice_bytes_kernel(const int64_t* cum_bytes, const uint8_t* u
 /* host-callable launchers (defined here so that the kernels stay in one translation unit) */
 extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_t stream) {
   dim3 grid(p->n_cells), block(threads);
+  const int N = p->R * p->S;
+  const int ept = (N + threads - 1) / threads;
   switch (p->sched) {
-    case 1: hipLaunchKernelGGL(rs_cell_kernel<1>, grid, block, p->lds_bytes, stream, *p); break;
-    case 7: hipLaunchKernelGGL(rs_cell_kernel<7>, grid, block, p->lds_bytes, stream, *p); break;
-    case 8: hipLaunchKernelGGL(rs_cell_kernel<8>, grid, block, p->lds_bytes, stream, *p); break;
-    case 9: hipLaunchKernelGGL(rs_cell_kernel<9>, grid, block, p->lds_bytes, stream, *p); break;
+    case 1: hipLaunchKernelGGL((rs_cell_kernel<1, 0>), grid, block, p->lds_bytes, stream, *p); break;
+    case 7: hipLaunchKernelGGL((rs_cell_kernel<7, 0>), grid, block, p->lds_bytes, stream, *p); break;
+    case 8: hipLaunchKernelGGL((rs_cell_kernel<8, 0>), grid, block, p->lds_bytes, stream, *p); break;
+    case 9:
+      if (ept <= 1) hipLaunchKernelGGL((rs_cell_kernel<9, 1>), grid, block, p->lds_bytes, stream, *p);
+      else if (ept <= 2) hipLaunchKernelGGL((rs_cell_kernel<9, 2>), grid, block, p->lds_bytes, stream, *p);
+      else if (ept <= 4) hipLaunchKernelGGL((rs_cell_kernel<9, 4>), grid, block, p->lds_bytes, stream, *p);
+      else hipLaunchKernelGGL((rs_cell_kernel<9, 0>), grid, block, p->lds_bytes, stream, *p);
+      break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes) {
-  hipError_t e;
-  e = hipFuncSetAttribute((const void*)rs_cell_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)rs_cell_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)rs_cell_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)rs_cell_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes);
-  return e;
+  const void* fns[] = {(const void*)rs_cell_kernel<1, 0>, (const void*)rs_cell_kernel<7, 0>, (const void*)rs_cell_kernel<8, 0>,
+                       (const void*)rs_cell_kernel<9, 0>, (const void*)rs_cell_kernel<9, 1>, (const void*)rs_cell_kernel<9, 2>,
+                       (const void*)rs_cell_kernel<9, 4>};
+  for (const void* f : fns) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,

@@ -87,7 +87,7 @@ def test_phy_error_draws_stream(rs, oracle):
     _check_batch(rs, oracle, 9, [5] * 20, 64, 8, n_cells=2, n_ttis=60, phy=1)
 
 
-@pytest.mark.parametrize("threads", [64, 128, 512, 1024])
+@pytest.mark.parametrize("threads", [64, 128, 320, 512])
 def test_workgroup_sizes(rs, oracle, threads):
     _check_batch(rs, oracle, 9, [5] * 20, 25, 4, n_cells=2, n_ttis=45, threads=threads)
 
