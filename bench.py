@@ -65,16 +65,35 @@ def cpu_baseline(args, slices, seeds):
         return time.perf_counter() - t0
 
     probe = one(0, grids_for(200), 200)  # calibrate: seconds per 200 TTIs on one core
-    n_ttis = int(max(200, min(40000, 12.0 / (probe / 200.0))))
+    per_core = 200.0 / probe
+
+    def run(threads, n_ttis, grids):
+        cells = [O.Cell(slices.ues_per_slice, R, args.rbg_size, args.sched, weights=slices.weight) for _ in range(threads)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda i: cells[i].run_synth(grids, int(seeds[i % len(seeds)]), n_ttis, log=False), range(threads)))
+        return threads * n_ttis / (time.perf_counter() - t0)
+
+    # os.cpu_count() can exceed what the container may use: find the thread count that actually scales
+    short = int(max(200, 1.0 * per_core))
+    g_short = grids_for(short)
+    best_t, best_rate, t = 1, per_core, 2
+    while t <= cores:
+        rate = run(t, short, g_short)
+        if rate > best_rate * 1.10:
+            best_t, best_rate = t, rate
+            t *= 2
+        else:
+            break
+    cores = best_t
+    n_ttis = int(max(200, min(40000, 10.0 * per_core)))
     grids = grids_for(n_ttis)
-    cells = [O.Cell(slices.ues_per_slice, R, args.rbg_size, args.sched, weights=slices.weight) for _ in range(cores)]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda i: cells[i].run_synth(grids, int(seeds[i % len(seeds)]), n_ttis, log=False), range(cores)))
-    wall = time.perf_counter() - t0
+    rate = run(cores, n_ttis, grids)
+    wall = cores * n_ttis / rate
     return {"value": cores * n_ttis / wall, "unit": "TTIs/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} independent cells x {n_ttis} TTIs of the same workload, one oracle "
-                      f"thread per host core; single core: {200.0 / probe:.0f} TTIs/s"}
+            "sample": f"{cores} independent cells x {n_ttis} TTIs of the same workload, one oracle thread each "
+                      f"(thread count = where throughput stopped scaling, os.cpu_count()={os.cpu_count()}); "
+                      f"single core: {per_core:.0f} TTIs/s"}
 
 
 def main():

@@ -356,7 +356,7 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   if (cfg->n_cells < 1) { fail(RS_ERR_INVALID, "n_cells %d < 1", cfg->n_cells); return nullptr; }
   if (!direct && cfg->cqi_refresh < 1) { fail(RS_ERR_INVALID, "cqi_refresh %d < 1", cfg->cqi_refresh); return nullptr; }
   if (cfg->first_tti < 0) { fail(RS_ERR_INVALID, "first_tti %d < 0", cfg->first_tti); return nullptr; }
-  int threads = cfg->threads_per_cell ? cfg->threads_per_cell : 256;
+  int threads = cfg->threads_per_cell ? cfg->threads_per_cell : 512;
   if (threads % 64 || threads < 64 || threads > 512) { fail(RS_ERR_INVALID, "threads_per_cell %d", threads); return nullptr; }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { fail(RS_ERR_NO_DEVICE, "no HIP device"); return nullptr; }

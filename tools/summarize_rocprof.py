@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Copy the rocprofv3 summaries gpurun merged into gpurun_out/ into profiles/ and derive
+profiles/traffic.json (HBM bytes per launch of the cell kernel from the PMC passes).
+
+    python tools/summarize_rocprof.py r01 sched9_S20_U500_R25_cells512_ttis400
+
+Counter handling per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE are collected in separate passes, both are in KiB, and on gfx950 FETCH_SIZE reports half
+of the bytes of wide (16 B/lane) coalesced reads, so the read side is doubled.  Other access widths
+are uncalibrated; the figure is an upper-bound style estimate of fabric-side traffic.
+"""
+import csv
+import glob
+import json
+import shutil
+import statistics
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+tag, key = sys.argv[1], sys.argv[2]
+out = ROOT / "profiles"
+
+
+def one(pattern):
+    f = sorted(glob.glob(str(ROOT / "gpurun_out" / pattern)))
+    if not f:
+        raise SystemExit(f"missing {pattern}")
+    return Path(f[-1])
+
+
+ks = one("prof_kt/*/*_kernel_stats.csv")
+shutil.copy(ks, out / f"{tag}_kernel_stats.csv")
+rows = list(csv.DictReader(ks.open()))
+cell = [r for r in rows if "rs_cell_kernel" in r["Name"]][0]
+
+
+def counter(pattern, name):
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(one(pattern).open())
+            if "rs_cell_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    return vals
+
+
+fetch = counter("prof_fetch/*/*_counter_collection.csv", "FETCH_SIZE")
+write = counter("prof_write/*/*_counter_collection.csv", "WRITE_SIZE")
+fetch_b = statistics.mean(fetch) * 1024 * 2  # gfx950: wide reads are tallied at half their bytes
+write_b = statistics.mean(write) * 1024
+traffic = {"kernel": cell["Name"], "launches_profiled": len(fetch),
+           "FETCH_SIZE_KiB_mean": statistics.mean(fetch), "WRITE_SIZE_KiB_mean": statistics.mean(write),
+           "hbm_read_bytes_per_launch": fetch_b, "hbm_write_bytes_per_launch": write_b,
+           "hbm_bytes_per_launch": fetch_b + write_b,
+           "kernel_trace_avg_ns": float(cell["AverageNs"]), "kernel_trace_calls": int(cell["Calls"]),
+           "note": "FETCH_SIZE doubled per the gfx950 correction; WRITE_SIZE includes the 8-byte "
+                   "cum_bytes/cum_rbs atomics (2 per served UE per TTI)"}
+tf = out / "traffic.json"
+tj = json.loads(tf.read_text()) if tf.exists() else {}
+tj[key] = traffic
+tf.write_text(json.dumps(tj, indent=1))
+print(json.dumps(traffic, indent=1))
