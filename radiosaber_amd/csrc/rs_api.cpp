@@ -213,14 +213,22 @@ int validate(const rs_config* c) {
   return RS_OK;
 }
 
+int upad_of(int U) {
+  int k = (U + 7) / 8;
+  if ((k & 1) == 0) k += 1; /* 8 * odd: 8-byte column reads of 32 consecutive RBGs hit 32 distinct bank pairs */
+  return 8 * k;
+}
+
 void carve_lds(rs_batch* b, RsLaunch* L) {
   const int U = b->U, R = b->R, S = b->S;
+  const int Upad = upad_of(U);
+  L->Upad = Upad;
   int n_seg = b->sched == RS_SCHED_PF ? (U + RS_PF_SEG - 1) / RS_PF_SEG : (b->sched == RS_SCHED_NVS ? 1 : S);
   int n_items = R * n_seg;
   int off = 0;
   off += 8 * U;               /* avg */
   L->off_avgk = off; off += 8 * U;
-  L->off_rcp = off; off += round_up(4 * U, 16);
+  L->off_rcp = off; off += round_up(4 * Upad, 16);
   L->off_tab = off; off += 8 * 48 + 64;
   L->off_slice = off; off += 8 * 128;
   L->off_tx = off; off += round_up(4 * U, 16);
@@ -234,7 +242,7 @@ void carve_lds(rs_batch* b, RsLaunch* L) {
     const int ept = (R * S + b->threads - 1) / b->threads;
     L->off_sortx = off; off += b->sched == RS_SCHED_MAXCELL ? round_up((ept <= 4 ? 2 : 8) * R * S, 16) : 0;
   }
-  L->off_cqi = off; off += round_up(U * R, 16);
+  L->off_cqi = off; off += round_up(Upad * R, 16);
   L->lds_bytes = off;
   L->n_seg = n_seg;
   L->n_items = n_items;
@@ -693,6 +701,7 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   HIP_TRY(hipMemsetAsync(c->d_uinfo, 0, 4 * (size_t)n, st));
   RsLaunch L = b->base;
   L.U = n;
+  L.Upad = upad_of(n);
   L.n_ttis = 1;
   L.direct = 1;
   L.rand0 = in->rand0;

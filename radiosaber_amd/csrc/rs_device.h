@@ -60,6 +60,7 @@ enum { RS_CQI_NONE = 0, RS_CQI_EPOCHS = 1, RS_CQI_TRACE = 2 };
 struct RsLaunch {
   /* geometry */
   int32_t S, U, R, G;        /* slices, users, RBGs, PRBs per RBG */
+  int32_t Upad;              /* LDS row stride of the RBG-major CQI grid: 8 * odd >= U */
   int32_t sched;
   int32_t n_cells, n_ttis;
   int32_t refresh, phy_draws;

@@ -73,6 +73,20 @@ struct BitBallots {
   }
 };
 
+/* C integer division (truncation toward zero) for |a| < 2^20, 1 <= b <= 512: one correctly rounded
+ * FP32 division instead of the ~35-instruction integer sequence; the fix-up makes it exact whatever
+ * the rounding did. */
+__device__ __forceinline__ int idiv_small(int a, int b) {
+  int q = (int)((float)a / (float)b);
+  int r = a - q * b;
+  if (a >= 0) {
+    if (r < 0) q--; else if (r >= b) q++;
+  } else {
+    if (r > 0) q++; else if (r <= -b) q--;
+  }
+  return q;
+}
+
 /* glibc TYPE_3 rand(): ring of 31 words held one per lane of one wave (lane l = r[l]); f, b uniform.
  * (glibc 2.35 stdlib/random_r.c __random_r; the reference draws from libc rand():
  *  downlink-transport-scheduler.cpp:490,511) */
@@ -492,7 +506,8 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
   uint32_t* s_sorted = (uint32_t*)(lds + p.off_sorted);
   Misc* m = (Misc*)(lds + p.off_misc);
   int32_t* s_tbs = (int32_t*)(lds + p.off_tbs); /* [R+1][27] TBS bits of n RBGs at itbs */
-  uint8_t* s_cqi = lds + p.off_cqi;
+  uint8_t* s_cqi = lds + p.off_cqi; /* [R][Upad], Upad = 8 * odd >= U: conflict-free 8-byte column reads */
+  const int Upad = p.Upad;
 
   const RsTables* tab = p.tab;
   RsCellScalars* scal = p.scal + cell;
@@ -503,6 +518,8 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
     s_tx[u] = p.tx_bytes[(size_t)cell * U + u];
   }
   for (int i = tid; i < (R + 1) * 27; i += nt) s_tbs[i] = p.tbs_eff[i];
+  for (int i = tid; i < (R * Upad) >> 2; i += nt) ((uint32_t*)s_cqi)[i] = 0;
+  for (int i = tid; i < Upad; i += nt) s_rcp32[i] = 0.0f;
   if (tid < 16) {
     s_num[tid] = SCHED == 1 ? tab->pfnum[tid] : tab->kbps[tid];
     s_e[tid] = tab->eesm_e[tid];
@@ -543,6 +560,10 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
   if (wave == quota_wave && lane < 31) rng.r = scal->rng_r[lane];
   const int nb_rbs = R * G;
   int local_err = 0;
+  /* bit k: the k-th user of this thread (u = tid + k*nt) belongs to a slice with psi == 1 */
+  uint32_t psi_mask = 0;
+  if (SCHED != 1)
+    for (int u = tid, k = 0; u < U; u += nt, ++k) psi_mask |= (p.psi[p.user_slice[u]] ? 1u : 0u) << k;
   __syncthreads();
 
 #ifndef RS_STAMPS
@@ -561,10 +582,22 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
       if (p.direct || n_done % p.refresh == 0) {
         long long e = p.direct ? 0 : n_done / p.refresh;
         if (e >= p.n_epochs) { local_err = RS_CQI_EPOCHS; e = p.n_epochs - 1; }
+        /* HBM grid is [U][R] (one row per UE, like the reference's per-UE CQI vectors); LDS keeps it
+         * RBG-major [R][Upad] so that the metric scan reads 8 consecutive UEs of one RBG per load */
         const uint4* src = (const uint4*)(p.epochs + ((size_t)cell * p.n_epochs + (size_t)e) * p.grid_stride);
-        uint4* dst = (uint4*)s_cqi;
         const int n16 = (int)(p.grid_stride >> 4);
-        for (int i = tid; i < n16; i += nt) dst[i] = src[i];
+        const int total = U * R;
+        for (int i = tid; i < n16; i += nt) {
+          const uint4 w = src[i];
+          const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+          int idx = i << 4;
+          int u = idx / R, r = idx - u * R;
+#pragma unroll
+          for (int k = 0; k < 16; ++k, ++idx) {
+            if (idx < total) s_cqi[r * Upad + u] = (uint8_t)(ww[k >> 2] >> ((k & 3) * 8));
+            if (++r == R) { r = 0; ++u; }
+          }
+        }
       }
     } else if (p.cqi_mode == RS_CQI_TRACE) {
       /* ref: src/device/CqiManager/cqi-manager.cpp:105-123 (interval 40),
@@ -578,7 +611,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
         for (int i = tid; i < U * R; i += nt) {
           int u = i / R, r = i - u * R;
           int tr = p.user_trace[(size_t)cell * U + u];
-          s_cqi[i] = p.trace[((size_t)tr * p.n_rows + row) * R + r];
+          s_cqi[r * Upad + u] = p.trace[((size_t)tr * p.n_rows + row) * R + r];
         }
       }
     }
@@ -586,7 +619,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
     {
       const bool do_ewma = !p.direct && !(t == last_update);
       const double dt = t - last_update;
-      for (int u = tid; u < U; u += nt) {
+      for (int u = tid, ku = 0; u < U; u += nt, ++ku) {
         double a = s_avg[u];
         if (do_ewma) {
           double rate = (double)(s_tx[u] * 8) / dt;
@@ -602,7 +635,8 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
           k += a;
           k /= 1000.0;
           s_avgk[u] = k;
-          s_rcp32[u] = (float)(1.0 / k); /* stage-1 ranking only, never part of a result */
+          /* stage-1 ranking only, never part of a result; psi == 0 slices rank on the numerator */
+          s_rcp32[u] = ((psi_mask >> ku) & 1u) ? (float)(1.0 / k) : 1.0f;
         } else {
           s_rcp32[u] = (float)(1.0 / a);
         }
@@ -631,20 +665,27 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
         int target = 0;
         if (has) target = (int)(nb_rbs * s_w[lane] + s_sstate[lane]);
         int extra = nb_rbs - wave_sum(target);
-        /* first non-empty slice in the rotation starting at rand % S */
-        int pos0 = has ? (int)(((long long)lane - (r0 % S) + S) % S) : 1 << 20;
+        /* first non-empty slice in the rotation k = (i + rand) % S, i = 0..S-1 */
+        const int r0m = (int)((unsigned)r0 % (unsigned)S), r1m = (int)((unsigned)r1 % (unsigned)S);
+        int pos0 = lane - r0m;
+        pos0 = pos0 < 0 ? pos0 + S : pos0;
+        pos0 = has ? pos0 : 1 << 20;
         int first0 = wave_min(pos0);
+        const int share = idiv_small(extra, nonempty), rem = extra - share * nonempty; /* C '/' and '%' */
         if (has) {
-          target += extra / nonempty;
-          if (pos0 == first0) target += extra % nonempty;
+          target += share;
+          if (pos0 == first0) target += rem;
         }
-        int quota = in ? (int)(target / G) : 0;
+        int quota = in ? idiv_small(target, G) : 0;
         int extra_g = R - wave_sum(quota);
-        int pos1 = has ? (int)(((long long)lane - (r1 % S) + S) % S) : 1 << 20;
+        int pos1 = lane - r1m;
+        pos1 = pos1 < 0 ? pos1 + S : pos1;
+        pos1 = has ? pos1 : 1 << 20;
         int first1 = wave_min(pos1);
+        const int share_g = idiv_small(extra_g, nonempty), rem_g = extra_g - share_g * nonempty;
         if (has) {
-          quota += extra_g / nonempty;
-          if (pos1 == first1) quota += extra_g % nonempty;
+          quota += share_g;
+          if (pos1 == first1) quota += rem_g;
         }
         m->target[lane] = target;
         m->quota[lane] = quota;
@@ -711,37 +752,58 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
           sl_eps = p.eps[sl];
           sl_psi = p.psi[sl];
         }
-        const uint8_t* cq = s_cqi + r;
+        const uint8_t* rowp = s_cqi + r * Upad;
         /* Exact two-stage argmax.  Stage 1 ranks the segment's users by the cheap
          * FP32 product a~ = fl32(num) * fl32(fl(1/den)), which is within 2^-22 (relative) of the
          * reference's rounded FP64 quotient q = fl(num/den); a user whose a~ is below (1 - 2^-19) of
          * the largest a~ has a strictly smaller q and can neither win nor tie.  Stage 2 evaluates
-         * the survivors with the real IEEE FP64 division, ascending user order, strict '>'. */
+         * the survivors with the real IEEE FP64 division, ascending user order, strict '>'.
+         * Stage 1 reads 8 users per step (one 8-byte CQI load, two 16-byte reciprocal loads), keeps
+         * the 32 products of a block in registers, takes their maximum, then marks the survivors. */
         const float kTol = 0x1.ffffcp-1f; /* 1 - 2^-19 */
-        for (int blk = ub; blk < ue; blk += 32) {
-          const int len = (ue - blk) < 32 ? (ue - blk) : 32;
-          float best_a = -3.0e38f, tol_a = -3.0e38f;
-          uint32_t cand = 0;
-          const uint8_t* pc = cq + blk * R;
-          for (int j = 0; j < len; ++j, pc += R) {
-            const int c = *pc;
-            const float num = (SCHED == 1 || sl_eps) ? s_num32[c] : 1.0f;
-            const float rcp = (SCHED == 1 || sl_psi) ? s_rcp32[blk + j] : 1.0f;
-            const float a = num * rcp;
-            const float ta = a * kTol;
-            const bool gt = a > best_a;
-            const bool reset = gt && (best_a < ta);
-            const bool add = gt || (a >= tol_a);
-            cand = reset ? 0u : cand;
-            cand |= add ? (1u << j) : 0u;
-            best_a = gt ? a : best_a;
-            tol_a = gt ? ta : tol_a;
+        const bool one_num = SCHED != 1 && !sl_eps;
+#ifdef RS_EXP_P3_SKIP
+        bu = ub; bkey = rowp[ub]; best = 1.0; /* timing experiment only: wrong results */
+        for (int blk = ue; blk < ue; blk += 32) {
+#else
+        for (int blk = ub & ~7; blk < ue; blk += 32) {
+#endif
+          /* a~ of the 32 users blk..blk+31 (0 for users outside [ub, ue) and for the padding) */
+          float av[32];
+          float best_a = 0.0f;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int u0 = blk + 8 * g;
+            uint2 cw = make_uint2(0u, 0u);
+            float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+            if (u0 < ue) {
+              cw = *(const uint2*)(rowp + u0);
+              ra = *(const float4*)(s_rcp32 + u0);
+              rb = *(const float4*)(s_rcp32 + u0 + 4);
+            }
+            const float rc[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int u = u0 + k;
+              const uint32_t c = ((k < 4 ? cw.x : cw.y) >> (8 * (k & 3))) & 15u;
+              const float nm = one_num ? 1.0f : s_num32[c];
+              const float a = (u >= ub && u < ue) ? nm * rc[k] : 0.0f;
+              av[8 * g + k] = a;
+              best_a = fmaxf(best_a, a);
+            }
           }
+          const float thr = best_a * kTol;
+          uint32_t cand = 0;
+#pragma unroll
+          for (int k = 0; k < 32; ++k) cand |= (av[k] >= thr && av[k] > 0.0f) ? (1u << k) : 0u;
+#ifdef RS_EXP_ONE_CAND
+          if (cand) cand = 1u << (31 - __clz((int)cand)); /* timing experiment only: wrong results */
+#endif
           while (cand) {
             const int j = __ffs((int)cand) - 1;
             cand &= cand - 1;
             const int u = blk + j;
-            const int c = cq[u * R];
+            const int c = rowp[u];
             double metric;
             if (SCHED == 1) {
               /* ref: dl-pf-packet-scheduler.cpp:128-140  (se*180000.)/avg */
@@ -876,11 +938,11 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
          * (src/utility/eesm-effective-sinr.h:33-46 with the exp() values tabulated by the host) */
         unsigned long long mm = leader ? same : 0ull;
         double sum = 0;
-        const uint8_t* row = s_cqi + (owner < 0 ? 0 : owner) * R;
+        const uint8_t* col = s_cqi + (owner < 0 ? 0 : owner);
         while (mm) {
           const int r2 = __ffsll((long long)mm) - 1;
           mm &= mm - 1;
-          const double ev = s_e[row[r2]];
+          const double ev = s_e[col[r2 * Upad]];
           for (int k = 0; k < G; ++k) sum += ev;
           nprb += G;
         }
