@@ -796,9 +796,6 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
           uint32_t cand = 0;
 #pragma unroll
           for (int k = 0; k < 32; ++k) cand |= (av[k] >= thr && av[k] > 0.0f) ? (1u << k) : 0u;
-#ifdef RS_EXP_ONE_CAND
-          if (cand) cand = 1u << (31 - __clz((int)cand)); /* timing experiment only: wrong results */
-#endif
           while (cand) {
             const int j = __ffs((int)cand) - 1;
             cand &= cand - 1;

@@ -25,9 +25,10 @@ def _oracle_cells(oracle, ues, R, G, sched, weights, grids, seeds, n_ttis, eps=N
     return out
 
 
-def _check_batch(rs, oracle, sched, ues, R, G, n_cells, n_ttis, threads=0, eps=None, psi=None, phy=0, seed=1):
+def _check_batch(rs, oracle, sched, ues, R, G, n_cells, n_ttis, threads=0, eps=None, psi=None, phy=0, seed=1,
+                 weights=None):
     S = len(ues)
-    weights = [1.0 / S] * S
+    weights = weights or [1.0 / S] * S
     sc = rs.SliceConfig(ues, weight=weights, algo_epsilon=eps or [], algo_psi=psi or [])
     U = sc.n_users
     n_epochs = (n_ttis + 39) // 40
@@ -72,6 +73,21 @@ def test_ragged_slices_and_empty_slice(rs, oracle):
     # slice 2 has no UE at all, sizes differ
     _check_batch(rs, oracle, 9, [3, 7, 0, 1, 12], 25, 4, n_cells=2, n_ttis=50)
     _check_batch(rs, oracle, 8, [3, 7, 0, 1, 12], 25, 4, n_cells=2, n_ttis=50)
+
+
+def test_skewed_weights_negative_quotas(rs, oracle):
+    # a slice whose weight is far below its share keeps a negative slice_rbs_offset_ / quota
+    # (the reference's "(2, -20, -2)" lines): C truncation toward zero must be reproduced
+    w = [0.62, 0.3, 0.05, 0.02, 0.01]
+    _check_batch(rs, oracle, 9, [10, 10, 10, 10, 10], 25, 4, n_cells=3, n_ttis=120, weights=w)
+    _check_batch(rs, oracle, 8, [10, 10, 10, 10, 10], 64, 8, n_cells=2, n_ttis=80, weights=w)
+
+
+def test_many_slices_and_big_slices(rs, oracle):
+    _check_batch(rs, oracle, 9, [2] * 64, 25, 4, n_cells=2, n_ttis=50)      # S = 64 (lane limit)
+    _check_batch(rs, oracle, 9, [70, 45, 5], 25, 4, n_cells=2, n_ttis=50)   # slices longer than one 32-user block
+    _check_batch(rs, oracle, 1, [70, 45, 5], 25, 4, n_cells=2, n_ttis=50)
+    _check_batch(rs, oracle, 7, [70, 45, 5], 25, 4, n_cells=2, n_ttis=50)
 
 
 def test_single_user_single_slice(rs, oracle):
@@ -120,6 +136,33 @@ def test_trace_replay_appendix_a(rs, oracle, traces):
     np.testing.assert_array_equal(got["tbs_bits"][0], logs["tbs_bits"])
     np.testing.assert_array_equal(got["quota"][0], logs["quota"])
     b.close()
+
+
+def test_trace_replay_500_ues_all_schedulers(rs, oracle, traces):
+    """BASELINE configs[1]: 20 x 25 UEs on the real CQI traces (64 RBGs), GPU vs CPU oracle bit for bit.
+    (The reference's own rand() position for this config is not recorded anywhere; a fixed skip is used.)"""
+    ues = [25] * 20
+    sc = rs.SliceConfig(ues, weight=[0.05] * 20)
+    U = sc.n_users
+    for sched, mapping in ((9, 1), (8, 2), (7, 3), (1, 0)):
+        b = rs.BatchScheduler(sc, 64, 8, 1, sched=sched, phy_error_draws=True)
+        b.seed(np.array([749913912], np.uint32), np.array([5000], np.int64))
+        b.set_trace(traces["cqi"], traces["mapping"][mapping][np.arange(U) % 474][None, :])
+        got = b.run_logged(130)
+        st = b.state()
+        cell = oracle.Cell(ues, 64, 8, sched, weights=[0.05] * 20)
+        logs = cell.run_trace(traces["cqi"], traces["mapping"][mapping], 749913912, 5000, 130)
+        np.testing.assert_array_equal(got["rbg_to_user"][0], logs["rbg_to_user"], err_msg=f"sched {sched}")
+        np.testing.assert_array_equal(got["tbs_bits"][0], logs["tbs_bits"], err_msg=f"sched {sched}")
+        np.testing.assert_array_equal(st["cum_bytes"][0], cell.state()["cum_bytes"])
+        assert st["avg_rate"][0].tobytes() == cell.state()["avg_rate"].tobytes()
+        b.close()
+
+
+def test_1000_ues_config3(rs, oracle):
+    """BASELINE configs[2] shape: 20 slices x 50 UEs, schedulers 1/7/8/9 on synthetic sub-band CQI."""
+    for sched in (9, 8, 7, 1):
+        _check_batch(rs, oracle, sched, [50] * 20, 25, 4, n_cells=1, n_ttis=45)
 
 
 def test_device_synth_grids_in_range_and_runs(rs, oracle):
