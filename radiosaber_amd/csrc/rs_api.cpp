@@ -389,6 +389,7 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
 
 int check_device_err(rs_batch* b) {
   int e = 0;
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   HIP_TRY(hipMemcpy(&e, b->d_err, 4, hipMemcpyDeviceToHost));
   if (e) {
     HIP_TRY(hipMemset(b->d_err, 0, 4));
@@ -404,6 +405,7 @@ int check_device_err(rs_batch* b) {
 int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d_target, int32_t* d_tbs, int32_t* d_uinfo) {
   if (n_ttis < 1) return fail(RS_ERR_INVALID, "n_ttis %d < 1", n_ttis);
   if (b->cqi_mode == RS_CQI_NONE) return fail(RS_ERR_STATE, "no CQI source set");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   RsLaunch L = b->base;
   L.n_ttis = n_ttis;
   L.cqi_mode = b->cqi_mode;
@@ -435,12 +437,14 @@ void rs_batch_destroy(rs_batch* b) {
 
 int rs_batch_seed(rs_batch* b, const uint32_t* seed, const int64_t* rand_skip) {
   if (!b || !seed) return fail(RS_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   if (b->ttis_done) return fail(RS_ERR_STATE, "rs_batch_seed after TTIs were run");
   return init_scalars(b, seed, rand_skip);
 }
 
 int rs_batch_upload_cqi_epochs(rs_batch* b, const uint8_t* h_cqi, int32_t n_epochs) {
   if (!b || !h_cqi || n_epochs < 1) return fail(RS_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   const size_t grid = (size_t)b->U * b->R;
   const size_t stride = round_up((int)grid, 16);
   const size_t total = (size_t)b->n_cells * n_epochs;
@@ -459,6 +463,7 @@ int rs_batch_upload_cqi_epochs(rs_batch* b, const uint8_t* h_cqi, int32_t n_epoc
 
 int rs_batch_synthesize_cqi(rs_batch* b, uint64_t seed, const double* w, int32_t n_epochs) {
   if (!b || !w || n_epochs < 1) return fail(RS_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   double tot = 0;
   for (int i = 0; i < 15; i++) {
     if (!(w[i] >= 0)) return fail(RS_ERR_INVALID, "negative CQI weight");
@@ -524,6 +529,7 @@ int rs_batch_run_async(rs_batch* b, int32_t n_ttis) {
 
 int rs_batch_sync(rs_batch* b) {
   if (!b) return fail(RS_ERR_INVALID, "null batch");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   return check_device_err(b);
 }
@@ -536,6 +542,7 @@ int rs_batch_run(rs_batch* b, int32_t n_ttis) {
 
 int rs_batch_run_logged(rs_batch* b, int32_t n_ttis, int16_t* h_map, int32_t* h_tbs, int16_t* h_quota) {
   if (!b) return fail(RS_ERR_INVALID, "null batch");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   if (n_ttis < 1) return fail(RS_ERR_INVALID, "n_ttis %d < 1", n_ttis);
   const size_t rows = (size_t)b->n_cells * n_ttis;
   int16_t *d_map = nullptr, *d_quota = nullptr;
@@ -559,6 +566,7 @@ int rs_batch_run_logged(rs_batch* b, int32_t n_ttis, int16_t* h_map, int32_t* h_
 
 int rs_batch_run_timed(rs_batch* b, int32_t n_ttis, int32_t launches, float* ms) {
   if (!b || !ms || launches < 1) return fail(RS_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   std::vector<hipEvent_t> ev(launches + 1);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   int rc = RS_OK;
@@ -576,6 +584,7 @@ int rs_batch_run_timed(rs_batch* b, int32_t n_ttis, int32_t launches, float* ms)
 
 int rs_batch_read_state(rs_batch* b, double* avg, int64_t* cum_bytes, int64_t* cum_rbs, double* slice_state) {
   if (!b) return fail(RS_ERR_INVALID, "null batch");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   const size_t n = (size_t)b->n_cells * b->U;
   if (avg) HIP_TRY(hipMemcpy(avg, b->d_avg, 8 * n, hipMemcpyDeviceToHost));
@@ -587,6 +596,7 @@ int rs_batch_read_state(rs_batch* b, double* avg, int64_t* cum_bytes, int64_t* c
 
 int rs_batch_slice_bytes_device(rs_batch* b, uint64_t* d_out) {
   if (!b || !d_out) return fail(RS_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   HIP_TRY(rs_launch_slice_bytes(b->d_cumb, b->d_user_slice, b->n_cells, b->U, b->S, (unsigned long long*)d_out, b->stream));
   return RS_OK;
 }
@@ -676,6 +686,7 @@ void rs_destroy(rs_ctx* c) {
 int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   if (!c || !in || !out) return fail(RS_ERR_INVALID, "null argument");
   rs_batch* b = c->b;
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   const int n = in->n_users, R = b->R, S = b->S;
   if (n < 1 || n > b->U) return fail(RS_ERR_INVALID, "n_users %d outside 1..%d", n, b->U);
   if (!in->cqi || !in->avg_rate) return fail(RS_ERR_INVALID, "null cqi/avg_rate");
