@@ -825,6 +825,12 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
     RS_STAMP(2);
 
     /* ---------------- P4: inter-slice assignment ---------------- */
+#ifdef RS_EXP_NO_SORT
+    if (SCHED == 9) { /* counter experiment only (tools/pmc_insts.sh): wrong results */
+      for (int i = tid; i < R * S; i += nt) s_sorted[i] = s_elems[i];
+      __syncthreads();
+    } else
+#endif
     if (SCHED == 9) {
       const int N = R * S;
       /* std::sort emulation (:361): introsort loop, then the final insertion sort */
