@@ -174,11 +174,12 @@ int rs_batch_run(rs_batch* b, int32_t n_ttis);
 /* same, not waiting (for overlap and hipEvent timing by the caller) */
 int rs_batch_run_async(rs_batch* b, int32_t n_ttis);
 int rs_batch_sync(rs_batch* b);
-/* same as rs_batch_run, also returning the per-TTI decisions of every cell (parity tests):
+/* same as rs_batch_run, also returning the per-TTI decisions of every cell (parity tests, log writer):
  * h_rbg_to_user [n_cells][n_ttis][R] (int16, -1 = none), h_tbs_bits [n_cells][n_ttis][U] (int32),
- * h_quota [n_cells][n_ttis][S] (int16); any may be NULL */
+ * h_quota / h_target [n_cells][n_ttis][S] (int16), h_uinfo [n_cells][n_ttis][U] (int32:
+ * nPRB | final_cqi << 16 | mcs << 24, 0 = not scheduled); any may be NULL */
 int rs_batch_run_logged(rs_batch* b, int32_t n_ttis, int16_t* h_rbg_to_user, int32_t* h_tbs_bits,
-                        int16_t* h_quota);
+                        int16_t* h_quota, int16_t* h_target, int32_t* h_uinfo);
 /* `launches` back-to-back launches of n_ttis each, timed with HIP events on the batch's stream;
  * ms_per_launch[launches] receives each launch's duration */
 int rs_batch_run_timed(rs_batch* b, int32_t n_ttis, int32_t launches, float* ms_per_launch);

@@ -106,7 +106,7 @@ def lib():
     L.rs_batch_run_async.argtypes = [C.c_void_p, C.c_int32]
     L.rs_batch_sync.argtypes = [C.c_void_p]
     L.rs_batch_run_logged.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int16), C.POINTER(C.c_int32),
-                                      C.POINTER(C.c_int16)]
+                                      C.POINTER(C.c_int16), C.POINTER(C.c_int16), C.POINTER(C.c_int32)]
     L.rs_batch_run_timed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     L.rs_batch_read_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_double)]
@@ -333,8 +333,12 @@ class BatchScheduler:
         m = np.zeros((self.n_cells, n_ttis, self.R), np.int16)
         tb = np.zeros((self.n_cells, n_ttis, self.U), np.int32)
         q = np.zeros((self.n_cells, n_ttis, self.S), np.int16)
-        _check(lib().rs_batch_run_logged(self._h, n_ttis, _p(m, C.c_int16), _p(tb, C.c_int32), _p(q, C.c_int16)))
-        return {"rbg_to_user": m, "tbs_bits": tb, "quota": q}
+        tg = np.zeros((self.n_cells, n_ttis, self.S), np.int16)
+        ui = np.zeros((self.n_cells, n_ttis, self.U), np.int32)
+        _check(lib().rs_batch_run_logged(self._h, n_ttis, _p(m, C.c_int16), _p(tb, C.c_int32), _p(q, C.c_int16),
+                                         _p(tg, C.c_int16), _p(ui, C.c_int32)))
+        return {"rbg_to_user": m, "tbs_bits": tb, "quota": q, "target": tg, "nprb": ui & 0xFFFF,
+                "final_cqi": (ui >> 16) & 0xFF, "mcs": (ui >> 24) & 0xFF}
 
     def run_timed(self, n_ttis, launches):
         ms = np.zeros(launches, np.float32)

@@ -540,27 +540,35 @@ int rs_batch_run(rs_batch* b, int32_t n_ttis) {
   return rs_batch_sync(b);
 }
 
-int rs_batch_run_logged(rs_batch* b, int32_t n_ttis, int16_t* h_map, int32_t* h_tbs, int16_t* h_quota) {
+int rs_batch_run_logged(rs_batch* b, int32_t n_ttis, int16_t* h_map, int32_t* h_tbs, int16_t* h_quota,
+                        int16_t* h_target, int32_t* h_uinfo) {
   if (!b) return fail(RS_ERR_INVALID, "null batch");
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   if (n_ttis < 1) return fail(RS_ERR_INVALID, "n_ttis %d < 1", n_ttis);
   const size_t rows = (size_t)b->n_cells * n_ttis;
-  int16_t *d_map = nullptr, *d_quota = nullptr;
-  int32_t* d_tbs = nullptr;
+  int16_t *d_map = nullptr, *d_quota = nullptr, *d_target = nullptr;
+  int32_t *d_tbs = nullptr, *d_uinfo = nullptr;
   HIP_TRY(hipMalloc(&d_map, 2 * rows * b->R));
   HIP_TRY(hipMalloc(&d_quota, 2 * rows * b->S));
+  HIP_TRY(hipMalloc(&d_target, 2 * rows * b->S));
   HIP_TRY(hipMalloc(&d_tbs, 4 * rows * b->U));
+  HIP_TRY(hipMalloc(&d_uinfo, 4 * rows * b->U));
   HIP_TRY(hipMemsetAsync(d_tbs, 0, 4 * rows * b->U, b->stream));
-  int rc = launch(b, n_ttis, d_map, d_quota, nullptr, d_tbs, nullptr);
+  HIP_TRY(hipMemsetAsync(d_uinfo, 0, 4 * rows * b->U, b->stream));
+  int rc = launch(b, n_ttis, d_map, d_quota, d_target, d_tbs, d_uinfo);
   if (!rc) rc = rs_batch_sync(b);
   if (!rc) {
     if (h_map) HIP_TRY(hipMemcpy(h_map, d_map, 2 * rows * b->R, hipMemcpyDeviceToHost));
     if (h_quota) HIP_TRY(hipMemcpy(h_quota, d_quota, 2 * rows * b->S, hipMemcpyDeviceToHost));
+    if (h_target) HIP_TRY(hipMemcpy(h_target, d_target, 2 * rows * b->S, hipMemcpyDeviceToHost));
     if (h_tbs) HIP_TRY(hipMemcpy(h_tbs, d_tbs, 4 * rows * b->U, hipMemcpyDeviceToHost));
+    if (h_uinfo) HIP_TRY(hipMemcpy(h_uinfo, d_uinfo, 4 * rows * b->U, hipMemcpyDeviceToHost));
   }
   (void)hipFree(d_map);
   (void)hipFree(d_quota);
+  (void)hipFree(d_target);
   (void)hipFree(d_tbs);
+  (void)hipFree(d_uinfo);
   return rc;
 }
 

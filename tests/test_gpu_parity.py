@@ -135,6 +135,12 @@ def test_trace_replay_appendix_a(rs, oracle, traces):
     np.testing.assert_array_equal(got["rbg_to_user"][0], logs["rbg_to_user"])
     np.testing.assert_array_equal(got["tbs_bits"][0], logs["tbs_bits"])
     np.testing.assert_array_equal(got["quota"][0], logs["quota"])
+    np.testing.assert_array_equal(got["target"][0], logs["target"])
+    np.testing.assert_array_equal(got["final_cqi"][0], logs["final_cqi"])
+    # the reference's stderr lines rebuilt from the device log
+    from radiosaber_amd import logfmt
+    err = logfmt.stderr_lines(got["tbs_bits"][0], got["rbg_to_user"][0], sc.user_to_slice, 8)
+    assert "299 app: 5 cumu_bytes: 110838 cumu_rbs: 1336 hol_delay: 0 user: 5 slice: 1" in err
     b.close()
 
 
