@@ -636,7 +636,7 @@ const char* rs_batch_kernel_name(rs_batch* b) {
     case 8: return "rs_cell_kernel<8, 0>";
     default: {
       const int ept = (b->R * b->S + b->threads - 1) / b->threads;
-      return ept <= 1 ? "rs_cell_kernel<9, 1>" : ept <= 2 ? "rs_cell_kernel<9, 2>" : ept <= 4 ? "rs_cell_kernel<9, 4>" : "rs_cell_kernel<9, 0>";
+      return ept <= 1 ? "rs_cell_kernel<9, 1>" : ept <= 2 ? "rs_cell_kernel<9, 2>" : ept <= 3 ? "rs_cell_kernel<9, 3>" : ept <= 4 ? "rs_cell_kernel<9, 4>" : "rs_cell_kernel<9, 0>";
     }
   }
 }

@@ -1094,6 +1094,7 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
     case 9:
       if (ept <= 1) hipLaunchKernelGGL((rs_cell_kernel<9, 1>), grid, block, p->lds_bytes, stream, *p);
       else if (ept <= 2) hipLaunchKernelGGL((rs_cell_kernel<9, 2>), grid, block, p->lds_bytes, stream, *p);
+      else if (ept <= 3) hipLaunchKernelGGL((rs_cell_kernel<9, 3>), grid, block, p->lds_bytes, stream, *p);
       else if (ept <= 4) hipLaunchKernelGGL((rs_cell_kernel<9, 4>), grid, block, p->lds_bytes, stream, *p);
       else hipLaunchKernelGGL((rs_cell_kernel<9, 0>), grid, block, p->lds_bytes, stream, *p);
       break;
@@ -1104,7 +1105,7 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
 
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes) {
   const void* fns[] = {(const void*)rs_cell_kernel<1, 0>, (const void*)rs_cell_kernel<7, 0>, (const void*)rs_cell_kernel<8, 0>,
-                       (const void*)rs_cell_kernel<9, 0>, (const void*)rs_cell_kernel<9, 1>, (const void*)rs_cell_kernel<9, 2>,
+                       (const void*)rs_cell_kernel<9, 0>, (const void*)rs_cell_kernel<9, 1>, (const void*)rs_cell_kernel<9, 2>, (const void*)rs_cell_kernel<9, 3>,
                        (const void*)rs_cell_kernel<9, 4>};
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes);
