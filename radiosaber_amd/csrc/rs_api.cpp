@@ -648,13 +648,32 @@ const char* rs_batch_kernel_name(rs_batch* b) {
 
 struct rs_ctx {
   rs_batch* b = nullptr;
-  int16_t *d_map = nullptr, *d_quota = nullptr, *d_target = nullptr;
-  int32_t *d_tbs = nullptr, *d_uinfo = nullptr;
-  uint8_t* d_grid = nullptr;
-  std::vector<uint8_t> h_grid, h_slice;
-  std::vector<int16_t> h_map, h_quota, h_target;
-  std::vector<int32_t> h_tbs, h_uinfo;
+  /* one pinned staging block each way, mirrored by one device block each way:
+   *   in : [ CQI grid, stride bytes | user slice ids, round16(U) | avg_rate f64[U] ]
+   *   out: [ tbs i32[U] | uinfo i32[U] | map i16[R] | quota i16[S] | target i16[S] ] */
+  uint8_t *h_in = nullptr, *d_in = nullptr, *h_out = nullptr, *d_out = nullptr;
+  size_t in_bytes = 0, out_bytes = 0;
 };
+
+namespace {
+struct CtxLayout {
+  size_t grid, slice, avg, in_total, tbs, uinfo, map, quota, target, out_total;
+};
+CtxLayout ctx_layout(int n, int R, int S) {
+  CtxLayout l;
+  l.grid = 0;
+  l.slice = round_up(n * R, 16);
+  l.avg = l.slice + round_up(n, 16);
+  l.in_total = l.avg + 8 * (size_t)n;
+  l.tbs = 0;
+  l.uinfo = 4 * (size_t)n;
+  l.map = 8 * (size_t)n;
+  l.quota = l.map + round_up(2 * R, 8);
+  l.target = l.quota + round_up(2 * S, 8);
+  l.out_total = l.target + round_up(2 * S, 8);
+  return l;
+}
+}  // namespace
 
 extern "C" {
 
@@ -670,23 +689,23 @@ rs_ctx* rs_create(const rs_config* cfg) {
   rs_ctx* c = new (std::nothrow) rs_ctx();
   if (!c) { rs_batch_destroy(b); fail(RS_ERR_INVALID, "out of memory"); return nullptr; }
   c->b = b;
-  const int U = b->U, R = b->R, S = b->S;
-  const size_t stride = round_up(U * R, 16);
-  bool ok = hipMalloc(&c->d_map, 2 * R) == hipSuccess && hipMalloc(&c->d_quota, 2 * S) == hipSuccess &&
-            hipMalloc(&c->d_target, 2 * S) == hipSuccess && hipMalloc(&c->d_tbs, 4 * U) == hipSuccess &&
-            hipMalloc(&c->d_uinfo, 4 * U) == hipSuccess && hipMalloc(&c->d_grid, stride) == hipSuccess;
-  if (!ok) { fail(RS_ERR_HIP, "hipMalloc failed"); rs_destroy(c); return nullptr; }
-  c->h_grid.resize(stride); c->h_slice.resize(U);
-  c->h_map.resize(R); c->h_quota.resize(S); c->h_target.resize(S); c->h_tbs.resize(U); c->h_uinfo.resize(U);
+  const CtxLayout l = ctx_layout(b->U, b->R, b->S);
+  c->in_bytes = l.in_total;
+  c->out_bytes = l.out_total;
+  bool ok = hipMalloc(&c->d_in, c->in_bytes) == hipSuccess && hipMalloc(&c->d_out, c->out_bytes) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_in, c->in_bytes, hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_out, c->out_bytes, hipHostMallocDefault) == hipSuccess;
+  if (!ok) { fail(RS_ERR_HIP, "allocation of the staging blocks failed"); rs_destroy(c); return nullptr; }
   return c;
 }
 
 void rs_destroy(rs_ctx* c) {
   if (!c) return;
-  void* ptrs[] = {c->d_map, c->d_quota, c->d_target, c->d_tbs, c->d_uinfo, c->d_grid};
   if (c->b && c->b->stream) (void)hipStreamSynchronize(c->b->stream);
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+  if (c->d_in) (void)hipFree(c->d_in);
+  if (c->d_out) (void)hipFree(c->d_out);
+  if (c->h_in) (void)hipHostFree(c->h_in);
+  if (c->h_out) (void)hipHostFree(c->h_out);
   rs_batch_destroy(c->b);
   delete c;
 }
@@ -699,25 +718,23 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   if (n < 1 || n > b->U) return fail(RS_ERR_INVALID, "n_users %d outside 1..%d", n, b->U);
   if (!in->cqi || !in->avg_rate) return fail(RS_ERR_INVALID, "null cqi/avg_rate");
   if (!out->rbg_to_user || !out->user_tbs_bits) return fail(RS_ERR_INVALID, "null output array");
+  const CtxLayout l = ctx_layout(n, R, S);
+  uint8_t* h_slice = c->h_in + l.slice;
   for (int i = 0; i < n; i++) {
     int id = in->user_id ? in->user_id[i] : i;
     if (id < 0 || id >= b->U) return fail(RS_ERR_INVALID, "user id %d out of range", id);
     if (i && in->user_id && in->user_id[i] <= in->user_id[i - 1]) return fail(RS_ERR_INVALID, "user_id must ascend");
-    c->h_slice[i] = (uint8_t)b->u2s[id];
-    if (b->sched == RS_SCHED_NVS && c->h_slice[i] != c->h_slice[0])
+    h_slice[i] = (uint8_t)b->u2s[id];
+    if (b->sched == RS_SCHED_NVS && h_slice[i] != h_slice[0])
       return fail(RS_ERR_INVALID, "RS_SCHED_NVS: pass only the users of the served slice");
   }
   for (int i = 0; i < n * R; i++)
     if (in->cqi[i] < 1 || in->cqi[i] > 15) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", in->cqi[i]);
-  const size_t stride = round_up(n * R, 16);
-  memset(c->h_grid.data(), 0, stride);
-  memcpy(c->h_grid.data(), in->cqi, (size_t)n * R);
+  memcpy(c->h_in + l.grid, in->cqi, (size_t)n * R);
+  memset(c->h_in + l.grid + (size_t)n * R, 0, l.slice - (size_t)n * R);
+  memcpy(c->h_in + l.avg, in->avg_rate, 8 * (size_t)n);
   hipStream_t st = b->stream;
-  HIP_TRY(hipMemcpyAsync(c->d_grid, c->h_grid.data(), stride, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(b->d_user_slice, c->h_slice.data(), n, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(b->d_avg, in->avg_rate, 8 * (size_t)n, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(c->d_tbs, 0, 4 * (size_t)n, st));
-  HIP_TRY(hipMemsetAsync(c->d_uinfo, 0, 4 * (size_t)n, st));
+  HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, l.in_total, hipMemcpyHostToDevice, st));
   RsLaunch L = b->base;
   L.U = n;
   L.Upad = upad_of(n);
@@ -727,33 +744,40 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   L.rand1 = in->rand1;
   L.cqi_mode = RS_CQI_EPOCHS;
   L.refresh = 1;
-  L.epochs = c->d_grid;
-  L.grid_stride = (int64_t)stride;
-  L.n_epochs = 1 << 30; /* the single grid is re-read on every call */
+  L.epochs = c->d_in + l.grid;
+  L.grid_stride = (int64_t)l.slice;
+  L.n_epochs = 1;
+  L.user_slice = c->d_in + l.slice;
+  L.avg = (double*)(c->d_in + l.avg);
   if (b->sched == RS_SCHED_PF) { L.n_seg = (n + RS_PF_SEG - 1) / RS_PF_SEG; L.n_items = R * L.n_seg; }
-  L.log_map = c->d_map; L.log_quota = c->d_quota; L.log_target = c->d_target; L.log_tbs = c->d_tbs; L.log_uinfo = c->d_uinfo;
-  /* one grid only: epoch index must stay 0 -> run with n_done forced to 0 by the direct flag */
+  L.log_tbs = (int32_t*)(c->d_out + l.tbs);
+  L.log_uinfo = (int32_t*)(c->d_out + l.uinfo);
+  L.log_map = (int16_t*)(c->d_out + l.map);
+  L.log_quota = (int16_t*)(c->d_out + l.quota);
+  L.log_target = (int16_t*)(c->d_out + l.target);
+  /* direct mode: the kernel clears its per-user outputs itself and reads the single grid on every call */
   HIP_TRY(rs_launch_cells(&L, b->threads, st));
-  HIP_TRY(hipMemcpyAsync(c->h_map.data(), c->d_map, 2 * R, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(c->h_quota.data(), c->d_quota, 2 * S, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(c->h_target.data(), c->d_target, 2 * S, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(c->h_tbs.data(), c->d_tbs, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(c->h_uinfo.data(), c->d_uinfo, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, l.out_total, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  const int16_t* h_map = (const int16_t*)(c->h_out + l.map);
+  const int16_t* h_quota = (const int16_t*)(c->h_out + l.quota);
+  const int16_t* h_target = (const int16_t*)(c->h_out + l.target);
+  const int32_t* h_tbs = (const int32_t*)(c->h_out + l.tbs);
+  const int32_t* h_uinfo = (const int32_t*)(c->h_out + l.uinfo);
   for (int r = 0; r < R; r++) {
-    int o = c->h_map[r];
+    int o = h_map[r];
     out->rbg_to_user[r] = o < 0 ? -1 : (in->user_id ? in->user_id[o] : o);
   }
   for (int s = 0; s < S; s++) {
-    if (out->target_rbs) out->target_rbs[s] = c->h_target[s];
-    if (out->quota_rbgs) out->quota_rbgs[s] = c->h_quota[s];
+    if (out->target_rbs) out->target_rbs[s] = h_target[s];
+    if (out->quota_rbgs) out->quota_rbgs[s] = h_quota[s];
   }
   for (int i = 0; i < n; i++) {
-    int32_t ui = c->h_uinfo[i];
+    int32_t ui = h_uinfo[i];
     if (out->user_nprb) out->user_nprb[i] = ui & 0xFFFF;
     if (out->user_final_cqi) out->user_final_cqi[i] = (ui >> 16) & 0xFF;
     if (out->user_mcs) out->user_mcs[i] = (ui >> 24) & 0xFF;
-    out->user_tbs_bits[i] = c->h_tbs[i];
+    out->user_tbs_bits[i] = h_tbs[i];
   }
   return RS_OK;
 }

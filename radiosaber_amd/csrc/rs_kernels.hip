@@ -516,6 +516,10 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
   for (int u = tid; u < U; u += nt) {
     s_avg[u] = p.avg[(size_t)cell * U + u];
     s_tx[u] = p.tx_bytes[(size_t)cell * U + u];
+    if (p.direct) { /* rs_schedule_tti: one row of per-user outputs, cleared here instead of by a memset */
+      if (p.log_tbs) p.log_tbs[u] = 0;
+      if (p.log_uinfo) p.log_uinfo[u] = 0;
+    }
   }
   for (int i = tid; i < (R + 1) * 27; i += nt) s_tbs[i] = p.tbs_eff[i];
   for (int i = tid; i < (R * Upad) >> 2; i += nt) ((uint32_t*)s_cqi)[i] = 0;
