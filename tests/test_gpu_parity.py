@@ -90,6 +90,32 @@ def test_many_slices_and_big_slices(rs, oracle):
     _check_batch(rs, oracle, 7, [70, 45, 5], 25, 4, n_cells=2, n_ttis=50)
 
 
+def test_long_run_few_slices_over_110_prbs(rs, oracle):
+    """3 slices share 64 RBGs: UEs regularly hold > 110 PRBs, incl. multiples of 5 (the reference's
+    out-of-bounds TBS row, pinned to the as-shipped build), over 1 500 TTIs; final state bitwise."""
+    ues, R, G, n_cells, n_ttis = [4, 4, 4], 64, 8, 6, 1500
+    for sched in (9, 7):
+        sc = rs.SliceConfig(ues)
+        b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched)
+        seeds = np.arange(n_cells, dtype=np.uint32) + 5
+        b.seed(seeds)
+        b.synthesize_cqi(77, (n_ttis + 39) // 40)
+        b.run(n_ttis)
+        st = b.state()
+        big = 0
+        for c in range(n_cells):
+            cell = oracle.Cell(ues, R, G, sched)
+            logs = cell.run_synth(b.download_cqi_epochs(c), int(seeds[c]), n_ttis)
+            ost = cell.state()
+            np.testing.assert_array_equal(st["cum_bytes"][c], ost["cum_bytes"])
+            np.testing.assert_array_equal(st["cum_rbs"][c], ost["cum_rbs"])
+            assert st["avg_rate"][c].tobytes() == ost["avg_rate"].tobytes()
+            nprb = np.stack([np.bincount(m[m >= 0], minlength=12) for m in logs["rbg_to_user"]]) * G
+            big += int(((nprb > 110) & (nprb % 5 == 0)).sum())
+        assert big > 0, "the >110-PRB multiple-of-5 case was not exercised"
+        b.close()
+
+
 def test_single_user_single_slice(rs, oracle):
     _check_batch(rs, oracle, 9, [1], 12, 2, n_cells=1, n_ttis=45)
 
