@@ -99,10 +99,15 @@ typedef struct rs_tti_in {
   int32_t n_users;          /* users to schedule this TTI (<= cfg.n_users)                          */
   const int32_t* user_id;   /* [n] ascending user ids; NULL = 0..n-1                                */
   const uint8_t* cqi;       /* [n][R] CQI (1..15) of PRB rbg*rbg_size = GetCqiFeedbacks().at(rbg*rbg_size);
-                               the whole RBG carries that CQI (true for every shipped trace)        */
+                               the whole RBG carries that CQI (true for every shipped trace);
+                               see cqi_prb for the general case                                     */
   const double* avg_rate;   /* [n] sum over the user's bearers of GetAverageTransmissionRate()      */
   int32_t rand0, rand1;     /* the two rand() values RBsAllocation draws (ref: :490, :511);
                                ignored by RS_SCHED_PF / RS_SCHED_NVS                                */
+  const uint8_t* cqi_prb;   /* optional [n][R*rbg_size]: the full per-PRB GetCqiFeedbacks() vectors.  When
+                               non-NULL `cqi` is ignored (the metric reads PRB rbg*rbg_size, ref: :536) and link
+                               adaptation reads every allocated PRB (ref: :643-646), so CQIs may differ inside
+                               an RBG as the simulated channel's reports do                           */
 } rs_tti_in;
 
 /* What RBsAllocation() leaves behind (ref: :589-620 allocation lists + slice_rbs_offset_,

@@ -87,6 +87,12 @@ class GpuDownlinkScheduler {
   void SetCQI(int user_id, const uint8_t* cqi_per_rbg) {
     for (int r = 0; r < nb_rbgs_; ++r) cqi_[(size_t)user_id * nb_rbgs_ + r] = cqi_per_rbg[r];
   }
+  /* the full per-PRB vector, as UserEquipmentRecord::GetCQI() holds it (CQIs may differ inside an RBG) */
+  void SetCQIPerPrb(int user_id, const int* cqi_per_prb) {
+    if (cqi_prb_.empty()) cqi_prb_.assign(user_to_slice_.size() * (size_t)nb_rbs_, 10);
+    for (int k = 0; k < nb_rbs_; ++k) cqi_prb_[(size_t)user_id * nb_rbs_ + k] = (uint8_t)cqi_per_prb[k];
+    for (int r = 0; r < nb_rbgs_; ++r) cqi_[(size_t)user_id * nb_rbgs_ + r] = (uint8_t)cqi_per_prb[r * rbg_size_];
+  }
   BearerState& Bearer(int user_id) { return bearers_[user_id]; }
   unsigned long GetTimeStamp() const { return ts_; }
   const std::vector<Allocation>& LastAllocations() const { return allocations_; }
@@ -161,11 +167,17 @@ class GpuDownlinkScheduler {
       for (int r = 0; r < nb_rbgs_; ++r) in_cqi_[(size_t)i * nb_rbgs_ + r] = cqi_[(size_t)u * nb_rbgs_ + r];
       in_avg_[i] = bearers_[u].average_transmission_rate;
     }
+    if (!cqi_prb_.empty()) {
+      in_prb_.resize((size_t)n * nb_rbs_);
+      for (int i = 0; i < n; ++i)
+        for (int k = 0; k < nb_rbs_; ++k) in_prb_[(size_t)i * nb_rbs_ + k] = cqi_prb_[(size_t)users_[i] * nb_rbs_ + k];
+    }
     rs_tti_in in{};
     in.n_users = n;
     in.user_id = users_.data();
     in.cqi = in_cqi_.data();
     in.avg_rate = in_avg_.data();
+    in.cqi_prb = cqi_prb_.empty() ? nullptr : in_prb_.data();
     if (sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL) {
       in.rand0 = rand();
       in.rand1 = rand();
@@ -206,7 +218,7 @@ class GpuDownlinkScheduler {
   std::vector<int> alpha_, beta_, eps_, psi_, user_to_slice_;
   std::vector<double> slice_ewma_time_;
   std::vector<BearerState> bearers_;
-  std::vector<uint8_t> cqi_, in_cqi_;
+  std::vector<uint8_t> cqi_, in_cqi_, cqi_prb_, in_prb_;
   std::vector<double> in_avg_;
   std::vector<int> users_, target_, quota_, rbg_to_user_, nprb_, fcqi_, mcs_, tbs_;
   std::vector<Allocation> allocations_;

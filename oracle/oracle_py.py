@@ -74,6 +74,7 @@ def lib():
         L.rso_cell_create.argtypes = [C.POINTER(_Config)]
         L.rso_cell_destroy.argtypes = [C.c_void_p]
         L.rso_cell_set_cqi.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        L.rso_cell_set_cqi_prb.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         L.rso_cell_set_last_update.argtypes = [C.c_void_p, C.c_double]
         L.rso_cell_set_avg_rate.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.rso_cell_step.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(_TtiOut)]
@@ -200,6 +201,11 @@ class Cell:
         a = np.ascontiguousarray(cqi, np.uint8)
         assert a.shape == (self.U, self.R)
         lib().rso_cell_set_cqi(self.h, _p(a, C.c_uint8))
+
+    def set_cqi_prb(self, prb):
+        a = np.ascontiguousarray(prb, np.uint8)
+        assert a.shape == (self.U, self.R * self.rbg_size)
+        lib().rso_cell_set_cqi_prb(self.h, _p(a, C.c_uint8))
 
     def set_avg_rate(self, avg):
         a = np.ascontiguousarray(avg, np.float64)

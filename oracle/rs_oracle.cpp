@@ -233,7 +233,8 @@ struct rso_cell {
   /* scheduler state */
   std::vector<double> offset; /* slice_rbs_offset_ (ref: downlink-transport-scheduler.h:38) */
   std::vector<double> ewma;   /* slice_ewma_time_  (ref: downlink-nvs-scheduler.h:41)       */
-  std::vector<uint8_t> cqi;   /* [U][R] */
+  std::vector<uint8_t> cqi;   /* [U][R]  CQI of PRB r*rbg_size (what the metric reads) */
+  std::vector<uint8_t> cqi_prb; /* [U][R*G] per-PRB CQI when given (EESM/TBS read every PRB), else empty */
   double eff_of_cqi[16];
 };
 
@@ -266,6 +267,15 @@ void rso_cell_destroy(rso_cell* c) { delete c; }
 
 void rso_cell_set_cqi(rso_cell* c, const uint8_t* cqi) {
   memcpy(c->cqi.data(), cqi, (size_t)c->U * c->R);
+  c->cqi_prb.clear();
+}
+/* per-PRB CQI vectors as ENodeB::UserEquipmentRecord::GetCQI() holds them: the metric reads PRB
+ * rbg*rbg_size (downlink-transport-scheduler.cpp:536), link adaptation every allocated PRB (:643-646) */
+void rso_cell_set_cqi_prb(rso_cell* c, const uint8_t* prb) {
+  const int n = c->R * c->rbg_size;
+  c->cqi_prb.assign(prb, prb + (size_t)c->U * n);
+  for (int u = 0; u < c->U; u++)
+    for (int r = 0; r < c->R; r++) c->cqi[(size_t)u * c->R + r] = prb[(size_t)u * n + r * c->rbg_size];
 }
 void rso_cell_set_user_cqi(rso_cell* c, int user, const uint8_t* row) {
   memcpy(&c->cqi[(size_t)user * c->R], row, c->R);
@@ -285,6 +295,11 @@ void rso_cell_get_state(const rso_cell* c, double* avg, int64_t* cum_bytes, int6
 }  // extern "C"
 
 namespace {
+
+inline uint8_t prb_cqi(const rso_cell* c, int u, int r, int k) {
+  if (c->cqi_prb.empty()) return c->cqi[(size_t)u * c->R + r];
+  return c->cqi_prb[(size_t)u * c->R * c->rbg_size + r * c->rbg_size + k];
+}
 
 /* ref: flows/radio-bearer.cpp:139-164 */
 void update_average_rate(rso_cell* c, double now) {
@@ -322,7 +337,7 @@ void link_adaptation(const rso_cell* c, const int* rbg_to_user, rso_tti_out* out
     prb.clear();
     for (int r = 0; r < R; r++)
       if (rbg_to_user[r] == u)
-        for (int k = 0; k < G; k++) prb.push_back(c->cqi[(size_t)u * R + r]);
+        for (int k = 0; k < G; k++) prb.push_back(prb_cqi(c, u, r, k));
     if (prb.empty()) continue;
     int fc = rso_final_cqi(prb.data(), (int)prb.size());
     int mcs = kCqiToMcs[fc - 1];
@@ -436,7 +451,7 @@ int allocate_pf(rso_cell* c, const double* avg, rso_tti_out* out) {
     }
     if (pick < 0) continue;
     out->rbg_to_user[r] = pick;
-    for (int k = 0; k < G; k++) prbs[pick].push_back(c->cqi[(size_t)pick * R + r]);
+    for (int k = 0; k < G; k++) prbs[pick].push_back(prb_cqi(c, pick, r, k));
     /* :253-265 incremental TBS test against dataToTransmit*8 = 800 000 000 bits */
     int fc = rso_final_cqi(prbs[pick].data(), (int)prbs[pick].size());
     int tbs = rso_tbs_bits(kCqiToMcs[fc - 1], (int)prbs[pick].size());
@@ -482,7 +497,7 @@ int allocate_nvs(rso_cell* c, const double* avg, int slice, rso_tti_out* out) {
   for (int u = 0; u < U; u++) {
     if (c->u2s[u] != slice) continue;
     for (int r = 0; r < R; r++)
-      for (int k = 0; k < G; k++) all[r * G + k] = c->cqi[(size_t)u * R + r];
+      for (int k = 0; k < G; k++) all[r * G + k] = prb_cqi(c, u, r, k);
     int wide = rso_final_cqi(all.data(), R * G);
     required[u] = (100000000 * 8) / kTbs[0][kMcsToItbs[kCqiToMcs[wide - 1]]];
   }

@@ -104,6 +104,8 @@ void rso_cell_destroy(rso_cell* c);
 /* current per-RBG CQI grid [U][R] (values 1..15); the oracle expands it to per-PRB internally */
 void rso_cell_set_cqi(rso_cell* c, const uint8_t* cqi);
 void rso_cell_set_user_cqi(rso_cell* c, int user, const uint8_t* cqi_row);
+/* per-PRB CQI [U][R*rbg_size] (may vary inside an RBG, as the simulated channel's reports do) */
+void rso_cell_set_cqi_prb(rso_cell* c, const uint8_t* cqi_prb);
 /* bearer creation instant (RadioBearer ctor -> ResetTransmittedBytes: lastUpdate = Now) */
 void rso_cell_set_last_update(rso_cell* c, double t);
 /* one TTI of DoSchedule(): EWMA update at time `now`, RBsAllocation with the two rand() values,

@@ -657,14 +657,15 @@ struct rs_ctx {
 
 namespace {
 struct CtxLayout {
-  size_t grid, slice, avg, in_total, tbs, uinfo, map, quota, target, out_total;
+  size_t grid, slice, avg, prb, in_total, tbs, uinfo, map, quota, target, out_total;
 };
-CtxLayout ctx_layout(int n, int R, int S) {
+CtxLayout ctx_layout(int n, int R, int S, int G) {
   CtxLayout l;
   l.grid = 0;
   l.slice = round_up(n * R, 16);
   l.avg = l.slice + round_up(n, 16);
-  l.in_total = l.avg + 8 * (size_t)n;
+  l.prb = l.avg + 8 * (size_t)n;
+  l.in_total = l.prb + round_up(n * R * G, 16);
   l.tbs = 0;
   l.uinfo = 4 * (size_t)n;
   l.map = 8 * (size_t)n;
@@ -689,7 +690,7 @@ rs_ctx* rs_create(const rs_config* cfg) {
   rs_ctx* c = new (std::nothrow) rs_ctx();
   if (!c) { rs_batch_destroy(b); fail(RS_ERR_INVALID, "out of memory"); return nullptr; }
   c->b = b;
-  const CtxLayout l = ctx_layout(b->U, b->R, b->S);
+  const CtxLayout l = ctx_layout(b->U, b->R, b->S, b->G);
   c->in_bytes = l.in_total;
   c->out_bytes = l.out_total;
   bool ok = hipMalloc(&c->d_in, c->in_bytes) == hipSuccess && hipMalloc(&c->d_out, c->out_bytes) == hipSuccess &&
@@ -716,9 +717,9 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   const int n = in->n_users, R = b->R, S = b->S;
   if (n < 1 || n > b->U) return fail(RS_ERR_INVALID, "n_users %d outside 1..%d", n, b->U);
-  if (!in->cqi || !in->avg_rate) return fail(RS_ERR_INVALID, "null cqi/avg_rate");
+  if ((!in->cqi && !in->cqi_prb) || !in->avg_rate) return fail(RS_ERR_INVALID, "null cqi/avg_rate");
   if (!out->rbg_to_user || !out->user_tbs_bits) return fail(RS_ERR_INVALID, "null output array");
-  const CtxLayout l = ctx_layout(n, R, S);
+  const CtxLayout l = ctx_layout(n, R, S, b->G);
   uint8_t* h_slice = c->h_in + l.slice;
   for (int i = 0; i < n; i++) {
     int id = in->user_id ? in->user_id[i] : i;
@@ -728,13 +729,25 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
     if (b->sched == RS_SCHED_NVS && h_slice[i] != h_slice[0])
       return fail(RS_ERR_INVALID, "RS_SCHED_NVS: pass only the users of the served slice");
   }
-  for (int i = 0; i < n * R; i++)
-    if (in->cqi[i] < 1 || in->cqi[i] > 15) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", in->cqi[i]);
-  memcpy(c->h_in + l.grid, in->cqi, (size_t)n * R);
+  const int G = b->G;
+  size_t in_bytes = l.prb; /* the per-PRB block travels only when given */
+  if (in->cqi_prb) {
+    const size_t np = (size_t)n * R * G;
+    for (size_t i = 0; i < np; i++)
+      if (in->cqi_prb[i] < 1 || in->cqi_prb[i] > 15) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", in->cqi_prb[i]);
+    memcpy(c->h_in + l.prb, in->cqi_prb, np);
+    for (int i = 0; i < n; i++)
+      for (int r = 0; r < R; r++) c->h_in[l.grid + (size_t)i * R + r] = in->cqi_prb[((size_t)i * R + r) * G];
+    in_bytes = l.prb + np;
+  } else {
+    for (int i = 0; i < n * R; i++)
+      if (in->cqi[i] < 1 || in->cqi[i] > 15) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", in->cqi[i]);
+    memcpy(c->h_in + l.grid, in->cqi, (size_t)n * R);
+  }
   memset(c->h_in + l.grid + (size_t)n * R, 0, l.slice - (size_t)n * R);
   memcpy(c->h_in + l.avg, in->avg_rate, 8 * (size_t)n);
   hipStream_t st = b->stream;
-  HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, l.in_total, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, st));
   RsLaunch L = b->base;
   L.U = n;
   L.Upad = upad_of(n);
@@ -749,6 +762,7 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   L.n_epochs = 1;
   L.user_slice = c->d_in + l.slice;
   L.avg = (double*)(c->d_in + l.avg);
+  L.prb_cqi = in->cqi_prb ? c->d_in + l.prb : nullptr;
   if (b->sched == RS_SCHED_PF) { L.n_seg = (n + RS_PF_SEG - 1) / RS_PF_SEG; L.n_items = R * L.n_seg; }
   L.log_tbs = (int32_t*)(c->d_out + l.tbs);
   L.log_uinfo = (int32_t*)(c->d_out + l.uinfo);

@@ -72,6 +72,7 @@ struct RsLaunch {
   const int32_t* eps;        /* [S] */
   const int32_t* psi;        /* [S] */
   const uint8_t* user_slice; /* [U] */
+  const uint8_t* prb_cqi;    /* direct mode, optional: [U][R*G] per-PRB CQI for the EESM sum */
   const int32_t* tbs_eff;    /* [R+1][27] TBS bits of n RBGs (n*G PRBs) at itbs, incl. the >110-PRB rule */
   /* state */
   double* avg;               /* [cells][U] */

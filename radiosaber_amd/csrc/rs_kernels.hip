@@ -949,8 +949,14 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
         while (mm) {
           const int r2 = __ffsll((long long)mm) - 1;
           mm &= mm - 1;
-          const double ev = s_e[col[r2 * Upad]];
-          for (int k = 0; k < G; ++k) sum += ev;
+          if (p.prb_cqi) {
+            /* per-PRB reports (drop-in mode with the simulated channel): read the RBG's PRBs from HBM */
+            const uint8_t* pr = p.prb_cqi + ((size_t)owner * R + r2) * G;
+            for (int k = 0; k < G; ++k) sum += s_e[pr[k]];
+          } else {
+            const double ev = s_e[col[r2 * Upad]];
+            for (int k = 0; k < G; ++k) sum += ev;
+          }
           nprb += G;
         }
         if (leader) {

@@ -258,3 +258,33 @@ def test_drop_in_single_tti(rs, oracle, sched):
         np.testing.assert_array_equal(res.user_mcs, out.user_mcs)
         np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits)
     ts.close()
+
+
+@pytest.mark.parametrize("sched", [9, 8, 1])
+def test_drop_in_per_prb_cqi(rs, oracle, sched):
+    """Per-PRB CQI reports that differ inside an RBG (the simulated-channel case): the metric reads PRB
+    rbg*rbg_size, link adaptation every allocated PRB -- against the oracle's per-PRB path."""
+    ues, R, G = [5] * 20, 64, 8
+    sc = rs.SliceConfig(ues, weight=[0.05] * 20)
+    U = sc.n_users
+    ts = rs.TtiScheduler(sc, R, G, sched=sched)
+    cell = oracle.Cell(ues, R, G, sched, weights=[0.05] * 20)
+    rng = np.random.default_rng(17)
+    for it in range(8):
+        base = synth_cqi(300 + it, (U, R), HIST).astype(np.int16)
+        prb = np.clip(np.repeat(base, G, axis=1) + rng.integers(-2, 3, (U, R * G)), 1, 15).astype(np.uint8)
+        avg = rng.uniform(1e3, 5e6, U)
+        r0, r1 = int(rng.integers(0, 2**31 - 1)), int(rng.integers(0, 2**31 - 1))
+        cell.set_cqi_prb(prb)
+        out = cell.new_out()
+        assert cell.allocate(avg, r0, r1, out) == 0
+        res = ts.schedule_tti(None, avg, r0, r1, cqi_prb=prb)
+        np.testing.assert_array_equal(res.rbg_to_user, out.rbg_to_user)
+        np.testing.assert_array_equal(res.user_nprb, out.user_nprb)
+        np.testing.assert_array_equal(res.user_final_cqi, out.user_final_cqi)
+        np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits)
+        # and the per-RBG entry point on the same metric grid differs only in link adaptation
+        res2 = ts.schedule_tti(prb[:, ::G], avg, r0, r1)
+        if sched != 1:
+            ts.slice_offset = cell.state()["slice_state"]  # res2 advanced slice_rbs_offset_ a second time
+    ts.close()
