@@ -465,6 +465,10 @@ __device__ void counting_sort_desc(const uint32_t* v, uint32_t* out, int N, Misc
   __syncthreads();
 }
 
+#ifndef RS_P3_BLOCK
+#define RS_P3_BLOCK 32 /* users ranked per stage-1 block (multiple of 8, <= 32) */
+#endif
+
 #ifdef RS_STAMPS
 /* diagnostic build only: cycles per phase of thread 0, accumulated over the launch (never in the
  * product library; the values go to a buffer nothing else reads) */
@@ -768,15 +772,15 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
         const bool one_num = SCHED != 1 && !sl_eps;
 #ifdef RS_EXP_P3_SKIP
         bu = ub; bkey = rowp[ub]; best = 1.0; /* timing experiment only: wrong results */
-        for (int blk = ue; blk < ue; blk += 32) {
+        for (int blk = ue; blk < ue; blk += RS_P3_BLOCK) {
 #else
-        for (int blk = ub & ~7; blk < ue; blk += 32) {
+        for (int blk = ub & ~7; blk < ue; blk += RS_P3_BLOCK) {
 #endif
           /* a~ of the 32 users blk..blk+31 (0 for users outside [ub, ue) and for the padding) */
-          float av[32];
+          float av[RS_P3_BLOCK];
           float best_a = 0.0f;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
+          for (int g = 0; g < RS_P3_BLOCK / 8; ++g) {
             const int u0 = blk + 8 * g;
             uint2 cw = make_uint2(0u, 0u);
             float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
@@ -799,7 +803,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
           const float thr = best_a * kTol;
           uint32_t cand = 0;
 #pragma unroll
-          for (int k = 0; k < 32; ++k) cand |= (av[k] >= thr && av[k] > 0.0f) ? (1u << k) : 0u;
+          for (int k = 0; k < RS_P3_BLOCK; ++k) cand |= (av[k] >= thr && av[k] > 0.0f) ? (1u << k) : 0u;
           while (cand) {
             const int j = __ffs((int)cand) - 1;
             cand &= cand - 1;
@@ -889,6 +893,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
         int my_slice = -1;                        /* lane r: slice that got RBG r */
         unsigned long long taken = 0;
         int assigned = 0;
+        int scan_end = 0;
         for (int c0 = 0; c0 < N && assigned < R; c0 += 64) {
           const int i = c0 + lane;
           const uint32_t e = i < N ? s_sorted[i] : 0;
@@ -906,8 +911,15 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
             if (lane == fsl) left--;
             taken |= 1ull << frbg;
             assigned++;
+            scan_end = c0 + f;
           }
         }
+#ifdef RS_STAMPS
+        if (tid == 0) { /* how deep the greedy scan went: last sorted position it looked at */
+          stamp_acc[9] += (unsigned long long)assigned;
+          stamp_acc[10] += (unsigned long long)scan_end;
+        }
+#endif
         if (lane < S) got = m->quota[lane] - left;
         if (lane < R && my_slice >= 0) {
           int u = s_best_user[my_slice * R + lane];
