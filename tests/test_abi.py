@@ -91,3 +91,18 @@ def test_slice_config_from_reference_json(rs):
     sc = rs.SliceConfig.from_json(cfg)
     assert sc.n_slices == 20 and sc.n_users == 100 and sc.weight == [0.05] * 20
     assert sc.user_to_slice.tolist() == [i // 5 for i in range(100)]
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under radiosaber_amd/ or include/ may import, include,
+    link or execute it (the oracle includes the product's table data, not the other way round)."""
+    bad = []
+    for f in list((ROOT / "radiosaber_amd").rglob("*")) + list((ROOT / "include").rglob("*")):
+        if f.is_file() and f.suffix in (".py", ".h", ".hpp", ".hip", ".cpp", ".inc"):
+            for n, line in enumerate(f.read_text(errors="ignore").splitlines(), 1):
+                code = line.split("//")[0]
+                if re.search(r"(import|from|include|CDLL|dlopen).*\boracle", code):
+                    bad.append(f"{f.relative_to(ROOT)}:{n}: {line.strip()}")
+    assert not bad, bad
+    so = (ROOT / "radiosaber_amd" / "libradiosaber_hip.so").read_bytes()
+    assert b"librs_oracle" not in so and b"rso_" not in so

@@ -288,3 +288,31 @@ def test_drop_in_per_prb_cqi(rs, oracle, sched):
         if sched != 1:
             ts.slice_offset = cell.state()["slice_state"]  # res2 advanced slice_rbs_offset_ a second time
     ts.close()
+
+
+def test_device_side_range_errors_are_reported(rs, traces):
+    sc = rs.SliceConfig([2, 2])
+    b = rs.BatchScheduler(sc, 12, 2, 1, sched=9)
+    b.seed(np.array([1], np.uint32))
+    with pytest.raises(rs.RadioSaberError) as e:
+        b.run(10)
+    assert "no CQI source" in str(e.value)
+    b.upload_cqi_epochs(np.full((1, 1, 4, 12), 7, np.uint8))
+    b.run(40)  # exactly the uploaded epoch
+    with pytest.raises(rs.RadioSaberError) as e:
+        b.run(1)  # TTI 40 needs epoch 1
+    assert e.value.code == -5 and "epoch" in str(e.value)
+    b.close()
+    # trace replay past the uploaded rows
+    sc = rs.SliceConfig([2, 2])
+    b = rs.BatchScheduler(sc, 64, 8, 1, sched=9)
+    b.seed(np.array([1], np.uint32))
+    b.set_trace(traces["cqi"][:4, :3], np.zeros((1, 4), np.int32))  # rows 0..2 only: the first report (row 2) fits
+    b.run(40)
+    with pytest.raises(rs.RadioSaberError) as e:
+        b.run(1)  # TTI 140 reads row 3
+    assert e.value.code == -5
+    b.close()
+    with pytest.raises(rs.RadioSaberError) as e:
+        rs.TtiScheduler(rs.SliceConfig([2, 2]), 12, 2).schedule_tti(np.zeros((4, 12), np.uint8), np.ones(4))
+    assert "outside 1..15" in str(e.value)
