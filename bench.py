@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--sched", type=int, default=9)
     ap.add_argument("--threads", type=int, default=0, help="workgroup size per cell (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-jit", action="store_true", help="use the kernels built into the library instead of the "
+                    "shape-specialised one compiled at create time")
     args = ap.parse_args()
 
     import torch
@@ -137,7 +139,7 @@ def main():
     slices = rs.SliceConfig([args.ues_per_slice] * S, weight=[1.0 / S] * S)
     n_epochs = ((args.steps + args.warmup) * args.ttis + 39) // 40
     batch = rs.BatchScheduler(slices, R, args.rbg_size, args.cells, sched=args.sched, device=local_rank,
-                              threads_per_cell=args.threads)
+                              threads_per_cell=args.threads, jit=not args.no_jit)
     # cell ids are global: rank r owns cells [r*cells, (r+1)*cells)
     seeds = sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, args.cells))
     batch.seed(seeds)

@@ -18,6 +18,7 @@
 #ifndef RADIOSABER_HIP_H_
 #define RADIOSABER_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -151,6 +152,10 @@ typedef struct rs_batch_config {
                                 reference's PHY error model does on the shared libc stream
                                 (ref: src/phy/wideband-cqi-eesm-error-model.cpp:69)              */
   int32_t threads_per_cell;  /* workgroup size, multiple of 64 in [64,512]; 0 = default        */
+  int32_t jit;               /* 1: compile the cell kernel for this batch's exact shape at create time
+                                (hiprtc, ~2 s, cached per process); results are identical, the built-in
+                                kernels are used if the compilation fails.  0: built-in kernels.
+                                The environment variable RS_JIT=0|1 overrides.                    */
 } rs_batch_config;
 
 rs_batch* rs_batch_create(const rs_batch_config* cfg);
@@ -199,6 +204,10 @@ int rs_batch_read_state(rs_batch* b, double* avg_rate, int64_t* cum_bytes, int64
  * all-reduces over RCCL (the reference's plot_throughput.py:26-56 sums it per slice post hoc) */
 int rs_batch_slice_bytes_device(rs_batch* b, uint64_t* d_out);
 int rs_batch_slice_bytes(rs_batch* b, uint64_t* h_out /* [S] */);
+/* build check (needs no GPU): compile the shape-specialised kernel for one shape with hiprtc; returns the
+ * code object size or a negative value with the compiler log in err */
+int rs_jit_selfcheck(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, char* err,
+                     size_t errlen);
 /* diagnostics: cycles per kernel phase of one cell's first thread, summed over the last launch;
  * only in the separate -DRS_STAMPS build (RS_ERR_STATE in the product library) */
 int rs_batch_debug_stamps(rs_batch* b, int32_t cell, uint64_t* out20);

@@ -46,7 +46,7 @@ class _Config(C.Structure):
 class _BatchConfig(C.Structure):
     _fields_ = [("cell", _Config), ("n_cells", C.c_int32), ("first_tti", C.c_int32),
                 ("cqi_refresh", C.c_int32), ("phy_error_draws", C.c_int32),
-                ("threads_per_cell", C.c_int32)]
+                ("threads_per_cell", C.c_int32), ("jit", C.c_int32)]
 
 
 class _TtiIn(C.Structure):
@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "rs_batch_synthesize_cqi", "rs_batch_download_cqi_epochs", "rs_batch_set_trace",
     "rs_batch_run", "rs_batch_run_async", "rs_batch_sync", "rs_batch_run_logged",
     "rs_batch_run_timed", "rs_batch_read_state", "rs_batch_slice_bytes_device",
-    "rs_batch_slice_bytes", "rs_batch_debug_stamps", "rs_batch_ttis_done", "rs_batch_stream", "rs_batch_kernel_name",
+    "rs_batch_slice_bytes", "rs_jit_selfcheck", "rs_batch_debug_stamps", "rs_batch_ttis_done", "rs_batch_stream", "rs_batch_kernel_name",
 ]
 
 _lib = None
@@ -112,6 +112,7 @@ def lib():
                                       C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.rs_batch_slice_bytes_device.argtypes = [C.c_void_p, C.c_void_p]
     L.rs_batch_slice_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.rs_jit_selfcheck.argtypes = [C.c_int] * 6 + [C.c_char_p, C.c_size_t]
     L.rs_batch_debug_stamps.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]
     L.rs_batch_ttis_done.restype = C.c_int64
     L.rs_batch_ttis_done.argtypes = [C.c_void_p]
@@ -130,6 +131,15 @@ def _check(rc):
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+def jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCHED_MAXCELL):
+    """Compile the shape-specialised kernel for one shape (hiprtc, no GPU needed); returns the code size."""
+    buf = C.create_string_buffer(4096)
+    n = lib().rs_jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads, sched, buf, 4096)
+    if n < 0:
+        raise RadioSaberError(n, buf.value.decode(errors="replace"))
+    return n
 
 
 def device_count():
@@ -283,11 +293,13 @@ class BatchScheduler:
 
     def __init__(self, slices: SliceConfig, n_rbgs: int, rbg_size: int, n_cells: int,
                  sched: int = RS_SCHED_MAXCELL, device: int = 0, first_tti: int = 100, cqi_refresh: int = 40,
-                 phy_error_draws: bool = False, threads_per_cell: int = 0, stream: Optional[int] = None):
+                 phy_error_draws: bool = False, threads_per_cell: int = 0, stream: Optional[int] = None,
+                 jit: bool = False):
         self.slices, self.R, self.rbg_size, self.sched, self.n_cells = slices, n_rbgs, rbg_size, sched, n_cells
         self.S, self.U = slices.n_slices, slices.n_users
         self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream)
-        bc = _BatchConfig(self._cfg.c, n_cells, first_tti, cqi_refresh, int(phy_error_draws), threads_per_cell)
+        bc = _BatchConfig(self._cfg.c, n_cells, first_tti, cqi_refresh, int(phy_error_draws), threads_per_cell,
+                          int(jit))
         self._h = lib().rs_batch_create(C.byref(bc))
         if not self._h:
             raise RadioSaberError(-1, lib().rs_last_error().decode())

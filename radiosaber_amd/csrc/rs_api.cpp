@@ -25,6 +25,9 @@
 
 extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_t stream);
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes);
+struct RsJitKernel;
+extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, char* err, size_t errlen);
+extern "C" hipError_t rs_jit_launch(RsJitKernel* k, const RsLaunch* p, hipStream_t stream);
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,
                                       uint64_t seed, const uint32_t* cdf16, hipStream_t stream);
 extern "C" hipError_t rs_launch_slice_bytes(const int64_t* cum_bytes, const uint8_t* user_slice, int n_cells, int U,
@@ -183,6 +186,7 @@ struct rs_batch {
   int32_t* d_err = nullptr;
   unsigned long long* d_slice_bytes = nullptr;
   unsigned long long* d_stamps = nullptr;
+  RsJitKernel* jit = nullptr; /* shape-specialised kernel (owned by the process-wide cache) */
   int64_t ttis_done = 0;
   RsLaunch base{};
 };
@@ -213,39 +217,17 @@ int validate(const rs_config* c) {
   return RS_OK;
 }
 
-int upad_of(int U) {
-  int k = (U + 7) / 8;
-  if ((k & 1) == 0) k += 1; /* 8 * odd: 8-byte column reads of 32 consecutive RBGs hit 32 distinct bank pairs */
-  return 8 * k;
-}
+int upad_of(int U) { return rs_upad_of(U); }
 
 void carve_lds(rs_batch* b, RsLaunch* L) {
-  const int U = b->U, R = b->R, S = b->S;
-  const int Upad = upad_of(U);
-  L->Upad = Upad;
-  int n_seg = b->sched == RS_SCHED_PF ? (U + RS_PF_SEG - 1) / RS_PF_SEG : (b->sched == RS_SCHED_NVS ? 1 : S);
-  int n_items = R * n_seg;
-  int off = 0;
-  off += 8 * U;               /* avg */
-  L->off_avgk = off; off += 8 * U;
-  L->off_rcp = off; off += round_up(4 * Upad, 16);
-  L->off_tab = off; off += 8 * 48 + 64;
-  L->off_slice = off; off += 8 * 128;
-  L->off_tx = off; off += round_up(4 * U, 16);
-  L->off_misc = off; off += round_up((int)sizeof(RsMisc), 16);
-  L->off_tbs = off; off += round_up(4 * 27 * (R + 1), 16);
-  L->off_elems = off; off += round_up(b->sched == RS_SCHED_PF ? 8 * n_items : 4 * R * S, 16);
-  L->off_sorted = off; off += round_up(4 * R * S, 16);
-  L->off_items = off; off += round_up(2 * n_items, 16);
-  {
-    /* level-synchronous introsort scratch: cut per sub-range (+ bounds/pivots when the state lives in LDS) */
-    const int ept = (R * S + b->threads - 1) / b->threads;
-    L->off_sortx = off; off += b->sched == RS_SCHED_MAXCELL ? round_up((ept <= 4 ? 2 : 8) * R * S, 16) : 0;
-  }
-  L->off_cqi = off; off += round_up(Upad * R, 16);
-  L->lds_bytes = off;
-  L->n_seg = n_seg;
-  L->n_items = n_items;
+  const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads);
+  L->Upad = c.Upad;
+  L->off_avgk = c.off_avgk; L->off_rcp = c.off_rcp; L->off_tab = c.off_tab; L->off_slice = c.off_slice;
+  L->off_tx = c.off_tx; L->off_misc = c.off_misc; L->off_tbs = c.off_tbs; L->off_elems = c.off_elems;
+  L->off_sorted = c.off_sorted; L->off_items = c.off_items; L->off_sortx = c.off_sortx; L->off_cqi = c.off_cqi;
+  L->lds_bytes = c.lds_bytes;
+  L->n_seg = c.n_seg;
+  L->n_items = c.n_items;
 }
 
 int init_scalars(rs_batch* b, const uint32_t* seed, const int64_t* skip) {
@@ -384,6 +366,12 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   b->cfg.cell.slice_weight = nullptr; b->cfg.cell.algo_alpha = nullptr; b->cfg.cell.algo_beta = nullptr;
   b->cfg.cell.algo_epsilon = nullptr; b->cfg.cell.algo_psi = nullptr; b->cfg.cell.user_to_slice = nullptr;
   if (batch_alloc(b)) { rs_batch_destroy(b); return nullptr; }
+  int want_jit = cfg->jit;
+  if (const char* e = getenv("RS_JIT")) want_jit = atoi(e);
+  if (want_jit && !direct) {
+    /* failure is not an error: g_err keeps the reason, the built-in kernels stay in use */
+    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, g_err, sizeof g_err);
+  }
   return b;
 }
 
@@ -413,7 +401,8 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
   L.trace = b->d_trace; L.n_traces = b->n_traces; L.n_rows = b->n_rows; L.row_mod = b->row_mod;
   L.user_trace = b->d_user_trace;
   L.log_map = d_map; L.log_quota = d_quota; L.log_target = d_target; L.log_tbs = d_tbs; L.log_uinfo = d_uinfo;
-  HIP_TRY(rs_launch_cells(&L, b->threads, b->stream));
+  if (b->jit) HIP_TRY(rs_jit_launch(b->jit, &L, b->stream));
+  else HIP_TRY(rs_launch_cells(&L, b->threads, b->stream));
   b->ttis_done += n_ttis;
   return RS_OK;
 }
@@ -630,6 +619,7 @@ int64_t rs_batch_ttis_done(rs_batch* b) { return b ? b->ttis_done : -1; }
 void* rs_batch_stream(rs_batch* b) { return b ? (void*)b->stream : nullptr; }
 const char* rs_batch_kernel_name(rs_batch* b) {
   if (!b) return "";
+  if (b->jit) return "rs_cell_kernel_jit";
   switch (b->sched) {
     case 1: return "rs_cell_kernel<1, 0>";
     case 7: return "rs_cell_kernel<7, 0>";

@@ -5,7 +5,20 @@
 #ifndef RS_DEVICE_H_
 #define RS_DEVICE_H_
 
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#elif !defined(RS_RTC_STDINT)
+#define RS_RTC_STDINT /* hiprtc keeps its fixed-width types in a namespace */
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef short int16_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long size_t;
+#endif
 
 #define RS_WAVE 64
 #define RS_PF_SEG 32 /* sched 1: users are scanned in segments of this many for the per-RBG argmax */
@@ -30,6 +43,43 @@ struct RsMisc {
   int32_t nvs_slice;
   int32_t pad[2];
 };
+
+/* LDS carve of one cell (byte offsets from the dynamic LDS base), a pure function of the cell shape so
+ * that the host and a shape-specialised kernel build agree on it */
+struct RsCarve {
+  int Upad, n_seg, n_items, ept;
+  int off_avgk, off_rcp, off_tab, off_slice, off_tx, off_misc, off_tbs, off_elems, off_sorted, off_items,
+      off_sortx, off_cqi, lds_bytes;
+};
+constexpr int rs_round_up(int x, int a) { return (x + a - 1) / a * a; }
+constexpr int rs_upad_of(int U) {
+  /* 8 * odd: 8-byte column reads of 32 consecutive RBGs hit 32 distinct bank pairs */
+  int k = (U + 7) / 8;
+  return 8 * ((k & 1) ? k : k + 1);
+}
+constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads) {
+  RsCarve c{};
+  c.Upad = rs_upad_of(U);
+  c.n_seg = sched == 1 ? (U + RS_PF_SEG - 1) / RS_PF_SEG : (sched == 7 ? 1 : S);
+  c.n_items = R * c.n_seg;
+  c.ept = (R * S + threads - 1) / threads;
+  int off = 8 * U; /* avg */
+  c.off_avgk = off; off += 8 * U;
+  c.off_rcp = off; off += rs_round_up(4 * c.Upad, 16);
+  c.off_tab = off; off += 8 * 48 + 64;
+  c.off_slice = off; off += 8 * 128;
+  c.off_tx = off; off += rs_round_up(4 * U, 16);
+  c.off_misc = off; off += rs_round_up((int)sizeof(RsMisc), 16);
+  c.off_tbs = off; off += rs_round_up(4 * 27 * (R + 1), 16);
+  c.off_elems = off; off += rs_round_up(sched == 1 ? 8 * c.n_items : 4 * R * S, 16);
+  c.off_sorted = off; off += rs_round_up(4 * R * S, 16);
+  c.off_items = off; off += rs_round_up(2 * c.n_items, 16);
+  /* level-synchronous introsort scratch: cut per sub-range (+ bounds/pivots when the state lives in LDS) */
+  c.off_sortx = off; off += sched == 9 ? rs_round_up((c.ept <= 4 ? 2 : 8) * R * S, 16) : 0;
+  c.off_cqi = off; off += rs_round_up(c.Upad * R, 16);
+  c.lds_bytes = off;
+  return c;
+}
 
 /* link-adaptation constants (host libm -> device), see rs_link_tables() in radiosaber_hip.h */
 struct RsTables {

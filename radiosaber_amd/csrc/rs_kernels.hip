@@ -20,8 +20,10 @@
  * `ref:` paths are relative to /root/reference/src/protocolStack/mac/packet-scheduler/ unless they
  * start with src/.
  */
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "rs_device.h"
 #include "rs_sort_emul.h"
@@ -484,34 +486,57 @@ __device__ void counting_sort_desc(const uint32_t* v, uint32_t* out, int N, Misc
 #define RS_STAMP(i) do { } while (0)
 #endif
 
-template <int SCHED, int EPT>
-__global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
-  extern __shared__ __align__(16) unsigned char lds[];
+/*
+ * The whole per-cell TTI loop.  FIXED = false: the cell shape comes from the launch arguments (the
+ * kernels built into the library).  FIXED = true: shape, block size and the LDS carve are the compile-
+ * time constants RS_JIT_* -- the form rs_jit.cpp compiles with hiprtc for one batch's exact shape
+ * (constant divisors, constant LDS offsets, static LDS, fewer live scalars).
+ */
+#ifndef RS_JIT_S
+#define RS_JIT_S 1
+#define RS_JIT_U 1
+#define RS_JIT_R 1
+#define RS_JIT_G 1
+#define RS_JIT_NT 64
+#define RS_JIT_SCHED 8
+#endif
+
+template <int SCHED, int EPT, bool FIXED>
+__device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* lds) {
   const int cell = blockIdx.x;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x;
+  const int nt = FIXED ? RS_JIT_NT : (int)blockDim.x;
   const int lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
-  const int S = p.S, U = p.U, R = p.R, G = p.G;
+  const int S = FIXED ? RS_JIT_S : p.S, U = FIXED ? RS_JIT_U : p.U, R = FIXED ? RS_JIT_R : p.R, G = FIXED ? RS_JIT_G : p.G;
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT);
+  /* byte offsets of the LDS arrays: constants in a shape-specialised build */
+  struct Offs { int avgk, rcp, tab, slice, tx, misc, tbs, elems, sorted, items, sortx, cqi, Upad, n_seg, n_items; };
+  const Offs o = FIXED ? Offs{kCv.off_avgk, kCv.off_rcp, kCv.off_tab, kCv.off_slice, kCv.off_tx, kCv.off_misc, kCv.off_tbs,
+                              kCv.off_elems, kCv.off_sorted, kCv.off_items, kCv.off_sortx, kCv.off_cqi, kCv.Upad,
+                              kCv.n_seg, kCv.n_items}
+                       : Offs{p.off_avgk, p.off_rcp, p.off_tab, p.off_slice, p.off_tx, p.off_misc, p.off_tbs, p.off_elems,
+                              p.off_sorted, p.off_items, p.off_sortx, p.off_cqi, p.Upad, p.n_seg, p.n_items};
   constexpr bool kTransport = (SCHED == 8 || SCHED == 9);
   const int quota_wave = nwaves - 1; /* P2 runs on the last wave, beside the other waves' P3 */
 
   double* s_avg = (double*)lds;
-  double* s_avgk = (double*)(lds + p.off_avgk);
-  float* s_rcp32 = (float*)(lds + p.off_rcp);
-  int32_t* s_tx = (int32_t*)(lds + p.off_tx);
-  double* s_num = (double*)(lds + p.off_tab); /* metric numerator per CQI */
+  double* s_avgk = (double*)(lds + o.avgk);
+  float* s_rcp32 = (float*)(lds + o.rcp);
+  int32_t* s_tx = (int32_t*)(lds + o.tx);
+  double* s_num = (double*)(lds + o.tab); /* metric numerator per CQI */
   double* s_e = s_num + 16;
   double* s_x = s_e + 16;
   float* s_num32 = (float*)(s_x + 16);
-  double* s_w = (double*)(lds + p.off_slice);
+  double* s_w = (double*)(lds + o.slice);
   double* s_sstate = s_w + 64;
-  uint16_t* s_best_user = (uint16_t*)(lds + p.off_items);
-  double* s_best_metric = (double*)(lds + p.off_elems); /* sched 1 only (aliases elems) */
-  uint32_t* s_elems = (uint32_t*)(lds + p.off_elems);
-  uint32_t* s_sorted = (uint32_t*)(lds + p.off_sorted);
-  Misc* m = (Misc*)(lds + p.off_misc);
-  int32_t* s_tbs = (int32_t*)(lds + p.off_tbs); /* [R+1][27] TBS bits of n RBGs at itbs */
-  uint8_t* s_cqi = lds + p.off_cqi; /* [R][Upad], Upad = 8 * odd >= U: conflict-free 8-byte column reads */
-  const int Upad = p.Upad;
+  uint16_t* s_best_user = (uint16_t*)(lds + o.items);
+  double* s_best_metric = (double*)(lds + o.elems); /* sched 1 only (aliases elems) */
+  uint32_t* s_elems = (uint32_t*)(lds + o.elems);
+  uint32_t* s_sorted = (uint32_t*)(lds + o.sorted);
+  Misc* m = (Misc*)(lds + o.misc);
+  int32_t* s_tbs = (int32_t*)(lds + o.tbs); /* [R+1][27] TBS bits of n RBGs at itbs */
+  uint8_t* s_cqi = lds + o.cqi; /* [R][Upad], Upad = 8 * odd >= U: conflict-free 8-byte column reads */
+  const int Upad = o.Upad;
 
   const RsTables* tab = p.tab;
   RsCellScalars* scal = p.scal + cell;
@@ -542,7 +567,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
   }
   /* segments scanned in P3: slices (7/8/9) or fixed runs of RS_PF_SEG users (1) */
   if (SCHED == 1) {
-    if (tid <= p.n_seg) m->seg_begin[tid] = min(tid * RS_PF_SEG, U);
+    if (tid <= o.n_seg) m->seg_begin[tid] = min(tid * RS_PF_SEG, U);
   } else {
     if (tid <= S) m->seg_begin[tid] = U; /* filled below */
   }
@@ -746,7 +771,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
 
     /* ---------------- P3: best user of every (RBG, segment) ---------------- */
     {
-      const int n_items = p.n_items;
+      const int n_items = o.n_items;
       for (int it = tid; it < n_items; it += nt) {
         int sg = it / R, r = it - sg * R; /* r fastest: neighbouring lanes read neighbouring CQI bytes */
         int seg = SCHED == 7 ? seg_lo : sg;
@@ -851,7 +876,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
       __syncthreads();
 #else
       {
-        uint16_t* sx = (uint16_t*)(lds + p.off_sortx);
+        uint16_t* sx = (uint16_t*)(lds + o.sortx);
         uint16_t* pa = (uint16_t*)s_sorted;
         /* EPT = array positions per thread, picked by the host (0: any size, state in LDS) */
         if constexpr (EPT > 0) introsort_levels_reg<EPT>(s_elems, N, pa, pa + N, sx, m, sort_sub);
@@ -930,7 +955,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
          * here over the segment winners in ascending segment order */
         if (lane < R) {
           double best = 0.0;
-          for (int sg = 0; sg < p.n_seg; ++sg) {
+          for (int sg = 0; sg < o.n_seg; ++sg) {
             double v = s_best_metric[sg * R + lane];
             int u = s_best_user[sg * R + lane];
             if (u != 0xFFFF && v > best) { best = v; owner = u; }
@@ -1047,6 +1072,22 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
   }
 }
 
+#ifndef RS_JIT_BUILD
+template <int SCHED, int EPT>
+__global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  rs_cell_body<SCHED, EPT, false>(p, lds);
+}
+#else
+/* shape-specialised entry point compiled at run time (rs_jit.cpp): static LDS of exactly the carve's size */
+extern "C" __global__ void __launch_bounds__(RS_JIT_NT, (RS_JIT_NT == 512 ? 4 : 1)) rs_cell_kernel_jit(RsLaunch p) {
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT);
+  __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
+  constexpr int kEpt = RS_JIT_SCHED != 9 ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);
+  rs_cell_body<RS_JIT_SCHED, kEpt, true>(p, lds);
+}
+#endif
+
 /* ------------------------------------------------------------------------------------------
  * Synthetic CQI grids: i.i.d. draws from a 15-bin histogram, counter-based (SplitMix64 of
  * (seed, cell, epoch, user, rbg)).  One thread per byte, 16 consecutive bytes per lane.
@@ -1104,6 +1145,7 @@ __global__ void rs_slice_bytes_kernel(const int64_t* cum_bytes, const uint8_t* u
   if (threadIdx.x < S && acc[threadIdx.x]) atomicAdd(&d_out[threadIdx.x], acc[threadIdx.x]);
 }
 
+#if !defined(__HIPCC_RTC__) && !defined(RS_JIT_BUILD)
 /* host-callable launchers (defined here so that the kernels stay in one translation unit) */
 extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_t stream) {
   dim3 grid(p->n_cells), block(threads);
@@ -1160,3 +1202,5 @@ extern "C" hipError_t rs_launch_slice_bytes(const int64_t* cum_bytes, const uint
                      d_out);
   return hipGetLastError();
 }
+
+#endif /* host launchers */

@@ -20,7 +20,20 @@
 #ifndef RS_SORT_EMUL_H_
 #define RS_SORT_EMUL_H_
 
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#elif !defined(RS_RTC_STDINT)
+#define RS_RTC_STDINT /* hiprtc keeps its fixed-width types in a namespace */
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef short int16_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long size_t;
+#endif
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define RS_HD __host__ __device__ __forceinline__

@@ -106,3 +106,10 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
     so = (ROOT / "radiosaber_amd" / "libradiosaber_hip.so").read_bytes()
     assert b"librs_oracle" not in so and b"rso_" not in so
+
+
+@pytest.mark.parametrize("shape", [(20, 500, 25, 4, 512, 9), (20, 100, 64, 8, 512, 9), (5, 23, 25, 4, 128, 9),
+                                   (20, 500, 25, 4, 512, 8), (20, 1000, 25, 4, 512, 1), (20, 500, 64, 8, 256, 7)])
+def test_shape_specialised_source_compiles_for_gfx950(rs, shape):
+    """hiprtc build of the embedded kernel source with the cell shape as compile-time constants (no GPU needed)."""
+    assert rs.jit_selfcheck(*shape) > 10000

@@ -26,7 +26,7 @@ def _oracle_cells(oracle, ues, R, G, sched, weights, grids, seeds, n_ttis, eps=N
 
 
 def _check_batch(rs, oracle, sched, ues, R, G, n_cells, n_ttis, threads=0, eps=None, psi=None, phy=0, seed=1,
-                 weights=None):
+                 weights=None, jit=False):
     S = len(ues)
     weights = weights or [1.0 / S] * S
     sc = rs.SliceConfig(ues, weight=weights, algo_epsilon=eps or [], algo_psi=psi or [])
@@ -34,7 +34,9 @@ def _check_batch(rs, oracle, sched, ues, R, G, n_cells, n_ttis, threads=0, eps=N
     n_epochs = (n_ttis + 39) // 40
     grids = synth_cqi(seed, (n_cells, n_epochs, U, R), HIST)
     seeds = np.arange(n_cells, dtype=np.uint32) * 7919 + 805290992
-    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, phy_error_draws=bool(phy), threads_per_cell=threads)
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, phy_error_draws=bool(phy), threads_per_cell=threads, jit=jit)
+    if jit:
+        assert b.kernel_name == "rs_cell_kernel_jit", rs.lib().rs_last_error().decode()
     b.seed(seeds)
     b.upload_cqi_epochs(grids)
     got = b.run_logged(n_ttis)
@@ -316,3 +318,10 @@ def test_device_side_range_errors_are_reported(rs, traces):
     with pytest.raises(rs.RadioSaberError) as e:
         rs.TtiScheduler(rs.SliceConfig([2, 2]), 12, 2).schedule_tti(np.zeros((4, 12), np.uint8), np.ones(4))
     assert "outside 1..15" in str(e.value)
+
+
+@pytest.mark.parametrize("sched,ues,R,G,threads", [(9, [25] * 20, 25, 4, 0), (9, [5] * 20, 64, 8, 0), (9, [3, 7, 0, 1, 12], 25, 4, 128),
+                                                    (8, [25] * 20, 25, 4, 0), (7, [25] * 20, 64, 8, 256), (1, [50] * 20, 25, 4, 0)])
+def test_shape_specialised_kernels(rs, oracle, sched, ues, R, G, threads):
+    """The hiprtc build of the same source with the cell shape as compile-time constants."""
+    _check_batch(rs, oracle, sched, ues, R, G, n_cells=2, n_ttis=90, threads=threads, jit=True)
