@@ -23,7 +23,8 @@ out = ROOT / "profiles"
 
 
 def one(pattern):
-    f = sorted(glob.glob(str(ROOT / "gpurun_out" / pattern)))
+    # newest file wins (gpurun merges new runs next to older ones)
+    f = sorted(glob.glob(str(ROOT / "gpurun_out" / pattern)), key=lambda x: Path(x).stat().st_mtime)
     if not f:
         raise SystemExit(f"missing {pattern}")
     return Path(f[-1])
@@ -32,7 +33,7 @@ def one(pattern):
 ks = one("prof_kt/*/*_kernel_stats.csv")
 shutil.copy(ks, out / f"{tag}_kernel_stats.csv")
 rows = list(csv.DictReader(ks.open()))
-cell = [r for r in rows if "rs_cell_kernel" in r["Name"]][0]
+cell = max((r for r in rows if "rs_cell_kernel" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
 
 
 def counter(pattern, name):
