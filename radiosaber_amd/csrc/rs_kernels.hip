@@ -669,9 +669,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           k /= 1000.0;
           s_avgk[u] = k;
           /* stage-1 ranking only, never part of a result; psi == 0 slices rank on the numerator */
-          s_rcp32[u] = ((psi_mask >> ku) & 1u) ? (float)(1.0 / k) : 1.0f;
+          s_rcp32[u] = ((psi_mask >> ku) & 1u) ? __builtin_amdgcn_rcpf((float)k) : 1.0f; /* v_rcp_f32, 1 ulp */
         } else {
-          s_rcp32[u] = (float)(1.0 / a);
+          s_rcp32[u] = __builtin_amdgcn_rcpf((float)a);
         }
       }
       if (!p.direct) last_update = t;
@@ -787,7 +787,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
         const uint8_t* rowp = s_cqi + r * Upad;
         /* Exact two-stage argmax.  Stage 1 ranks the segment's users by the cheap
-         * FP32 product a~ = fl32(num) * fl32(fl(1/den)), which is within 2^-22 (relative) of the
+         * FP32 product a~ = fl32(num) * rcp32(fl32(den)) (v_rcp_f32, 1 ulp), which is within 2^-21.4 (relative) of the
          * reference's rounded FP64 quotient q = fl(num/den); a user whose a~ is below (1 - 2^-19) of
          * the largest a~ has a strictly smaller q and can neither win nor tie.  Stage 2 evaluates
          * the survivors with the real IEEE FP64 division, ascending user order, strict '>'.
