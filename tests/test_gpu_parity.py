@@ -325,3 +325,37 @@ def test_device_side_range_errors_are_reported(rs, traces):
 def test_shape_specialised_kernels(rs, oracle, sched, ues, R, G, threads):
     """The hiprtc build of the same source with the cell shape as compile-time constants."""
     _check_batch(rs, oracle, sched, ues, R, G, n_cells=2, n_ttis=90, threads=threads, jit=True)
+
+
+def test_full_size_batch_properties_and_sampled_parity(rs, oracle):
+    """BASELINE configs[3] at full size (512 cells x 20x25 UEs x 25 RBGs, the bench workload, shape-specialised
+    kernel): size-independent properties on every cell + bit-exact parity on a sample of cells."""
+    ues, R, G, n_cells, n_ttis = [25] * 20, 25, 4, 512, 400
+    sc = rs.SliceConfig(ues, weight=[0.05] * 20)
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=9, jit=True)
+    seeds = (np.arange(n_cells, dtype=np.uint64) * 2654435761 + 805290992) % (2**31 - 1)
+    b.seed(seeds.astype(np.uint32))
+    b.synthesize_cqi(99, n_ttis // 40)
+    b.run(n_ttis)
+    st = b.state()
+    # every RBG of every TTI is allocated exactly once
+    assert (st["cum_rbs"].sum(axis=1) == R * G * n_ttis).all()
+    # weighted fairness: slice_rbs_offset_ carries the remainder, so every slice's PRB total stays within
+    # one cell-width of its share
+    per_slice = st["cum_rbs"].reshape(n_cells, 20, 25).sum(axis=2)
+    assert np.abs(per_slice - 0.05 * R * G * n_ttis).max() <= R * G
+    # the carried offsets are integers and sum to ~0
+    assert (st["slice_state"] == np.round(st["slice_state"])).all()
+    assert np.abs(st["slice_state"].sum(axis=1)).max() <= R * G
+    # bytes are consistent with the per-slice reduction the multi-GPU run all-reduces
+    np.testing.assert_array_equal(b.slice_bytes().astype(np.int64),
+                                  st["cum_bytes"].reshape(n_cells, 20, 25).sum(axis=(0, 2)))
+    assert (st["avg_rate"] >= 1).all() and np.isfinite(st["avg_rate"]).all()
+    for c in (0, 1, 63, 64, 255, 256, 510, 511):
+        cell = oracle.Cell(ues, R, G, 9, weights=[0.05] * 20)
+        cell.run_synth(b.download_cqi_epochs(c), int(seeds[c]), n_ttis, log=False)
+        ost = cell.state()
+        np.testing.assert_array_equal(st["cum_bytes"][c], ost["cum_bytes"], err_msg=f"cell {c}")
+        assert st["avg_rate"][c].tobytes() == ost["avg_rate"].tobytes(), f"cell {c}"
+        assert st["slice_state"][c].tobytes() == ost["slice_state"].tobytes(), f"cell {c}"
+    b.close()
