@@ -30,10 +30,6 @@ struct RsMisc {
   int32_t seg_begin[68];
   int32_t target[64];
   int32_t quota[64];
-  int32_t got[64];
-  int32_t final_rbgs[64];
-  int32_t rbg_slice[64];
-  int32_t owner[64];
   int32_t stack[96];             /* serial introsort emulation (debug path) */
   int32_t n_level[48];           /* level-synchronous introsort: live sub-ranges per recursion level */
   uint16_t hist[64 * 16];        /* counting sort: per 64-element chunk, per key */

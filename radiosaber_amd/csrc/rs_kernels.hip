@@ -1,16 +1,22 @@
 /*
  * rs_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the RadioSaber downlink RBG allocation path.
  *
- * One workgroup = one cell.  The workgroup keeps the cell's whole scheduling state in LDS (per-RBG
- * CQI grid u8[U][R], PF averages f64[U], counters, the CQI->rate / EESM tables, slice quotas) and
- * runs n_ttis complete DoSchedule() iterations back to back:
+ * One workgroup = one cell.  The workgroup keeps the cell's whole scheduling state in LDS (RBG-major
+ * CQI grid u8[R][Upad], PF averages f64[U], the CQI->rate / EESM / TBS tables, slice quotas) and runs
+ * n_ttis complete DoSchedule() iterations back to back:
  *
- *   P0  CQI refresh (every 40 TTIs)        HBM -> LDS, 16 B per lane, coalesced
+ *   P0  CQI refresh (every 40 TTIs)        HBM -> LDS, 16 B per lane, transposed on the way in
  *   P1  PF EWMA update per user            ref: src/flows/radio-bearer.cpp:139-164
- *   P2  slice quotas (lanes = slices)      ref: downlink-transport-scheduler.cpp:463-521
- *   P3  best user per (RBG, slice)         ref: :530-567   (the UE x RBG metric scan, FP64 division)
- *   P4  inter-slice assignment             ref: :249-272 GreedyByRow / :351-376 MaximizeCell
+ *   P2  slice quotas (one wave, lanes = slices, beside P3)   ref: downlink-transport-scheduler.cpp:463-521
+ *   P3  best user per (RBG, slice)         ref: :530-567   exact two-stage arg-max: FP32 ranking of 8 users
+ *                                          per load, IEEE FP64 division only for the survivors
+ *   P4  inter-slice assignment             ref: :249-272 GreedyByRow / :351-376 MaximizeCell = exact
+ *                                          std::sort emulation (level-synchronous introsort loop + stable
+ *                                          counting sort) + greedy scan
  *   P5  apply + EESM link adaptation + DoStopSchedule counters     ref: :589-674, :170-221
+ *
+ * The same source is compiled twice: into the library with the cell shape as launch arguments, and at
+ * run time (hiprtc, rs_jit.cpp) with the shape as compile-time constants (RS_JIT_*).
  *
  * No MFMA: the only matrix-shaped object (metric[R][U]) is consumed by an argmax.  All floating
  * point is IEEE FP64 add/mul/div in the reference's operation order; the file MUST be compiled with

@@ -14,8 +14,9 @@
  * The final insertion sort is a stable sort of the array the introsort loop leaves, and a stable
  * order is unique, so it is done as a 16-bucket stable counting sort (descending key).
  *
- * Host+device: the same code is exercised on the CPU against the real std::sort by
- * tests/test_sort_emul.py (through rs_selftest_sort in the C ABI's test hooks).
+ * Host+device: the kernel uses median-of-3 / before() / heap_sort() from here (and the explicit-stack
+ * loop in the RS_SERIAL_SORT debug build); tests/test_sort_emul.py runs the same code on the CPU against
+ * the real std::sort and std::partial_sort (tests/csrc/sort_emul_check.cpp).
  */
 #ifndef RS_SORT_EMUL_H_
 #define RS_SORT_EMUL_H_
