@@ -151,7 +151,8 @@ typedef struct rs_batch_config {
   int32_t phy_error_draws;   /* 1: consume one rand() per UE served in the previous TTI, as the
                                 reference's PHY error model does on the shared libc stream
                                 (ref: src/phy/wideband-cqi-eesm-error-model.cpp:69)              */
-  int32_t threads_per_cell;  /* workgroup size, multiple of 64 in [64,512]; 0 = default        */
+  int32_t threads_per_cell;  /* workgroup size, multiple of 64 in [64,512]; 0 = default: 512, or 256
+                                once the batch puts 4 or more cells on every CU                  */
   int32_t jit;               /* 1: compile the cell kernel for this batch's exact shape at create time
                                 (hiprtc, ~2 s, cached per process); results are identical, the built-in
                                 kernels are used if the compilation fails.  0: built-in kernels.

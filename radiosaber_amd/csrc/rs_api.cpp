@@ -346,7 +346,16 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   if (cfg->n_cells < 1) { fail(RS_ERR_INVALID, "n_cells %d < 1", cfg->n_cells); return nullptr; }
   if (!direct && cfg->cqi_refresh < 1) { fail(RS_ERR_INVALID, "cqi_refresh %d < 1", cfg->cqi_refresh); return nullptr; }
   if (cfg->first_tti < 0) { fail(RS_ERR_INVALID, "first_tti %d < 0", cfg->first_tti); return nullptr; }
-  int threads = cfg->threads_per_cell ? cfg->threads_per_cell : 512;
+  int threads = cfg->threads_per_cell;
+  if (threads == 0) {
+    /* default: 512 threads per cell while the batch leaves at most ~2 cells per CU (per-level latency
+     * matters), 256 (two array positions per lane, fewer instructions per level) once 4+ cells share a CU */
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, cfg->cell.device) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    threads = (!direct && cfg->n_cells >= 4 * cus) ? 256 : 512;
+  }
   if (threads % 64 || threads < 64 || threads > 512) { fail(RS_ERR_INVALID, "threads_per_cell %d", threads); return nullptr; }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { fail(RS_ERR_NO_DEVICE, "no HIP device"); return nullptr; }

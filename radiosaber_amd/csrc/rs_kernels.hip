@@ -1086,7 +1086,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
 }
 #else
 /* shape-specialised entry point compiled at run time (rs_jit.cpp): static LDS of exactly the carve's size */
-extern "C" __global__ void __launch_bounds__(RS_JIT_NT, (RS_JIT_NT == 512 ? 4 : 1)) rs_cell_kernel_jit(RsLaunch p) {
+extern "C" __global__ void __launch_bounds__(RS_JIT_NT, 4) rs_cell_kernel_jit(RsLaunch p) {
   constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT);
   __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
   constexpr int kEpt = RS_JIT_SCHED != 9 ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);
