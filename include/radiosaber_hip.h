@@ -63,8 +63,9 @@ typedef struct rs_config {
   int32_t sched;                /* RS_SCHED_*                                               */
   int32_t device;               /* HIP device ordinal                                       */
   const double* slice_weight;   /* [S] "weight"                                             */
-  const int32_t* algo_alpha;    /* [S] must be 0 (backlogged PF family; alpha=1 is SURVEY 8f N3) */
-  const int32_t* algo_beta;     /* [S] unused while alpha == 0                              */
+  const int32_t* algo_alpha;    /* [S] 0, or 1 = customised slice (ref: :694-711): drop-in mode only, the
+                                   queue state comes in through rs_tti_in.hol_delay / prio_has_data  */
+  const int32_t* algo_beta;     /* [S] 0 or 1: with alpha = 1, multiply the metric by the HoL delay  */
   const int32_t* algo_epsilon;  /* [S] 0 or 1 (pow(x,0)=1, pow(x,1)=x are exact)            */
   const int32_t* algo_psi;      /* [S] 0 or 1                                               */
   const int32_t* user_to_slice; /* [U] non-decreasing (run-length expansion of ues_per_slice) */
@@ -109,6 +110,10 @@ typedef struct rs_tti_in {
                                non-NULL `cqi` is ignored (the metric reads PRB rbg*rbg_size, ref: :536) and link
                                adaptation reads every allocated PRB (ref: :643-646), so CQIs may differ inside
                                an RBG as the simulated channel's reports do                           */
+  /* customised slices (algo_alpha = 1), ref: downlink-transport-scheduler.cpp:694-711,
+   * downlink-nvs-scheduler.cpp:375-387; both may be NULL when every slice has algo_alpha = 0 */
+  const double* hol_delay;       /* [n] GetHeadOfLinePacketDelay() of the user's slice-priority bearer     */
+  const uint8_t* prio_has_data;  /* [n] m_dataToTransmit[slice_priority_[slice]] != 0; NULL = all 1        */
 } rs_tti_in;
 
 /* What RBsAllocation() leaves behind (ref: :589-620 allocation lists + slice_rbs_offset_,

@@ -36,6 +36,9 @@ struct BearerState {
   unsigned long cumulative_bytes = 0;
   unsigned long cumulative_rbs = 0;
   bool has_packets = true; /* InfiniteBuffer: always backlogged */
+  /* customised slices (algo_alpha = 1): state of the slice-priority bearer */
+  double hol_delay = 0;          /* GetHeadOfLinePacketDelay() */
+  bool prio_has_data = true;     /* m_dataToTransmit[slice_priority_[slice]] != 0 */
 };
 
 /* One PDCCH record group: what RBsAllocation() hands to the PHY per scheduled user
@@ -178,6 +181,14 @@ class GpuDownlinkScheduler {
     in.cqi = in_cqi_.data();
     in.avg_rate = in_avg_.data();
     in.cqi_prb = cqi_prb_.empty() ? nullptr : in_prb_.data();
+    in_hol_.resize(n);
+    in_prio_.resize(n);
+    for (int i = 0; i < n; ++i) {
+      in_hol_[i] = bearers_[users_[i]].hol_delay;
+      in_prio_[i] = bearers_[users_[i]].prio_has_data ? 1 : 0;
+    }
+    in.hol_delay = in_hol_.data();
+    in.prio_has_data = in_prio_.data();
     if (sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL) {
       in.rand0 = rand();
       in.rand1 = rand();
@@ -219,7 +230,8 @@ class GpuDownlinkScheduler {
   std::vector<double> slice_ewma_time_;
   std::vector<BearerState> bearers_;
   std::vector<uint8_t> cqi_, in_cqi_, cqi_prb_, in_prb_;
-  std::vector<double> in_avg_;
+  std::vector<double> in_avg_, in_hol_;
+  std::vector<uint8_t> in_prio_;
   std::vector<int> users_, target_, quota_, rbg_to_user_, nprb_, fcqi_, mcs_, tbs_;
   std::vector<Allocation> allocations_;
   unsigned long ts_ = 0;

@@ -75,6 +75,7 @@ def lib():
         L.rso_cell_destroy.argtypes = [C.c_void_p]
         L.rso_cell_set_cqi.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         L.rso_cell_set_cqi_prb.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        L.rso_cell_set_queue_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint8)]
         L.rso_cell_set_last_update.argtypes = [C.c_void_p, C.c_double]
         L.rso_cell_set_avg_rate.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.rso_cell_step.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(_TtiOut)]
@@ -206,6 +207,12 @@ class Cell:
         a = np.ascontiguousarray(prb, np.uint8)
         assert a.shape == (self.U, self.R * self.rbg_size)
         lib().rso_cell_set_cqi_prb(self.h, _p(a, C.c_uint8))
+
+    def set_queue_state(self, hol, prio_has_data):
+        h = np.ascontiguousarray(hol, np.float64)
+        q = np.ascontiguousarray(prio_has_data, np.uint8)
+        assert h.shape == (self.U,) and q.shape == (self.U,)
+        lib().rso_cell_set_queue_state(self.h, _p(h, C.c_double), _p(q, C.c_uint8))
 
     def set_avg_rate(self, avg):
         a = np.ascontiguousarray(avg, np.float64)

@@ -235,6 +235,8 @@ struct rso_cell {
   std::vector<double> ewma;   /* slice_ewma_time_  (ref: downlink-nvs-scheduler.h:41)       */
   std::vector<uint8_t> cqi;   /* [U][R]  CQI of PRB r*rbg_size (what the metric reads) */
   std::vector<uint8_t> cqi_prb; /* [U][R*G] per-PRB CQI when given (EESM/TBS read every PRB), else empty */
+  std::vector<double> hol;      /* [U] GetHeadOfLinePacketDelay() of the slice-priority bearer (alpha != 0 slices) */
+  std::vector<uint8_t> prio_has_data; /* [U] m_dataToTransmit[slice_priority_[slice]] != 0 */
   double eff_of_cqi[16];
 };
 
@@ -281,6 +283,11 @@ void rso_cell_set_user_cqi(rso_cell* c, int user, const uint8_t* row) {
   memcpy(&c->cqi[(size_t)user * c->R], row, c->R);
 }
 void rso_cell_set_last_update(rso_cell* c, double t) { c->last_update.assign(c->U, t); }
+/* queue state the customised (alpha = 1) slice metrics read: downlink-transport-scheduler.cpp:694-711 */
+void rso_cell_set_queue_state(rso_cell* c, const double* hol, const uint8_t* prio_has_data) {
+  c->hol.assign(hol, hol + c->U);
+  c->prio_has_data.assign(prio_has_data, prio_has_data + c->U);
+}
 void rso_cell_set_avg_rate(rso_cell* c, const double* a) { c->avg.assign(a, a + c->U); }
 
 void rso_cell_get_state(const rso_cell* c, double* avg, int64_t* cum_bytes, int64_t* cum_rbs,
@@ -314,13 +321,20 @@ void update_average_rate(rso_cell* c, double now) {
   }
 }
 
-/* ref: downlink-transport-scheduler.cpp:677-713 (alpha == 0 branch; identical in
- * downlink-nvs-scheduler.cpp:360-390).  One bearer per user. */
-double slice_metric(const rso_cell* c, int slice, double se, double avg_rate) {
+/* ref: downlink-transport-scheduler.cpp:677-713 and downlink-nvs-scheduler.cpp:360-390 (the NVS variant
+ * always multiplies the head-of-line delay when alpha != 0).  One bearer per user feeds the average. */
+double slice_metric(const rso_cell* c, int slice, double se, double avg_rate, int user = -1) {
   double average = 1;
   average += avg_rate;
   se = se * 180000 / 1000;
   average /= 1000.0;
+  if (c->alpha[slice] == 0) return pow(se, c->eps[slice]) / pow(average, c->psi[slice]);
+  /* the prioritized flow has no packet: metric 0 */
+  if (user >= 0 && !c->prio_has_data.empty() && c->prio_has_data[user] == 0) return 0;
+  if (c->sched == RSO_SCHED_NVS || c->beta[slice]) {
+    double HoL = (user >= 0 && !c->hol.empty()) ? c->hol[user] : 0;
+    return HoL * pow(se, c->eps[slice]) / pow(average, c->psi[slice]);
+  }
   return pow(se, c->eps[slice]) / pow(average, c->psi[slice]);
 }
 
@@ -392,7 +406,7 @@ int allocate_transport(rso_cell* c, const double* avg, int rand0, int rand1, rso
   std::vector<double> metrics((size_t)R * U);
   for (int i = 0; i < R; i++)
     for (int j = 0; j < U; j++)
-      metrics[(size_t)i * U + j] = slice_metric(c, c->u2s[j], c->eff_of_cqi[c->cqi[(size_t)j * R + i]], avg[j]);
+      metrics[(size_t)i * U + j] = slice_metric(c, c->u2s[j], c->eff_of_cqi[c->cqi[(size_t)j * R + i]], avg[j], j);
   /* :545-567 best user of every slice in every RBG, strict '>' from -1: first max wins */
   std::vector<int> user_index((size_t)R * S, -1);
   std::vector<double> slice_eff((size_t)R * S, 0);
@@ -506,7 +520,7 @@ int allocate_nvs(rso_cell* c, const double* avg, int slice, rso_tti_out* out) {
     int pick = -1;
     for (int u = 0; u < U; u++) {
       if (c->u2s[u] != slice) continue;
-      double m = slice_metric(c, slice, c->eff_of_cqi[c->cqi[(size_t)u * R + r]], avg[u]);
+      double m = slice_metric(c, slice, c->eff_of_cqi[c->cqi[(size_t)u * R + r]], avg[u], u);
       if (m > target && (long)got[u] < required[u]) { target = m; pick = u; }
     }
     out->rbg_to_user[r] = pick;
@@ -536,7 +550,7 @@ extern "C" {
 
 int rso_cell_allocate(rso_cell* c, const double* avg, int rand0, int rand1, rso_tti_out* out) {
   for (int s = 0; s < c->S; s++)
-    if (c->alpha[s] != 0) return -3;
+    if (c->alpha[s] != 0 && c->hol.empty()) return -3; /* customised slices need rso_cell_set_queue_state */
   switch (c->sched) {
     case RSO_SCHED_PF: return allocate_pf(c, avg, out);
     case RSO_SCHED_NVS: return -4; /* needs the slice choice: use rso_cell_step */

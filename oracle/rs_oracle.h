@@ -80,7 +80,7 @@ typedef struct {
   int rbg_size;              /* PRBs per RBG; nb_rbs = R*rbg_size */
   int sched;                 /* RSO_SCHED_* */
   const double* weights;     /* [S] */
-  const int* alpha;          /* [S] algo_alpha (must be 0: backlogged PF family) */
+  const int* alpha;          /* [S] algo_alpha (1 needs rso_cell_set_queue_state; rso_cell_allocate only) */
   const int* beta;           /* [S] */
   const int* epsilon;        /* [S] */
   const int* psi;            /* [S] */
@@ -108,6 +108,8 @@ void rso_cell_set_user_cqi(rso_cell* c, int user, const uint8_t* cqi_row);
 void rso_cell_set_cqi_prb(rso_cell* c, const uint8_t* cqi_prb);
 /* bearer creation instant (RadioBearer ctor -> ResetTransmittedBytes: lastUpdate = Now) */
 void rso_cell_set_last_update(rso_cell* c, double t);
+/* alpha != 0 slices: head-of-line delay and "prioritized bearer has data" per user */
+void rso_cell_set_queue_state(rso_cell* c, const double* hol, const uint8_t* prio_has_data);
 /* one TTI of DoSchedule(): EWMA update at time `now`, RBsAllocation with the two rand() values,
  * DoStopSchedule accounting.  active==NULL: every user is backlogged. */
 int rso_cell_step(rso_cell* c, double now, int rand0, int rand1, rso_tti_out* out);

@@ -52,7 +52,8 @@ class _BatchConfig(C.Structure):
 class _TtiIn(C.Structure):
     _fields_ = [("n_users", C.c_int32), ("user_id", C.POINTER(C.c_int32)),
                 ("cqi", C.POINTER(C.c_uint8)), ("avg_rate", C.POINTER(C.c_double)),
-                ("rand0", C.c_int32), ("rand1", C.c_int32), ("cqi_prb", C.POINTER(C.c_uint8))]
+                ("rand0", C.c_int32), ("rand1", C.c_int32), ("cqi_prb", C.POINTER(C.c_uint8)),
+                ("hol_delay", C.POINTER(C.c_double)), ("prio_has_data", C.POINTER(C.c_uint8))]
 
 
 class _TtiOut(C.Structure):
@@ -248,7 +249,7 @@ class TtiScheduler:
     __del__ = close
 
     def schedule_tti(self, cqi, avg_rate, rand0=0, rand1=0, user_id: Optional[Sequence[int]] = None,
-                     cqi_prb=None) -> TtiResult:
+                     cqi_prb=None, hol_delay=None, prio_has_data=None) -> TtiResult:
         """cqi [n][R] per-RBG CQI, or cqi_prb [n][R*rbg_size] per-PRB CQI (then cqi may be None)."""
         prb = None
         if cqi_prb is not None:
@@ -263,12 +264,16 @@ class TtiScheduler:
         avg = np.ascontiguousarray(avg_rate, np.float64)
         assert avg.shape == (n,)
         uid = None if user_id is None else np.ascontiguousarray(user_id, np.int32)
+        hol = None if hol_delay is None else np.ascontiguousarray(hol_delay, np.float64)
+        prio = None if prio_has_data is None else np.ascontiguousarray(prio_has_data, np.uint8)
         S = self.slices.n_slices
         res = TtiResult(np.zeros(S, np.int32), np.zeros(S, np.int32), np.zeros(self.R, np.int32),
                         np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32))
         tin = _TtiIn(n, _p(uid, C.c_int32) if uid is not None else None,
                      _p(cqi, C.c_uint8) if cqi is not None else None, _p(avg, C.c_double), rand0, rand1,
-                     _p(prb, C.c_uint8) if prb is not None else None)
+                     _p(prb, C.c_uint8) if prb is not None else None,
+                     _p(hol, C.c_double) if hol is not None else None,
+                     _p(prio, C.c_uint8) if prio is not None else None)
         tout = _TtiOut(_p(res.target_rbs, C.c_int32), _p(res.quota_rbgs, C.c_int32),
                        _p(res.rbg_to_user, C.c_int32), _p(res.user_nprb, C.c_int32),
                        _p(res.user_final_cqi, C.c_int32), _p(res.user_mcs, C.c_int32),

@@ -160,7 +160,9 @@ int rs_link_tables(double eff[16], double kbps[16], double eesm_e[16], double ee
 struct rs_batch {
   rs_batch_config cfg;
   std::vector<double> weight;
-  std::vector<int32_t> eps, psi, u2s;
+  std::vector<int32_t> eps, psi, u2s, alpha, beta;
+  bool any_alpha = false;
+  int32_t *d_alpha = nullptr, *d_beta = nullptr;
   int S, U, R, G, sched, n_cells, threads;
   bool direct = false;
   hipStream_t stream = nullptr;
@@ -193,7 +195,7 @@ struct rs_batch {
 
 namespace {
 
-int validate(const rs_config* c) {
+int validate(const rs_config* c, bool direct) {
   if (!c) return fail(RS_ERR_INVALID, "null config");
   if (c->n_slices < 1 || c->n_slices > RS_MAX_SLICES) return fail(RS_ERR_INVALID, "n_slices %d outside 1..%d", c->n_slices, RS_MAX_SLICES);
   if (c->n_users < 1 || c->n_users > RS_MAX_USERS) return fail(RS_ERR_INVALID, "n_users %d outside 1..%d", c->n_users, RS_MAX_USERS);
@@ -205,7 +207,10 @@ int validate(const rs_config* c) {
   if (!c->slice_weight || !c->algo_alpha || !c->algo_epsilon || !c->algo_psi || !c->user_to_slice)
     return fail(RS_ERR_INVALID, "null slice/user array");
   for (int s = 0; s < c->n_slices; s++) {
-    if (c->algo_alpha[s] != 0) return fail(RS_ERR_INVALID, "slice %d: algo_alpha != 0 is not supported", s);
+    if (c->algo_alpha[s] != 0 && !direct)
+      return fail(RS_ERR_INVALID, "slice %d: algo_alpha != 0 needs per-TTI queue state: drop-in mode (rs_create) only", s);
+    if ((c->algo_alpha[s] | 1) != 1 || (c->algo_alpha[s] && (!c->algo_beta || (c->algo_beta[s] | 1) != 1)))
+      return fail(RS_ERR_INVALID, "slice %d: algo_alpha/algo_beta must be 0 or 1", s);
     if ((c->algo_epsilon[s] | 1) != 1 || (c->algo_psi[s] | 1) != 1)
       return fail(RS_ERR_INVALID, "slice %d: algo_epsilon/algo_psi must be 0 or 1", s);
   }
@@ -282,6 +287,10 @@ int batch_alloc(rs_batch* b) {
   HIP_TRY(hipMemcpy(b->d_eps, b->eps.data(), 4 * S, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&b->d_psi, 4 * S));
   HIP_TRY(hipMemcpy(b->d_psi, b->psi.data(), 4 * S, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&b->d_alpha, 4 * S));
+  HIP_TRY(hipMemcpy(b->d_alpha, b->alpha.data(), 4 * S, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&b->d_beta, 4 * S));
+  HIP_TRY(hipMemcpy(b->d_beta, b->beta.data(), 4 * S, hipMemcpyHostToDevice));
   std::vector<uint8_t> us(U);
   for (size_t u = 0; u < U; u++) us[u] = (uint8_t)b->u2s[u];
   HIP_TRY(hipMalloc(&b->d_user_slice, U));
@@ -330,6 +339,7 @@ int batch_alloc(rs_batch* b) {
   L.refresh = b->cfg.cqi_refresh;
   L.phy_draws = b->cfg.phy_error_draws;
   L.tab = b->d_tab; L.weight = b->d_weight; L.eps = b->d_eps; L.psi = b->d_psi;
+  L.alpha = b->d_alpha; L.beta = b->d_beta;
   L.user_slice = b->d_user_slice;
   L.tbs_eff = b->d_tbs_eff;
   L.avg = b->d_avg; L.tx_bytes = b->d_tx; L.cum_bytes = b->d_cumb; L.cum_rbs = b->d_cumr;
@@ -342,7 +352,7 @@ int batch_alloc(rs_batch* b) {
 
 rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   if (!cfg) { fail(RS_ERR_INVALID, "null config"); return nullptr; }
-  if (validate(&cfg->cell)) return nullptr;
+  if (validate(&cfg->cell, direct)) return nullptr;
   if (cfg->n_cells < 1) { fail(RS_ERR_INVALID, "n_cells %d < 1", cfg->n_cells); return nullptr; }
   if (!direct && cfg->cqi_refresh < 1) { fail(RS_ERR_INVALID, "cqi_refresh %d < 1", cfg->cqi_refresh); return nullptr; }
   if (cfg->first_tti < 0) { fail(RS_ERR_INVALID, "first_tti %d < 0", cfg->first_tti); return nullptr; }
@@ -371,6 +381,10 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   b->weight.assign(c.slice_weight, c.slice_weight + b->S);
   b->eps.assign(c.algo_epsilon, c.algo_epsilon + b->S);
   b->psi.assign(c.algo_psi, c.algo_psi + b->S);
+  b->alpha.assign(c.algo_alpha, c.algo_alpha + b->S);
+  b->beta.assign(b->S, 0);
+  if (c.algo_beta) b->beta.assign(c.algo_beta, c.algo_beta + b->S);
+  for (int s = 0; s < b->S; s++) b->any_alpha |= b->alpha[s] != 0;
   b->u2s.assign(c.user_to_slice, c.user_to_slice + b->U);
   b->cfg.cell.slice_weight = nullptr; b->cfg.cell.algo_alpha = nullptr; b->cfg.cell.algo_beta = nullptr;
   b->cfg.cell.algo_epsilon = nullptr; b->cfg.cell.algo_psi = nullptr; b->cfg.cell.user_to_slice = nullptr;
@@ -425,7 +439,7 @@ rs_batch* rs_batch_create(const rs_batch_config* cfg) { return batch_new(cfg, fa
 void rs_batch_destroy(rs_batch* b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void* ptrs[] = {b->d_tab, b->d_weight, b->d_eps, b->d_psi, b->d_user_slice, b->d_tbs_eff, b->d_avg, b->d_tx, b->d_cumb, b->d_cumr,
+  void* ptrs[] = {b->d_tab, b->d_weight, b->d_eps, b->d_psi, b->d_alpha, b->d_beta, b->d_user_slice, b->d_tbs_eff, b->d_avg, b->d_tx, b->d_cumb, b->d_cumr,
                   b->d_sstate, b->d_scal, b->d_epochs, b->d_trace, b->d_user_trace, b->d_err, b->d_slice_bytes, b->d_stamps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -656,14 +670,16 @@ struct rs_ctx {
 
 namespace {
 struct CtxLayout {
-  size_t grid, slice, avg, prb, in_total, tbs, uinfo, map, quota, target, out_total;
+  size_t grid, slice, avg, hol, prio, prb, in_total, tbs, uinfo, map, quota, target, out_total;
 };
 CtxLayout ctx_layout(int n, int R, int S, int G) {
   CtxLayout l;
   l.grid = 0;
   l.slice = round_up(n * R, 16);
   l.avg = l.slice + round_up(n, 16);
-  l.prb = l.avg + 8 * (size_t)n;
+  l.hol = l.avg + 8 * (size_t)n;
+  l.prio = l.hol + 8 * (size_t)n;
+  l.prb = l.prio + round_up(n, 16);
   l.in_total = l.prb + round_up(n * R * G, 16);
   l.tbs = 0;
   l.uinfo = 4 * (size_t)n;
@@ -745,6 +761,18 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   }
   memset(c->h_in + l.grid + (size_t)n * R, 0, l.slice - (size_t)n * R);
   memcpy(c->h_in + l.avg, in->avg_rate, 8 * (size_t)n);
+  if (b->any_alpha) {
+    bool need_hol = false;
+    for (int i = 0; i < n; i++) {
+      const int sl = h_slice[i];
+      need_hol |= b->alpha[sl] && (b->sched == RS_SCHED_NVS || b->beta[sl]);
+    }
+    if (need_hol && !in->hol_delay) return fail(RS_ERR_INVALID, "hol_delay is required by a customised (alpha=1, beta=1) slice");
+    if (in->hol_delay) memcpy(c->h_in + l.hol, in->hol_delay, 8 * (size_t)n);
+    else memset(c->h_in + l.hol, 0, 8 * (size_t)n);
+    if (in->prio_has_data) memcpy(c->h_in + l.prio, in->prio_has_data, (size_t)n);
+    else memset(c->h_in + l.prio, 1, (size_t)n);
+  }
   hipStream_t st = b->stream;
   HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, st));
   RsLaunch L = b->base;
@@ -762,6 +790,9 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   L.user_slice = c->d_in + l.slice;
   L.avg = (double*)(c->d_in + l.avg);
   L.prb_cqi = in->cqi_prb ? c->d_in + l.prb : nullptr;
+  L.queue_mode = b->any_alpha ? 1 : 0;
+  L.hol = (const double*)(c->d_in + l.hol);
+  L.prio = c->d_in + l.prio;
   if (b->sched == RS_SCHED_PF) { L.n_seg = (n + RS_PF_SEG - 1) / RS_PF_SEG; L.n_items = R * L.n_seg; }
   L.log_tbs = (int32_t*)(c->d_out + l.tbs);
   L.log_uinfo = (int32_t*)(c->d_out + l.uinfo);

@@ -119,6 +119,12 @@ struct RsLaunch {
   const int32_t* psi;        /* [S] */
   const uint8_t* user_slice; /* [U] */
   const uint8_t* prb_cqi;    /* direct mode, optional: [U][R*G] per-PRB CQI for the EESM sum */
+  /* direct mode, customised slices (alpha = 1): */
+  int32_t queue_mode;        /* 1: some slice has alpha != 0 */
+  const int32_t* alpha;      /* [S] */
+  const int32_t* beta;       /* [S] */
+  const double* hol;         /* [U] head-of-line delay of the slice-priority bearer */
+  const uint8_t* prio;       /* [U] prioritized bearer has data (NULL = all) */
   const int32_t* tbs_eff;    /* [R+1][27] TBS bits of n RBGs (n*G PRBs) at itbs, incl. the >110-PRB rule */
   /* state */
   double* avg;               /* [cells][U] */

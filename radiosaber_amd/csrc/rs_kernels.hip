@@ -675,7 +675,18 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           k /= 1000.0;
           s_avgk[u] = k;
           /* stage-1 ranking only, never part of a result; psi == 0 slices rank on the numerator */
-          s_rcp32[u] = ((psi_mask >> ku) & 1u) ? __builtin_amdgcn_rcpf((float)k) : 1.0f; /* v_rcp_f32, 1 ulp */
+          float r32 = ((psi_mask >> ku) & 1u) ? __builtin_amdgcn_rcpf((float)k) : 1.0f; /* v_rcp_f32, 1 ulp */
+          if (p.queue_mode) {
+            /* customised slice (ref: :694-711): metric 0 while the prioritized bearer is empty, times the
+             * head-of-line delay when beta (sched 7: always) -- folded into the stage-1 factor */
+            const int sl = p.user_slice[u];
+            if (p.alpha[sl]) {
+              const bool has = p.prio ? p.prio[u] != 0 : true;
+              const bool use_hol = SCHED == 7 || p.beta[sl] != 0;
+              r32 = !has ? 0.0f : (use_hol ? r32 * (float)p.hol[u] : r32);
+            }
+          }
+          s_rcp32[u] = r32;
         } else {
           s_rcp32[u] = __builtin_amdgcn_rcpf((float)a);
         }
@@ -786,10 +797,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         double best = SCHED == 1 ? 0.0 : (SCHED == 7 ? -1.7976931348623157e308 : -1.0);
         int bu = -1, bkey = 0;
         int sl_eps = 1, sl_psi = 1;
+        int sl_custom = 0; /* 1: alpha slice, 2: alpha slice with the HoL factor */
         if (SCHED != 1) {
           int sl = SCHED == 7 ? (p.direct ? (int)p.user_slice[0] : seg) : seg;
           sl_eps = p.eps[sl];
           sl_psi = p.psi[sl];
+          if (p.queue_mode && p.alpha[sl]) sl_custom = (SCHED == 7 || p.beta[sl] != 0) ? 2 : 1;
         }
         const uint8_t* rowp = s_cqi + r * Upad;
         /* Exact two-stage argmax.  Stage 1 ranks the segment's users by the cheap
@@ -835,6 +848,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           uint32_t cand = 0;
 #pragma unroll
           for (int k = 0; k < RS_P3_BLOCK; ++k) cand |= (av[k] >= thr && av[k] > 0.0f) ? (1u << k) : 0u;
+          /* customised slices can rank every user at 0 (no prioritized data): the reference's scan then
+           * keeps the first user (0 > -1), so that user goes to stage 2 */
+          if (sl_custom && !cand) cand = 1u << ((ub > blk ? ub : blk) - blk);
           while (cand) {
             const int j = __ffs((int)cand) - 1;
             cand &= cand - 1;
@@ -846,7 +862,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               metric = s_num[c] / s_avg[u];
             } else {
               /* ref: :688-693  pow(se_kbps, eps) / pow(avg_kbps, psi), eps, psi in {0,1} */
-              metric = (sl_eps ? s_num[c] : 1.0) / (sl_psi ? s_avgk[u] : 1.0);
+              const double num = sl_eps ? s_num[c] : 1.0, den = sl_psi ? s_avgk[u] : 1.0;
+              if (sl_custom && p.prio && p.prio[u] == 0) metric = 0.0;
+              else if (sl_custom == 2) metric = p.hol[u] * num / den; /* HoL * pow(se) / pow(avg), left to right */
+              else metric = num / den;
             }
             if (metric > best) { best = metric; bu = u; bkey = c; }
           }

@@ -359,3 +359,61 @@ def test_full_size_batch_properties_and_sampled_parity(rs, oracle):
         assert st["avg_rate"][c].tobytes() == ost["avg_rate"].tobytes(), f"cell {c}"
         assert st["slice_state"][c].tobytes() == ost["slice_state"].tobytes(), f"cell {c}"
     b.close()
+
+
+@pytest.mark.parametrize("sched", [9, 8, 7])
+def test_drop_in_customised_slices(rs, oracle, sched):
+    """algo_alpha = 1 slices (metric 0 while the prioritized bearer is empty, times the
+    head-of-line delay when algo_beta = 1; sched 7 always multiplies it) -- drop-in mode vs the oracle."""
+    ues = [6, 5, 7, 4, 8, 6]
+    alpha = [0, 1, 1, 1, 1, 0]
+    beta = [0, 0, 1, 1, 1, 0]
+    eps = [1, 1, 1, 1, 0, 1]
+    psi = [1, 1, 1, 0, 1, 0]
+    S, R, G = len(ues), 25, 4
+    w = [1.0 / S] * S
+    sc = rs.SliceConfig(ues, weight=w, algo_alpha=alpha, algo_beta=beta, algo_epsilon=eps, algo_psi=psi)
+    U = sc.n_users
+    ts = rs.TtiScheduler(sc, R, G, sched=sched)
+    cell = oracle.Cell(ues, R, G, sched, weights=w, epsilon=eps, psi=psi, alpha=alpha, beta=beta)
+    rng = np.random.default_rng(23)
+    starts = np.cumsum([0] + ues)
+    for it in range(14):
+        cqi = synth_cqi(500 + it, (U, R), HIST)
+        avg = rng.uniform(1e3, 5e6, U)
+        hol = rng.uniform(1e-5, 0.4, U)
+        prio = (rng.random(U) < 0.7).astype(np.uint8)
+        if it % 4 == 1:
+            prio[starts[2]:starts[3]] = 0          # a whole customised slice without prioritized data
+        if it % 4 == 2:
+            avg[:] = 98000.0                       # exact ties: HoL alone separates the users
+        if it % 4 == 3:
+            hol[starts[3]:starts[4]] = hol[starts[3]]  # equal delays inside a slice
+        r0, r1 = int(rng.integers(0, 2**31 - 1)), int(rng.integers(0, 2**31 - 1))
+        cell.set_cqi(cqi)
+        cell.set_queue_state(hol, prio)
+        if sched == 7:
+            sl = it % S
+            ids = np.arange(starts[sl], starts[sl + 1])
+            res = ts.schedule_tti(cqi[ids], avg[ids], user_id=ids, hol_delay=hol[ids], prio_has_data=prio[ids])
+            # oracle: per RBG the first maximum of the NVS slice metric from lowest()
+            kb = rs.link_tables()["kbps"]
+            num = kb[cqi[ids]] if eps[sl] else np.ones((len(ids), R))
+            den = ((1 + avg[ids]) / 1000.0)[:, None] if psi[sl] else np.ones((len(ids), 1))
+            if alpha[sl]:
+                met = np.where(prio[ids][:, None] != 0, hol[ids][:, None] * num / den, 0.0)
+            else:
+                met = num / den
+            np.testing.assert_array_equal(res.rbg_to_user, ids[np.argmax(met, axis=0)], err_msg=f"it {it}")
+            continue
+        out = cell.new_out()
+        assert cell.allocate(avg, r0, r1, out) == 0
+        res = ts.schedule_tti(cqi, avg, r0, r1, hol_delay=hol, prio_has_data=prio)
+        np.testing.assert_array_equal(res.rbg_to_user, out.rbg_to_user, err_msg=f"it {it}")
+        np.testing.assert_array_equal(res.quota_rbgs, out.quota_rbgs)
+        np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits)
+    with pytest.raises(rs.RadioSaberError) as e:
+        ids = np.arange(starts[2], starts[3])  # a customised slice, no hol_delay given
+        ts.schedule_tti(cqi[ids], avg[ids], 1, 2, user_id=ids)
+    assert "hol_delay" in str(e.value)
+    ts.close()
