@@ -130,10 +130,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    # one rank per GPU; RS_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs than ranks
+    backend = os.environ.get("RS_BENCH_BACKEND", "nccl")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     S, U, R = args.slices, args.slices * args.ues_per_slice, args.rbgs
     slices = rs.SliceConfig([args.ues_per_slice] * S, weight=[1.0 / S] * S)
@@ -144,6 +150,8 @@ def main():
     seeds = sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, args.cells))
     batch.seed(seeds)
     batch.synthesize_cqi(sharding.cqi_seed_for_cell_block(0x5AB3, rank), n_epochs)  # generated on the device, stay in HBM
+
+    red_dev = "cuda" if backend == "nccl" else "cpu"  # where the tiny reductions live
 
     def sync_all():
         torch.cuda.synchronize()
@@ -159,7 +167,7 @@ def main():
     sync_all()
     wall = time.perf_counter() - t0
     if world > 1:
-        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([wall], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
 
@@ -168,6 +176,8 @@ def main():
     torch.cuda.synchronize()
     batch.slice_bytes_into(slice_bytes.data_ptr())
     batch.sync()
+    if red_dev == "cpu":
+        slice_bytes = slice_bytes.cpu()
     sharding.all_reduce_slice_bytes(slice_bytes, dist if world > 1 else None)
     total_bytes = int(slice_bytes.sum().item())
 
