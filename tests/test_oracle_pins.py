@@ -31,13 +31,11 @@ def _ref(oracle, name):
     return L
 
 
-def test_tables_match_golden_json(oracle):
-    g = json.loads((GOLDEN / "amc_tables.json").read_text())
+def test_tables_match_golden_fixture(oracle):
+    g = np.load(GOLDEN / "amc_tables.npz")
     t = oracle.tables()
-    assert (t["tbs"] == np.array(g["tbs"])).all()
-    assert (t["mcs_to_itbs"] == np.array(g["mcs_to_itbs"])).all()
-    assert (t["cqi_to_mcs"] == np.array(g["cqi_to_mcs"])).all()
-    assert (t["sinr_for_cqi"] == np.array(g["sinr_for_cqi"])).all()
+    for k in ("tbs", "mcs_to_itbs", "cqi_to_mcs", "sinr_for_cqi"):
+        assert (t[k] == g[k]).all(), k
 
 
 def test_tables_match_reference_unittest_copy(oracle):

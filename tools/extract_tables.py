@@ -6,12 +6,12 @@ initialisers of four arrays in src/protocolStack/mac/AMCModule.cpp
 (MapCQIToMCS :36-40, SINRForCQIIndex :96-100, McsToItbs :114-117,
 TransportBlockSizeTable :120-231 = 3GPP TS 36.213 Table 7.1.7.2.1-1) and writes
 
-  radiosaber_amd/csrc/rs_amc_tables.inc   numbers only, our own formatting
-  tests/golden/amc_tables.json            the same numbers for the python tests
+  radiosaber_amd/data/amc_tables.npz      binary arrays; radiosaber_amd/build.py turns them into the generated
+                                          (git-ignored) header csrc/rs_amc_tables.inc at build time
+  tests/golden/amc_tables.npz             the same numbers for the python tests
 
 No reference source text is copied: only the numeric values (3GPP-standard facts).
 """
-import json
 import re
 import sys
 from pathlib import Path
@@ -47,25 +47,14 @@ def main():
     assert len(tbs) == 110 * 27, len(tbs)
     sinr_txt = grab(txt, "double SINRForCQIIndex[15]")
 
-    out = ROOT / "radiosaber_amd" / "csrc" / "rs_amc_tables.inc"
-    with out.open("w") as f:
-        f.write("// GENERATED by tools/extract_tables.py -- numeric data only.\n")
-        f.write("// 3GPP TS 36.213 Table 7.1.7.2.1-1 (TBS, 110 x 27), Table 7.1.7.1-1 (MCS->Itbs),\n")
-        f.write("// CQI->MCS and CQI->SINR[dB] maps as used by the reference AMC module\n")
-        f.write("// (values captured from /root/reference/src/protocolStack/mac/AMCModule.cpp:36-40,96-100,114-117,120-231).\n")
-        f.write("#define RS_AMC_CQI_TO_MCS " + ", ".join(map(str, cqi_to_mcs)) + "\n")
-        f.write("#define RS_AMC_SINR_FOR_CQI " + ", ".join(sinr_txt) + "\n")
-        f.write("#define RS_AMC_MCS_TO_ITBS " + ", ".join(map(str, mcs_to_itbs)) + "\n")
-        f.write("#define RS_AMC_TBS_TABLE \\\n")
-        for r in range(110):
-            row = tbs[r * 27:(r + 1) * 27]
-            f.write("  " + ", ".join(map(str, row)) + (", \\\n" if r < 109 else "\n"))
-    gold = ROOT / "tests" / "golden" / "amc_tables.json"
-    gold.write_text(json.dumps({
-        "source": "AMCModule.cpp:36-40,96-100,114-117,120-231 (numeric values only)",
-        "cqi_to_mcs": cqi_to_mcs, "sinr_for_cqi": sinr, "mcs_to_itbs": mcs_to_itbs,
-        "tbs": [tbs[r * 27:(r + 1) * 27] for r in range(110)],
-    }))
+    import numpy as np
+    payload = dict(tbs=np.array(tbs, np.int32).reshape(110, 27), mcs_to_itbs=np.array(mcs_to_itbs, np.int32),
+                   cqi_to_mcs=np.array(cqi_to_mcs, np.int32), sinr_for_cqi=np.array(sinr, np.float64))
+    out = ROOT / "radiosaber_amd" / "data" / "amc_tables.npz"
+    out.parent.mkdir(exist_ok=True)
+    np.savez_compressed(out, **payload)
+    gold = ROOT / "tests" / "golden" / "amc_tables.npz"
+    np.savez_compressed(gold, **payload)
     print("wrote", out, gold)
 
 
