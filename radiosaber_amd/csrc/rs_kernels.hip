@@ -277,14 +277,40 @@ __device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
 #define RS_SUBSTAMP(i) do { } while (0)
 #endif
 
+/* inclusive wave64 prefix sum (same DPP ladder as the reductions; every lane keeps its partial) */
+__device__ __forceinline__ int wave_scan_incl(int v) {
+  const int identity = 0;
+  RS_DPP_STEP(op_add, 0x111, 0xf, 0xf); /* row_shr:1 */
+  RS_DPP_STEP(op_add, 0x112, 0xf, 0xf); /* row_shr:2 */
+  RS_DPP_STEP(op_add, 0x114, 0xf, 0xe); /* row_shr:4 */
+  RS_DPP_STEP(op_add, 0x118, 0xf, 0xc); /* row_shr:8 */
+  RS_DPP_STEP(op_add, 0x142, 0xa, 0xf); /* row_bcast:15 */
+  RS_DPP_STEP(op_add, 0x143, 0xc, 0xf); /* row_bcast:31 */
+  return v;
+}
+
+/*
+ * One std::__unguarded_partition per live sub-range and level, decided locally from stop counts.
+ * In [lo, hi) = (f, l) with pivot key pk, an A-stop is an element with key <= pk (where the upward scan
+ * halts), a B-stop one with key >= pk (downward scan).  With A(x) = A-stops in [lo, x) and B(x) = B-stops in
+ * (x, hi): the library swaps the j-th A-stop from the left with the j-th B-stop from the right while the
+ * former lies left of the latter, so
+ *     an A-stop x is swapped  <=>  B(x) > A(x)   (it receives the element of B-stop number A(x) from the right)
+ *     a  B-stop x is swapped  <=>  A(x) > B(x)   (it receives the element of A-stop number B(x) from the left)
+ * and the returned cut is the leftmost position that is an unswapped A-stop or a swapped B-stop.
+ * Swapped elements travel through `xbuf` (A-stop number a at f+a, B-stop number b at l-1-b: they cannot
+ * meet, a + b <= len - 3); the cut is an LDS atomicMin per sub-range (slot f>>4: live sub-ranges are longer
+ * than 16, so their slots differ).  Counts come from per-chunk ballots + one prefix scan per wave.
+ */
 template <int EPT>
-__device__ void introsort_levels_reg(uint32_t* v, int N, uint16_t* posA, uint16_t* posB, uint16_t* cutbuf, Misc* m,
+__device__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t* cuts, Misc* m,
                                      unsigned long long* sub) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
 #ifdef RS_STAMPS
   unsigned long long sub_prev = __builtin_readcyclecounter();
 #endif
   const int n_chunks = (N + 63) >> 6;
+  const unsigned long long lt_lane = (1ull << lane) - 1ull, le_lane = ~0ull >> (63 - lane);
   uint32_t e[EPT];
   int F[EPT], L[EPT];
 #pragma unroll
@@ -335,7 +361,7 @@ __device__ void introsort_levels_reg(uint32_t* v, int N, uint16_t* posA, uint16_
         else if (rs_sort::before(sb, sc)) { pick = ic; sp = sc; }
         else { pick = ib; sp = sb; }
         pk = (int)(sp >> 16);
-        if (x == f) { e[i] = sp; moved[i] = true; }
+        if (x == f) { e[i] = sp; moved[i] = true; cuts[f >> 4] = 0x7fffffff; }
         else if (x == pick) { e[i] = s0; moved[i] = true; }
       }
       const int k = (int)(e[i] >> 16);
@@ -348,75 +374,65 @@ __device__ void introsort_levels_reg(uint32_t* v, int N, uint16_t* posA, uint16_
         m->maskA[c] = mAi[i];
         m->maskB[c] = mBi[i];
       }
-      if (x < N) {
-        posA[x] = 0xFFFF;
-        posB[x] = 0xFFFF;
-      }
     }
     RS_SUBSTAMP(0);
     __syncthreads();
     RS_SUBSTAMP(1);
     if (m->n_level[level] == 0) break;
-    /* R: rank of every stop inside its sub-range; the swapped pivot/median go back to LDS */
+    /* R: stop counts -> swap decision; swapped elements to the exchange buffer, cut candidates to the slot */
+    int pre; /* lane c: stops in chunks < c, A-stops in the low half, B-stops in the high half */
+    {
+      int cnt = 0;
+      if (lane < n_chunks) cnt = __popcll(m->maskA[lane]) | (__popcll(m->maskB[lane]) << 16);
+      pre = wave_scan_incl(cnt) - cnt;
+    }
+    int slot[EPT]; /* where my element went / where its replacement arrives; -1: not swapped */
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       const int x = i * nt + tid;
       const int c = i * nwaves + wave;
       if (moved[i]) v[x] = e[i];
-      if (isA[i]) {
-        const int lo = F[i] + 1;
-        const int a = (lo >> 6) == c ? __popcll(mAi[i] & bit_range(lo & 63, lane)) : count_bits_in(m->maskA, lo, x);
-        posA[F[i] + a] = (uint16_t)x;
-      }
-      if (isB[i]) {
-        const int hi = L[i];
-        const int b = ((hi - 1) >> 6) == c ? __popcll(mBi[i] & bit_range(lane + 1, ((hi - 1) & 63) + 1))
-                                           : count_bits_in(m->maskB, x + 1, hi);
-        posB[F[i] + b] = (uint16_t)x;
-      }
+      /* counts are taken by every lane: ds_bpermute returns 0 for a source lane that is masked off */
+      const int lo = F[i] + 1, hm = L[i] != 0 ? L[i] - 1 : 0;
+      const int wlo = lo >> 6, whi = hm >> 6;
+      const int plo = __builtin_amdgcn_ds_bpermute(wlo << 2, pre) & 0xffff;
+      const int phi = (int)((unsigned)__builtin_amdgcn_ds_bpermute(whi << 2, pre) >> 16);
+      const unsigned long long mlo = m->maskA[wlo], mhi = m->maskB[whi];
+      const int pc = __builtin_amdgcn_readlane(pre, c & 63);
+      const int a = (pc & 0xffff) + __popcll(mAi[i] & lt_lane) - plo - __popcll(mlo & ((1ull << (lo & 63)) - 1ull));
+      const int b = phi + __popcll(mhi & (~0ull >> (63 - (hm & 63)))) - (int)((unsigned)pc >> 16) - __popcll(mBi[i] & le_lane);
+      slot[i] = (isA[i] && b > a) ? F[i] + a : (isB[i] && a > b) ? hm - b : -1;
+      if (slot[i] >= 0) xbuf[slot[i]] = e[i];
+      const bool cand = isA[i] ? !(b > a) : (isB[i] && a > b);
+      /* leftmost candidate of its sub-range inside this chunk reports */
+      const unsigned long long mC = __ballot(cand);
+      const int lo_in = lo - (c << 6);
+      if (cand && (mC & bit_range(lo_in > 0 ? lo_in : 0, lane)) == 0ull) atomicMin(&cuts[F[i] >> 4], x);
     }
     RS_SUBSTAMP(2);
     __syncthreads();
     RS_SUBSTAMP(3);
-    /* S: the Hoare swaps (L[j], Rr[j]) and the cut */
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int x = i * nt + tid;
-      if (L[i] != 0 && x > F[i]) {
-        const int f = F[i];
-        const int j = x - f - 1;
-        const int l = posA[f + j], r = posB[f + j];
-        const int l1 = posA[f + j + 1], r1 = posB[f + j + 1];
-        const bool sw = l != 0xFFFF && r != 0xFFFF && l < r;
-        const bool sw1 = l1 != 0xFFFF && r1 != 0xFFFF && l1 < r1;
-        if (sw) {
-          const uint32_t a = v[l], b = v[r];
-          v[l] = b;
-          v[r] = a;
-          if (!sw1) cutbuf[f] = (uint16_t)((l1 != 0xFFFF && l1 < r) ? l1 : r);
-        } else if (j == 0) {
-          cutbuf[f] = (uint16_t)l;
-        }
-      }
-    }
-    RS_SUBSTAMP(4);
-    __syncthreads();
-    RS_SUBSTAMP(5);
-    /* U: move to the child sub-range; sub-ranges of at most 16 retire */
+    /* S: receive the swapped element, then move to the child sub-range; sub-ranges of at most 16 retire */
     bool any = false;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       const int x = i * nt + tid;
       if (L[i] != 0) {
-        const int cut = cutbuf[F[i]];
-        e[i] = v[x];
+        const int cut = cuts[F[i] >> 4];
+        if (slot[i] >= 0) {
+          /* an A-stop's slot f+a pairs with B-stop slot l-1-a and vice versa */
+          e[i] = xbuf[F[i] + L[i] - 1 - slot[i]];
+          v[x] = e[i];
+        }
         if (x < cut) L[i] = cut; else F[i] = cut;
         if (L[i] - F[i] <= 16) L[i] = 0;
         any |= L[i] != 0;
       }
     }
     if (__ballot(any) && lane == 0) atomicAdd(&m->n_level[level + 1], 1);
-    RS_SUBSTAMP(6);
+    RS_SUBSTAMP(4);
+    __syncthreads();
+    RS_SUBSTAMP(5);
 #ifdef RS_STAMPS
     if (tid == 0) sub[7] += 1;
 #endif
@@ -904,7 +920,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         uint16_t* sx = (uint16_t*)(lds + o.sortx);
         uint16_t* pa = (uint16_t*)s_sorted;
         /* EPT = array positions per thread, picked by the host (0: any size, state in LDS) */
-        if constexpr (EPT > 0) introsort_levels_reg<EPT>(s_elems, N, pa, pa + N, sx, m, sort_sub);
+        if constexpr (EPT > 0) introsort_levels_reg<EPT>(s_elems, N, s_sorted, (int32_t*)sx, m, sort_sub);
         else introsort_loop_levels(s_elems, N, pa, pa + N, sx, sx + N, sx + 2 * N, sx + 3 * N, m);
       }
 #endif

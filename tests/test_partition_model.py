@@ -73,3 +73,52 @@ def test_parallel_partition_equals_serial():
         cut_p = parallel_partition(b, 1, n, b[0])
         assert cut_s == cut_p, (trial, n, cut_s, cut_p)
         assert (a == b).all(), trial
+
+
+def local_rule_partition(keys, lo, hi, pivot_key):
+    """The rule the register sort uses: every position decides from two stop counts.
+    A(x) = A-stops (key <= pivot) in [lo, x), B(x) = B-stops (key >= pivot) in (x, hi):
+    an A-stop is swapped iff B > A (takes B-stop number A from the right), a B-stop iff A > B;
+    cut = leftmost unswapped A-stop or swapped B-stop."""
+    k = keys[lo:hi].copy()
+    n = hi - lo
+    isA = k <= pivot_key
+    isB = k >= pivot_key
+    A = np.concatenate([[0], np.cumsum(isA)[:-1]])
+    B = np.concatenate([np.cumsum(isB[::-1])[::-1][1:], [0]])
+    swA = isA & (B > A)
+    swB = isB & ~swA & (A > B)
+    assert not (swA & swB).any()
+    xbuf = np.full(n + 1, -1, dtype=np.int64)
+    f = -1  # slots relative to f = lo - 1: A-stop a -> f + a (index a), B-stop b -> l - 1 - b
+    slot = np.full(n, -1)
+    slot[swA] = A[swA]
+    slot[swB] = (n - 1) - B[swB]
+    assert len(np.unique(slot[slot >= 0])) == (slot >= 0).sum()
+    xbuf[slot[slot >= 0]] = k[slot >= 0]
+    out = k.copy()
+    sw = slot >= 0
+    out[sw] = xbuf[(n - 1) - slot[sw]]
+    assert (out[sw] >= 0).all()
+    keys[lo:hi] = out
+    cand = np.where(isA, ~swA, swB)
+    return lo + int(np.argmax(cand)) if cand.any() else None
+
+
+def test_local_rule_equals_serial():
+    rng = np.random.default_rng(6)
+    for trial in range(4000):
+        n = int(rng.integers(17, 700))
+        levels = int(rng.integers(1, 17))
+        keys = rng.integers(0, levels, n).astype(np.int64)
+        if trial % 7 == 0:
+            keys.sort()
+        if trial % 11 == 0:
+            keys = keys[::-1].copy()
+        a = keys.copy()
+        median_to_first(a, 0, 1, n // 2, n - 1)
+        b = a.copy()
+        cut_s = serial_partition(a, 1, n, a[0])
+        cut_p = local_rule_partition(b, 1, n, b[0])
+        assert cut_s == cut_p, (trial, n, cut_s, cut_p)
+        assert (a == b).all(), trial

@@ -35,7 +35,7 @@ st = np.stack([b.debug_stamps(c) for c in (0, a.cells // 2, a.cells - 1)]).astyp
 tot = st.sum(1)
 print("greedy: RBGs assigned / TTI", st[:, 9] / a.ttis, " sorted position of the last assignment (mean)", st[:, 10] / a.ttis)
 print(f"launch {ms[0]:.3f} ms, {ms[0] * 1e3 / a.ttis:.2f} us/TTI/cell; cycles/TTI (thread 0): {tot / a.ttis}")
-SUB = ["sort F (pivot+ballots)", "sort barrier 1", "sort R (ranks)", "sort barrier 2", "sort S (swaps)", "sort barrier 3", "sort U (descend)", "sort levels (count)"]
+SUB = ["sort F (pivot+ballots)", "sort barrier 1", "sort R (counts, exchange)", "sort barrier 2", "sort S (receive, descend)", "sort barrier 3", "-", "sort levels (count)"]
 tot = st[:, :12].sum(1)
 for i, n in enumerate(SUB):
     print(f"    {n:26s} " + "  ".join(f"{st[c, 12 + i] / a.ttis:9.1f}" for c in range(3)))
