@@ -350,7 +350,9 @@ __device__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t
       if (active) {
         const int f = F[i], l = L[i];
         const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
-        const uint32_t s0 = v[f], sa = v[ia], sb = v[ib], sc = v[ic];
+        uint32_t s0 = v[f];
+        const uint32_t sa = v[ia], sb = v[ib], sc = v[ic];
+        asm volatile("" : "+v"(s0)); /* keep the four LDS reads in one batch (one latency, not two) */
         int pick;
         uint32_t sp;
         if (rs_sort::before(sa, sb)) {
@@ -401,9 +403,10 @@ __device__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t
       const int pc = __builtin_amdgcn_readlane(pre, c & 63);
       const int a = (pc & 0xffff) + __popcll(mAi[i] & lt_lane) - plo - __popcll(mlo & ((1ull << (lo & 63)) - 1ull));
       const int b = phi + __popcll(mhi & (~0ull >> (63 - (hm & 63)))) - (int)((unsigned)pc >> 16) - __popcll(mBi[i] & le_lane);
-      slot[i] = (isA[i] && b > a) ? F[i] + a : (isB[i] && a > b) ? hm - b : -1;
-      if (slot[i] >= 0) xbuf[slot[i]] = e[i];
-      const bool cand = isA[i] ? !(b > a) : (isB[i] && a > b);
+      const bool swA = isA[i] & (b > a), swB = isB[i] & (a > b); /* never both: b > a excludes a > b */
+      slot[i] = (swA | swB) ? (swA ? F[i] + a : hm - b) : -1;
+      if (swA | swB) xbuf[slot[i]] = e[i];
+      const bool cand = (isA[i] & !swA) | swB;
       /* leftmost candidate of its sub-range inside this chunk reports */
       const unsigned long long mC = __ballot(cand);
       const int lo_in = lo - (c << 6);
