@@ -960,25 +960,25 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         const int N = R * S;
         int left = lane < S ? m->quota[lane] : 0; /* lane s: quota[s] - granted[s] */
         int my_slice = -1;                        /* lane r: slice that got RBG r */
-        unsigned long long taken = 0;
         int assigned = 0;
         int scan_end = 0;
         for (int c0 = 0; c0 < N && assigned < R; c0 += 64) {
           const int i = c0 + lane;
           const uint32_t e = i < N ? s_sorted[i] : 0;
           const int rbg = (e >> 8) & 63, sl = e & 63;
-          int my_left = __shfl(left, sl, 64);
-          while (true) {
-            const bool ok = i < N && !((taken >> rbg) & 1ull) && my_left > 0;
-            const unsigned long long mk = __ballot(ok);
-            if (!mk) break;
-            const int f = __ffsll((long long)mk) - 1;
+          /* records of this chunk that can still be taken: RBG free and slice under quota */
+          /* (the two lane reads stay outside any branch: ds_bpermute returns 0 for a masked-off source lane) */
+          const int rbg_owner = __shfl(my_slice, rbg, 64), sl_left = __shfl(left, sl, 64);
+          unsigned long long live = __ballot((i < N) & (rbg_owner < 0) & (sl_left > 0));
+          while (live) {
+            const int f = __ffsll((long long)live) - 1;
             const int frbg = __builtin_amdgcn_readlane(rbg, f);
             const int fsl = __builtin_amdgcn_readlane(sl, f);
-            if (lane == frbg) my_slice = fsl;
-            if (sl == fsl) my_left--;
+            const int sleft = __builtin_amdgcn_readlane(left, fsl);
+            live &= ~__ballot(rbg == frbg); /* the RBG is gone (this drops record f too) */
+            if (sleft == 1) live &= ~__ballot(sl == fsl); /* the slice just used its last RBG */
             if (lane == fsl) left--;
-            taken |= 1ull << frbg;
+            if (lane == frbg) my_slice = fsl;
             assigned++;
             scan_end = c0 + f;
           }
