@@ -492,6 +492,62 @@ __device__ void counting_sort_desc(const uint32_t* v, uint32_t* out, int N, Misc
   __syncthreads();
 }
 
+/* The same stable counting sort when every wave owns at most CPW chunks (chunk j*nwaves + wave, like the
+ * register introsort): one ballot pass gives both the per-chunk counts and every element's rank among
+ * equal keys in its chunk; after one barrier every wave derives the output offsets of its own chunks
+ * from the count table (lane q = key q), so there is no single-wave step and no second barrier. */
+template <int CPW>
+__device__ void counting_sort_desc_owned(const uint32_t* v, uint32_t* out, int N, Misc* m) {
+  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
+  const int n_chunks = (N + 63) >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t e[CPW];
+  int rank[CPW];
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int c = j * nwaves + wave, i = (c << 6) + lane;
+    const bool valid = c < n_chunks && i < N;
+    e[j] = valid ? v[i] : 0u;
+    BitBallots<4> bb;
+    bb.gather((int)(e[j] >> 16), valid);
+    rank[j] = __popcll(bb.lanes_with((int)(e[j] >> 16)) & lt);
+    if (lane < 16 && c < n_chunks) m->hist[c * 16 + lane] = (uint16_t)__popcll(bb.lanes_with(lane));
+  }
+  __syncthreads();
+  int total = 0, below[CPW];
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) below[j] = 0;
+  if (lane < 16)
+    for (int c = 0; c < n_chunks; ++c) {
+      const int h = m->hist[c * 16 + lane];
+#pragma unroll
+      for (int j = 0; j < CPW; ++j) below[j] += c < j * nwaves + wave ? h : 0;
+      total += h;
+    }
+  /* elements with a larger key come first: lane q needs the sum of total over keys > q */
+  int inc = total;
+  {
+    int v_ = inc;
+    const int identity = 0;
+#define RS_ROW_STEP(ctrl, bmask) v_ = v_ + __builtin_amdgcn_update_dpp(identity, v_, ctrl, 0xf, bmask, false)
+    RS_ROW_STEP(0x111, 0xf);
+    RS_ROW_STEP(0x112, 0xf);
+    RS_ROW_STEP(0x114, 0xe);
+    RS_ROW_STEP(0x118, 0xc);
+#undef RS_ROW_STEP
+    inc = v_;
+  }
+  const int all = __builtin_amdgcn_readlane(inc, 15);
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int c = j * nwaves + wave, i = (c << 6) + lane;
+    const int base_q = all - inc + below[j]; /* lane q < 16 */
+    const int base = __builtin_amdgcn_ds_bpermute((int)(e[j] >> 16) << 2, base_q); /* every lane: no branch around it */
+    if (c < n_chunks && i < N) out[base + rank[j]] = e[j];
+  }
+  __syncthreads();
+}
+
 #ifndef RS_P3_BLOCK
 #define RS_P3_BLOCK 32 /* users ranked per stage-1 block (multiple of 8, <= 32) */
 #endif
@@ -928,7 +984,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       }
 #endif
       RS_STAMP(3);
-      counting_sort_desc(s_elems, s_sorted, N, m);
+      if constexpr (EPT > 0) counting_sort_desc_owned<EPT>(s_elems, s_sorted, N, m);
+      else counting_sort_desc(s_elems, s_sorted, N, m);
       RS_STAMP(4);
     }
     /* the rest of the TTI runs on wave 0: lanes = slices for the quota counters, lanes = RBGs for
