@@ -38,6 +38,7 @@ struct RsMisc {
   int32_t served;
   int32_t nvs_slice;
   int32_t pad[2];
+  float ones16[16];              /* numerator table of an epsilon = 0 slice (pow(x, 0) = 1) */
 };
 
 /* LDS carve of one cell (byte offsets from the dynamic LDS base), a pure function of the cell shape so

@@ -641,6 +641,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     s_num32[tid] = (float)(SCHED == 1 ? tab->pfnum[tid] : tab->kbps[tid]);
     m->mcs_of_cqi[tid] = tab->mcs_of_cqi[tid];
     m->itbs_of_cqi[tid] = tab->itbs_of_cqi[tid];
+    m->ones16[tid] = 1.0f;
   }
   if (tid < S) {
     s_w[tid] = p.weight[tid];
@@ -889,6 +890,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
          * the 32 products of a block in registers, takes their maximum, then marks the survivors. */
         const float kTol = 0x1.ffffcp-1f; /* 1 - 2^-19 */
         const bool one_num = SCHED != 1 && !sl_eps;
+        const float* numtab = one_num ? m->ones16 : s_num32; /* a table either way: no branch per user */
+        const unsigned seg_len = (unsigned)(ue - ub);
 #ifdef RS_EXP_P3_SKIP
         bu = ub; bkey = rowp[ub]; best = 1.0; /* timing experiment only: wrong results */
         for (int blk = ue; blk < ue; blk += RS_P3_BLOCK) {
@@ -909,12 +912,19 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               rb = *(const float4*)(s_rcp32 + u0 + 4);
             }
             const float rc[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+            const unsigned d0 = (unsigned)(u0 - ub); /* wraps to a huge value left of the segment */
+            float nm[8];
+            /* CQI bytes are <= 15, so four of them scale to table byte offsets with one shift and each address is
+             * one byte-select add */
+            const uint32_t cx4 = cw.x << 2, cy4 = cw.y << 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              nm[k] = *(const float*)((const char*)numtab + (((k < 4 ? cx4 : cy4) >> (8 * (k & 3))) & 0xffu));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(nm[k])); /* eight table reads in flight, none behind a branch */
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              const int u = u0 + k;
-              const uint32_t c = ((k < 4 ? cw.x : cw.y) >> (8 * (k & 3))) & 15u;
-              const float nm = one_num ? 1.0f : s_num32[c];
-              const float a = (u >= ub && u < ue) ? nm * rc[k] : 0.0f;
+              const float a = (d0 + (unsigned)k < seg_len) ? nm[k] * rc[k] : 0.0f;
               av[8 * g + k] = a;
               best_a = fmaxf(best_a, a);
             }
