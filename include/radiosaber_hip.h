@@ -185,6 +185,25 @@ int rs_batch_download_cqi_epochs(rs_batch* b, int32_t cell, uint8_t* h_cqi);
 int rs_batch_set_trace(rs_batch* b, const uint8_t* h_trace, int32_t n_traces, int32_t n_rows,
                        int32_t row_modulus, const int32_t* h_user_trace /* [n_cells][U] */);
 
+/* ---- the reference's CQI trace files (host side of source C; no GPU involved) ----------------------
+ * mapping<i>.config: lines "<user id> <trace id>"; user u replays trace map[u % n_entries]
+ *   (ref: src/protocolStack/mac/enb-mac-entity.cc:47-53 and :171).  Returns the number of entries read
+ *   (at most max_entries are stored), or a negative RS_ERR_*.
+ * ue<trace id>.log: one text line per 40-TTI report, nb_rbs space-separated CQI values per line taken from the
+ *   start of the line (ref: :173-186, MAX_TTI_TRACE = 475 lines).  rs_trace_read_ue_log parses the first n_rows
+ *   lines; out_prb (optional) = [n_rows][nb_rbs]; out_rbg (optional) = [n_rows][nb_rbs/rbg_size], the value of the
+ *   first PRB of every RBG -- what the metric reads (downlink-transport-scheduler.cpp:536).  Returns the number of
+ *   RBGs whose PRBs do NOT all carry the same value (0 for the shipped traces: then the RBG-granular replay of
+ *   rs_batch_set_trace is exact, otherwise use the per-PRB drop-in path), or a negative RS_ERR_*.
+ *   A line with fewer than nb_rbs values repeats the last value read, like the reference's extraction loop.
+ * rs_trace_load_dir reads ue0.log .. ue<n_traces-1>.log of one directory into out_rbg =
+ *   [n_traces][n_rows][nb_rbs/rbg_size] (the h_trace argument of rs_batch_set_trace); same return value. */
+int rs_trace_read_mapping(const char* path, int32_t* trace_of_entry, int32_t max_entries);
+int rs_trace_read_ue_log(const char* path, int32_t n_rows, int32_t nb_rbs, int32_t rbg_size, uint8_t* out_rbg,
+                         uint8_t* out_prb);
+int rs_trace_load_dir(const char* dir, int32_t n_traces, int32_t n_rows, int32_t nb_rbs, int32_t rbg_size,
+                      uint8_t* out_rbg);
+
 /* run n_ttis scheduled TTIs of every cell in ONE kernel launch on the batch's stream and wait */
 int rs_batch_run(rs_batch* b, int32_t n_ttis);
 /* same, not waiting (for overlap and hipEvent timing by the caller) */

@@ -72,6 +72,7 @@ ABI_SYMBOLS = [
     "rs_batch_run", "rs_batch_run_async", "rs_batch_sync", "rs_batch_run_logged",
     "rs_batch_run_timed", "rs_batch_read_state", "rs_batch_slice_bytes_device",
     "rs_batch_slice_bytes", "rs_jit_selfcheck", "rs_batch_debug_stamps", "rs_batch_ttis_done", "rs_batch_stream", "rs_batch_kernel_name",
+    "rs_trace_read_mapping", "rs_trace_read_ue_log", "rs_trace_load_dir",
 ]
 
 _lib = None
@@ -121,6 +122,10 @@ def lib():
     L.rs_batch_stream.argtypes = [C.c_void_p]
     L.rs_batch_kernel_name.restype = C.c_char_p
     L.rs_batch_kernel_name.argtypes = [C.c_void_p]
+    L.rs_trace_read_mapping.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_int32]
+    L.rs_trace_read_ue_log.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8),
+                                       C.POINTER(C.c_uint8)]
+    L.rs_trace_load_dir.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
     _lib = L
     return L
 
@@ -128,6 +133,13 @@ def lib():
 def _check(rc):
     if rc != 0:
         raise RadioSaberError(rc, lib().rs_last_error().decode())
+
+
+def _count(rc):
+    """calls that return a count (>= 0) or a negative RS_ERR_*"""
+    if rc < 0:
+        raise RadioSaberError(rc, lib().rs_last_error().decode())
+    return rc
 
 
 def _p(a, t):
@@ -152,6 +164,37 @@ def link_tables():
     out = [np.zeros(16, np.float64) for _ in range(4)]
     _check(lib().rs_link_tables(*[_p(a, C.c_double) for a in out]))
     return dict(zip(("eff", "kbps", "eesm_e", "eesm_x"), out))
+
+
+def read_trace_mapping(path, max_entries=4096):
+    """mapping<i>.config of the reference's cqi-traces-noise0 -> int32[n]: user u replays trace map[u % n]
+    (ref: enb-mac-entity.cc:47-53, :171)."""
+    out = np.zeros(max_entries, dtype=np.int32)
+    n = _count(lib().rs_trace_read_mapping(os.fsencode(str(path)), _p(out, C.c_int32), max_entries))
+    if n > max_entries:
+        raise RadioSaberError(-1, f"{path}: {n} entries, max_entries={max_entries}")
+    return out[:n].copy()
+
+
+def read_ue_trace(path, nb_rbs=512, rbg_size=8, n_rows=475, per_prb=False):
+    """One ue<id>.log -> (uint8[n_rows][nb_rbs/rbg_size], mixed) or, per_prb=True, (uint8[n_rows][nb_rbs], mixed);
+    `mixed` counts RBGs whose PRBs differ (0: the RBG-granular replay is exact).  ref: enb-mac-entity.cc:173-186."""
+    R = nb_rbs // rbg_size
+    rbg = np.zeros((n_rows, R), dtype=np.uint8)
+    prb = np.zeros((n_rows, nb_rbs), dtype=np.uint8) if per_prb else None
+    rc = _count(lib().rs_trace_read_ue_log(os.fsencode(str(path)), n_rows, nb_rbs, rbg_size, _p(rbg, C.c_uint8),
+                                           _p(prb, C.c_uint8) if per_prb else None))
+    return (prb if per_prb else rbg), rc
+
+
+def load_trace_dir(directory, n_traces=158, nb_rbs=512, rbg_size=8, n_rows=475):
+    """ue0.log .. ue<n_traces-1>.log -> (uint8[n_traces][n_rows][R], mixed): the `trace` argument of
+    BatchScheduler.set_trace (MAX_UE_TRACE = 158, MAX_TTI_TRACE = 475 in the reference)."""
+    R = nb_rbs // rbg_size
+    out = np.zeros((n_traces, n_rows, R), dtype=np.uint8)
+    rc = _count(lib().rs_trace_load_dir(os.fsencode(str(directory)), n_traces, n_rows, nb_rbs, rbg_size,
+                                        _p(out, C.c_uint8)))
+    return out, rc
 
 
 @dataclass

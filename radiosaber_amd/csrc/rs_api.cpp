@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <fstream>
 #include <vector>
 
 #include "../../include/radiosaber_hip.h"
@@ -838,6 +839,86 @@ int rs_set_slice_offset(rs_ctx* c, const double* offset) {
   HIP_TRY(hipStreamSynchronize(c->b->stream));
   HIP_TRY(hipMemcpy(c->b->d_sstate, offset, 8 * c->b->S, hipMemcpyHostToDevice));
   return RS_OK;
+}
+
+/* ---- the reference's CQI trace files (include/radiosaber_hip.h) ---- */
+
+int rs_trace_read_mapping(const char* path, int32_t* trace_of_entry, int32_t max_entries) {
+  if (!path || (!trace_of_entry && max_entries > 0)) return fail(RS_ERR_INVALID, "null argument");
+  std::ifstream ifs(path);
+  if (!ifs) return fail(RS_ERR_INVALID, "cannot open %s", path);
+  /* ref: enb-mac-entity.cc:50-53 -- `while (ifs >> uid >> tid) push_back(tid)`: the user id column is not used */
+  long long uid, tid;
+  int n = 0;
+  while (ifs >> uid >> tid) {
+    if (tid < 0 || tid > 0x7fffffff) return fail(RS_ERR_RANGE, "%s: trace id %lld out of range", path, tid);
+    if (n < max_entries) trace_of_entry[n] = (int32_t)tid;
+    n++;
+  }
+  if (n == 0) return fail(RS_ERR_INVALID, "%s: no \"<user> <trace>\" pairs", path);
+  return n;
+}
+
+int rs_trace_read_ue_log(const char* path, int32_t n_rows, int32_t nb_rbs, int32_t rbg_size, uint8_t* out_rbg,
+                         uint8_t* out_prb) {
+  if (!path) return fail(RS_ERR_INVALID, "null argument");
+  if (n_rows < 1 || nb_rbs < 1 || rbg_size < 1 || nb_rbs % rbg_size)
+    return fail(RS_ERR_INVALID, "n_rows=%d nb_rbs=%d rbg_size=%d", n_rows, nb_rbs, rbg_size);
+  std::ifstream ifs(path);
+  if (!ifs) return fail(RS_ERR_INVALID, "cannot open %s", path);
+  const int R = nb_rbs / rbg_size;
+  int mixed = 0;
+  int cqi = 0; /* ref: enb-mac-entity.cc:175 -- declared outside both loops: a failed extraction keeps the last value */
+  std::vector<int> row(nb_rbs);
+  for (int i = 0; i < n_rows; i++) {
+    std::string line;
+    std::getline(ifs, line);
+    const char* q = line.c_str();
+    bool failed = false; /* the istringstream's failbit: once set, every later `>>` leaves cqi alone */
+    for (int j = 0; j < nb_rbs; j++) {
+      if (!failed) {
+        while (*q == ' ' || *q == '\t' || *q == '\r' || *q == '\n' || *q == '\v' || *q == '\f') q++;
+        if (!*q) {
+          failed = true; /* end of line while skipping blanks: value untouched */
+        } else {
+          char* end = nullptr;
+          errno = 0;
+          long v = strtol(q, &end, 10);
+          if (end == q) { cqi = 0; failed = true; } /* not a number: C++11 num_get stores 0 and fails */
+          else {
+            if (errno == ERANGE || v < 0 || v > 255)
+              return fail(RS_ERR_RANGE, "%s: line %d value %d = %ld does not fit a CQI byte", path, i + 1, j + 1, v);
+            cqi = (int)v;
+            q = end;
+          }
+        }
+      }
+      row[j] = cqi;
+    }
+    for (int r = 0; r < R; r++) {
+      for (int k = 1; k < rbg_size; k++)
+        if (row[r * rbg_size + k] != row[r * rbg_size]) { mixed++; break; }
+      if (out_rbg) out_rbg[(size_t)i * R + r] = (uint8_t)row[r * rbg_size];
+    }
+    if (out_prb)
+      for (int j = 0; j < nb_rbs; j++) out_prb[(size_t)i * nb_rbs + j] = (uint8_t)row[j];
+  }
+  return mixed;
+}
+
+int rs_trace_load_dir(const char* dir, int32_t n_traces, int32_t n_rows, int32_t nb_rbs, int32_t rbg_size,
+                      uint8_t* out_rbg) {
+  if (!dir || !out_rbg) return fail(RS_ERR_INVALID, "null argument");
+  if (n_traces < 1 || rbg_size < 1 || nb_rbs < 1 || nb_rbs % rbg_size) return fail(RS_ERR_INVALID, "bad trace shape");
+  const size_t per = (size_t)n_rows * (nb_rbs / rbg_size);
+  long long mixed = 0;
+  for (int t = 0; t < n_traces; t++) {
+    std::string f = std::string(dir) + "/ue" + std::to_string(t) + ".log"; /* ref: enb-mac-entity.cc:172 */
+    int rc = rs_trace_read_ue_log(f.c_str(), n_rows, nb_rbs, rbg_size, out_rbg + (size_t)t * per, nullptr);
+    if (rc < 0) return rc;
+    mixed += rc;
+  }
+  return mixed > 0x7fffffff ? 0x7fffffff : (int)mixed;
 }
 
 }  // extern "C"
