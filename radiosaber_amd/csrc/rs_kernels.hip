@@ -1085,7 +1085,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 
       /* ---------------- P5: link adaptation + DoStopSchedule counters (lanes = RBGs) ---------------- */
       /* lanes holding the same user; the lowest one (leader) handles the user */
-      BitBallots<11> ob;
+      /* owner + 1 <= U <= 2047; a shape-specialised build knows how many bits that takes */
+      constexpr int kOwnerBits = !FIXED ? 11 : RS_JIT_U < 63 ? 6 : RS_JIT_U < 127 ? 7 : RS_JIT_U < 255 ? 8
+                                 : RS_JIT_U < 511 ? 9 : RS_JIT_U < 1023 ? 10 : 11;
+      BitBallots<kOwnerBits> ob;
       ob.gather(owner + 1, lane < R && owner >= 0);
       const unsigned long long same = owner >= 0 ? ob.lanes_with(owner + 1) : 0ull;
       const bool leader = owner >= 0 && (same & ((1ull << lane) - 1ull)) == 0;
