@@ -667,6 +667,9 @@ struct rs_ctx {
    *   out: [ tbs i32[U] | uinfo i32[U] | map i16[R] | quota i16[S] | target i16[S] ] */
   uint8_t *h_in = nullptr, *d_in = nullptr, *h_out = nullptr, *d_out = nullptr;
   size_t in_bytes = 0, out_bytes = 0;
+  /* zero-copy: the kernel reads the pinned input block and writes the pinned output block itself (a few KB over the host
+   * link inside one launch) instead of two hipMemcpyAsync around it; RS_DROPIN_COPY=1 restores the copies */
+  uint8_t *z_in = nullptr, *z_out = nullptr; /* device-side addresses of h_in / h_out; null: copy path */
 };
 
 namespace {
@@ -710,8 +713,16 @@ rs_ctx* rs_create(const rs_config* cfg) {
   c->in_bytes = l.in_total;
   c->out_bytes = l.out_total;
   bool ok = hipMalloc(&c->d_in, c->in_bytes) == hipSuccess && hipMalloc(&c->d_out, c->out_bytes) == hipSuccess &&
-            hipHostMalloc((void**)&c->h_in, c->in_bytes, hipHostMallocDefault) == hipSuccess &&
-            hipHostMalloc((void**)&c->h_out, c->out_bytes, hipHostMallocDefault) == hipSuccess;
+            hipHostMalloc((void**)&c->h_in, c->in_bytes, hipHostMallocMapped) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_out, c->out_bytes, hipHostMallocMapped) == hipSuccess;
+  const char* force_copy = getenv("RS_DROPIN_COPY");
+  if (ok && !(force_copy && force_copy[0] == '1')) {
+    void *zi = nullptr, *zo = nullptr;
+    if (hipHostGetDevicePointer(&zi, c->h_in, 0) == hipSuccess && hipHostGetDevicePointer(&zo, c->h_out, 0) == hipSuccess) {
+      c->z_in = (uint8_t*)zi;
+      c->z_out = (uint8_t*)zo;
+    }
+  }
   if (!ok) { fail(RS_ERR_HIP, "allocation of the staging blocks failed"); rs_destroy(c); return nullptr; }
   return c;
 }
@@ -775,7 +786,11 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
     else memset(c->h_in + l.prio, 1, (size_t)n);
   }
   hipStream_t st = b->stream;
-  HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, st));
+  /* per-PRB reports and queue state are read again and again inside the TTI: those calls keep the device copies */
+  const bool zc = c->z_in != nullptr && !in->cqi_prb && !b->any_alpha;
+  uint8_t* const dev_in = zc ? c->z_in : c->d_in;
+  uint8_t* const dev_out = zc ? c->z_out : c->d_out;
+  if (!zc) HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, st));
   RsLaunch L = b->base;
   L.U = n;
   L.Upad = upad_of(n);
@@ -785,24 +800,24 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   L.rand1 = in->rand1;
   L.cqi_mode = RS_CQI_EPOCHS;
   L.refresh = 1;
-  L.epochs = c->d_in + l.grid;
+  L.epochs = dev_in + l.grid;
   L.grid_stride = (int64_t)l.slice;
   L.n_epochs = 1;
-  L.user_slice = c->d_in + l.slice;
-  L.avg = (double*)(c->d_in + l.avg);
-  L.prb_cqi = in->cqi_prb ? c->d_in + l.prb : nullptr;
+  L.user_slice = dev_in + l.slice;
+  L.avg = (double*)(dev_in + l.avg);
+  L.prb_cqi = in->cqi_prb ? dev_in + l.prb : nullptr;
   L.queue_mode = b->any_alpha ? 1 : 0;
-  L.hol = (const double*)(c->d_in + l.hol);
-  L.prio = c->d_in + l.prio;
+  L.hol = (const double*)(dev_in + l.hol);
+  L.prio = dev_in + l.prio;
   if (b->sched == RS_SCHED_PF) { L.n_seg = (n + RS_PF_SEG - 1) / RS_PF_SEG; L.n_items = R * L.n_seg; }
-  L.log_tbs = (int32_t*)(c->d_out + l.tbs);
-  L.log_uinfo = (int32_t*)(c->d_out + l.uinfo);
-  L.log_map = (int16_t*)(c->d_out + l.map);
-  L.log_quota = (int16_t*)(c->d_out + l.quota);
-  L.log_target = (int16_t*)(c->d_out + l.target);
+  L.log_tbs = (int32_t*)(dev_out + l.tbs);
+  L.log_uinfo = (int32_t*)(dev_out + l.uinfo);
+  L.log_map = (int16_t*)(dev_out + l.map);
+  L.log_quota = (int16_t*)(dev_out + l.quota);
+  L.log_target = (int16_t*)(dev_out + l.target);
   /* direct mode: the kernel clears its per-user outputs itself and reads the single grid on every call */
   HIP_TRY(rs_launch_cells(&L, b->threads, st));
-  HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, l.out_total, hipMemcpyDeviceToHost, st));
+  if (!zc) HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, l.out_total, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   const int16_t* h_map = (const int16_t*)(c->h_out + l.map);
   const int16_t* h_quota = (const int16_t*)(c->h_out + l.quota);
