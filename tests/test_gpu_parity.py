@@ -417,3 +417,24 @@ def test_drop_in_customised_slices(rs, oracle, sched):
         ts.schedule_tti(cqi[ids], avg[ids], 1, 2, user_id=ids)
     assert "hol_delay" in str(e.value)
     ts.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_shapes_all_schedulers(rs, oracle, seed):
+    """Randomised cell shapes (ragged slices, empty slices, random weights, every workgroup size class and with it every
+    register/LDS variant of the sort), built-in and shape-specialised kernels, bit-exact against the oracle."""
+    rng = np.random.default_rng(seed)
+    for trial in range(6):
+        S = int(rng.integers(1, 24))
+        ues = [int(x) for x in rng.integers(0, 14, S)]
+        if sum(ues) == 0:
+            ues[0] = 3
+        R, G = [(25, 4), (64, 8), (12, 2), (50, 2), (17, 3), (33, 3)][int(rng.integers(0, 6))]
+        w = rng.uniform(0.2, 1.0, S)
+        w = [float(x) for x in w / w.sum()]
+        sched = [9, 9, 9, 8, 7, 1][int(rng.integers(0, 6))]
+        threads = [0, 64, 128, 256, 512][int(rng.integers(0, 5))]
+        psi = [int(x) for x in rng.integers(0, 2, S)] if sched != 1 else None
+        eps = [1] * S if sched != 1 else None
+        _check_batch(rs, oracle, sched, ues, R, G, n_cells=2, n_ttis=int(rng.integers(41, 90)), threads=threads,
+                     eps=eps, psi=psi, seed=seed * 100 + trial, weights=w, jit=bool(trial % 2), phy=int(rng.integers(0, 2)))
