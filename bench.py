@@ -193,6 +193,11 @@ def main():
             tj = json.loads(tfile.read_text())
             key = f"sched{args.sched}_S{S}_U{U}_R{R}_cells{args.cells}_ttis{args.ttis}"
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        try:  # attainable HBM rate of this GPU (16 B/lane streaming copy, 1 GiB each way), beside the spec peak
+            copy_gbs = rs.hbm_copy_probe(local_rank, 1 << 30, 10)
+        except Exception as e:  # measurement nicety only
+            print(f"hbm_copy_probe failed: {e}", file=sys.stderr)
+            copy_gbs = None
         line = {
             "metric": "scheduled TTIs/sec (and us/TTI) at 20 slices x 500 UEs x 25 RBGs; HBM GB/s",
             "value": value, "unit": "TTIs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,7 +215,7 @@ def main():
             "total_slice_bytes": total_bytes,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_cell_tti": b_tti},
+                         "algorithmic_bytes_per_cell_tti": b_tti, "measured_copy_gbs": copy_gbs},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, slices, seeds)

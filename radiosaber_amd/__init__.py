@@ -6,11 +6,12 @@ built library, raises.
 """
 from .api import (  # noqa: F401
     RS_SCHED_MAXCELL, RS_SCHED_NVS, RS_SCHED_PF, RS_SCHED_SEQUENTIAL, TRACE_CQI_HISTOGRAM,
-    BatchScheduler, RadioSaberError, SliceConfig, TtiResult, TtiScheduler, device_count, jit_selfcheck, lib,
+    BatchScheduler, RadioSaberError, SliceConfig, TtiResult, TtiScheduler, device_count, hbm_copy_probe, jit_selfcheck,
+    lib,
     link_tables, load_trace_dir, read_trace_mapping, read_ue_trace,
 )
 
 __all__ = ["RS_SCHED_PF", "RS_SCHED_NVS", "RS_SCHED_SEQUENTIAL", "RS_SCHED_MAXCELL", "SliceConfig",
            "TtiScheduler", "TtiResult", "BatchScheduler", "RadioSaberError", "device_count", "lib",
            "link_tables", "jit_selfcheck", "TRACE_CQI_HISTOGRAM", "read_trace_mapping", "read_ue_trace",
-           "load_trace_dir"]
+           "load_trace_dir", "hbm_copy_probe"]

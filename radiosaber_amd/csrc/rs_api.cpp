@@ -31,6 +31,7 @@ extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int N
 extern "C" hipError_t rs_jit_launch(RsJitKernel* k, const RsLaunch* p, hipStream_t stream);
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,
                                       uint64_t seed, const uint32_t* cdf16, hipStream_t stream);
+extern "C" hipError_t rs_launch_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t stream);
 extern "C" hipError_t rs_launch_slice_bytes(const int64_t* cum_bytes, const uint8_t* user_slice, int n_cells, int U,
                                             int S, unsigned long long* d_out, hipStream_t stream);
 
@@ -934,6 +935,40 @@ int rs_trace_load_dir(const char* dir, int32_t n_traces, int32_t n_rows, int32_t
     mixed += rc;
   }
   return mixed > 0x7fffffff ? 0x7fffffff : (int)mixed;
+}
+
+/* ---- measurement helper ---- */
+int rs_hbm_copy_probe(int device, uint64_t bytes, int iters, double* copy_gbs) {
+  if (!copy_gbs || iters < 1 || bytes < (1u << 20) || (bytes & 15)) return fail(RS_ERR_INVALID, "bad probe arguments");
+  HIP_TRY(hipSetDevice(device));
+  void *src = nullptr, *dst = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = RS_OK;
+  float ms = 0;
+#define PROBE_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = fail(RS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
+  PROBE_TRY(hipMalloc(&src, bytes));
+  PROBE_TRY(hipMalloc(&dst, bytes));
+  PROBE_TRY(hipMemset(src, 1, bytes));
+  PROBE_TRY(hipEventCreate(&e0));
+  PROBE_TRY(hipEventCreate(&e1));
+  PROBE_TRY(rs_launch_copy_probe(src, dst, bytes, nullptr)); /* warm-up */
+  *copy_gbs = 0;
+  for (int trial = 0; trial < 3; trial++) { /* best of three: the rate wanders by 10-15 % between trials */
+    PROBE_TRY(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; i++) PROBE_TRY(rs_launch_copy_probe(src, dst, bytes, nullptr));
+    PROBE_TRY(hipEventRecord(e1, nullptr));
+    PROBE_TRY(hipEventSynchronize(e1));
+    PROBE_TRY(hipEventElapsedTime(&ms, e0, e1));
+    const double g = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9; /* bytes read + bytes written */
+    if (g > *copy_gbs) *copy_gbs = g;
+  }
+done:
+#undef PROBE_TRY
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (src) (void)hipFree(src);
+  if (dst) (void)hipFree(dst);
+  return rc;
 }
 
 }  // extern "C"

@@ -1248,6 +1248,13 @@ __global__ void rs_synth_cqi_kernel(uint8_t* epochs, int64_t grid_stride, int n_
   }
 }
 
+/* measurement only: 16 bytes per lane streaming copy, to quote the attainable HBM rate next to the 8 TB/s spec
+ * (SURVEY 8d).  Grid-stride so that a launch of a few workgroups per CU covers any size. */
+__global__ void __launch_bounds__(256) rs_copy_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
 /* per-slice cumulative bytes over all cells -> d_out[S] (uint64) */
 __global__ void rs_slice_bytes_kernel(const int64_t* cum_bytes, const uint8_t* user_slice, int n_cells, int U,
                                       int S, unsigned long long* d_out) {
@@ -1318,6 +1325,11 @@ extern "C" hipError_t rs_launch_slice_bytes(const int64_t* cum_bytes, const uint
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(rs_slice_bytes_kernel, dim3(blocks), dim3(256), 0, stream, cum_bytes, user_slice, n_cells, U, S,
                      d_out);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t rs_launch_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t stream) {
+  hipLaunchKernelGGL(rs_copy_probe_kernel, dim3(256 * 4), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, bytes >> 4);
   return hipGetLastError();
 }
 
