@@ -438,3 +438,14 @@ def test_random_shapes_all_schedulers(rs, oracle, seed):
         eps = [1] * S if sched != 1 else None
         _check_batch(rs, oracle, sched, ues, R, G, n_cells=2, n_ttis=int(rng.integers(41, 90)), threads=threads,
                      eps=eps, psi=psi, seed=seed * 100 + trial, weights=w, jit=bool(trial % 2), phy=int(rng.integers(0, 2)))
+
+
+def test_maximum_sizes(rs, oracle):
+    """The limits of the ABI: 64 slices x 64 RBGs (4 096 sort records: the any-size LDS form of the sort),
+    1 024 UEs, and both at once as far as 160 KiB of LDS allow."""
+    _check_batch(rs, oracle, 9, [2] * 64, 64, 8, n_cells=2, n_ttis=45)            # R*S = 4096, U = 128
+    _check_batch(rs, oracle, 9, [2] * 64, 64, 8, n_cells=1, n_ttis=45, jit=True)
+    _check_batch(rs, oracle, 9, [16] * 64, 25, 4, n_cells=1, n_ttis=45)           # U = 1024 (RS_MAX_USERS), S = 64
+    _check_batch(rs, oracle, 8, [512, 512], 64, 8, n_cells=1, n_ttis=45)          # U = 1024 x 64 RBGs
+    _check_batch(rs, oracle, 1, [512, 512], 64, 8, n_cells=1, n_ttis=45)
+    _check_batch(rs, oracle, 7, [1024], 64, 8, n_cells=1, n_ttis=45)
