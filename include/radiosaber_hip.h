@@ -44,7 +44,9 @@ enum {
                               (ref: downlink-packet-scheduler.cpp:179-331, dl-pf-packet-scheduler.cpp:128-140) */
   RS_SCHED_NVS = 7,        /* DownlinkNVSScheduler (ref: downlink-nvs-scheduler.cpp:94-142,275-358) */
   RS_SCHED_SEQUENTIAL = 8, /* DownlinkTransportScheduler + GreedyByRow (ref: downlink-transport-scheduler.cpp:249-272) */
-  RS_SCHED_MAXCELL = 9     /* DownlinkTransportScheduler + MaximizeCell = RadioSaber (ref: :351-376) */
+  RS_SCHED_MAXCELL = 9,    /* DownlinkTransportScheduler + MaximizeCell = RadioSaber (ref: :351-376) */
+  RS_SCHED_VOGEL = 103     /* DownlinkTransportScheduler + VogelApproximate (ref: :378-451; inter_sched_ = 3, which no CLI
+                              scheduler number of the reference selects -- ENodeB::DLScheduler_VOGEL exists, ENodeB.cpp:375) */
 };
 
 #define RS_MAX_SLICES 64

@@ -204,7 +204,8 @@ int validate(const rs_config* c, bool direct) {
   if (c->n_rbgs < 1 || c->n_rbgs > RS_MAX_RBGS) return fail(RS_ERR_INVALID, "n_rbgs %d outside 1..%d", c->n_rbgs, RS_MAX_RBGS);
   if (c->rbg_size < 1 || c->rbg_size > 8) return fail(RS_ERR_INVALID, "rbg_size %d outside 1..8", c->rbg_size);
   if (c->n_rbgs * c->rbg_size > 512) return fail(RS_ERR_INVALID, "more than 512 PRBs (reference get_rbg_size throws)");
-  if (c->sched != RS_SCHED_PF && c->sched != RS_SCHED_NVS && c->sched != RS_SCHED_SEQUENTIAL && c->sched != RS_SCHED_MAXCELL)
+  if (c->sched != RS_SCHED_PF && c->sched != RS_SCHED_NVS && c->sched != RS_SCHED_SEQUENTIAL && c->sched != RS_SCHED_MAXCELL &&
+      c->sched != RS_SCHED_VOGEL)
     return fail(RS_ERR_INVALID, "sched %d not supported (1, 7, 8, 9)", c->sched);
   if (!c->slice_weight || !c->algo_alpha || !c->algo_epsilon || !c->algo_psi || !c->user_to_slice)
     return fail(RS_ERR_INVALID, "null slice/user array");
@@ -274,6 +275,7 @@ int batch_alloc(rs_batch* b) {
   if (rc) return rc;
   for (int c = 1; c <= 15; c++) {
     t.pfnum[c] = eff[c] * 180000.; /* dl-pf-packet-scheduler.cpp:138 */
+    t.eff[c] = eff[c];
     t.mcs_of_cqi[c] = kCqiToMcs[c - 1];
     t.itbs_of_cqi[c] = kMcsToItbs[kCqiToMcs[c - 1]];
   }
@@ -649,6 +651,7 @@ const char* rs_batch_kernel_name(rs_batch* b) {
     case 1: return "rs_cell_kernel<1, 0>";
     case 7: return "rs_cell_kernel<7, 0>";
     case 8: return "rs_cell_kernel<8, 0>";
+    case RS_SCHED_VOGEL: return "rs_cell_kernel<103, 0>";
     default: {
       const int ept = (b->R * b->S + b->threads - 1) / b->threads;
       return ept <= 1 ? "rs_cell_kernel<9, 1>" : ept <= 2 ? "rs_cell_kernel<9, 2>" : ept <= 3 ? "rs_cell_kernel<9, 3>" : ept <= 4 ? "rs_cell_kernel<9, 4>" : "rs_cell_kernel<9, 0>";

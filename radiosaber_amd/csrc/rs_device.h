@@ -39,6 +39,7 @@ struct RsMisc {
   int32_t nvs_slice;
   int32_t pad[2];
   float ones16[16];              /* numerator table of an epsilon = 0 slice (pow(x, 0) = 1) */
+  double eff16[16];              /* Vogel: flow_spectraleff of a key (key 0 = empty slice = 0.0) */
 };
 
 /* LDS carve of one cell (byte offsets from the dynamic LDS base), a pure function of the cell shape so
@@ -82,6 +83,7 @@ constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads) {
 struct RsTables {
   double kbps[16];   /* metric numerator of sched 7/8/9: eff*180000/1000              */
   double pfnum[16];  /* metric numerator of sched 1: eff*180000.                      */
+  double eff[16];    /* spectral efficiency of a CQI (0 for "no user"): VogelApproximate's differences */
   double eesm_e[16]; /* E[c] = exp(-10^(SINR[c]/10))                                  */
   double eesm_x[16]; /* decision thresholds X[1..13]                                  */
   int32_t mcs_of_cqi[16];

@@ -289,6 +289,18 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
   return v;
 }
 
+/* inclusive wave64 prefix maximum */
+__device__ __forceinline__ int wave_scan_max_incl(int v) {
+  const int identity = (int)0x80000000;
+  RS_DPP_STEP(op_max, 0x111, 0xf, 0xf);
+  RS_DPP_STEP(op_max, 0x112, 0xf, 0xf);
+  RS_DPP_STEP(op_max, 0x114, 0xf, 0xe);
+  RS_DPP_STEP(op_max, 0x118, 0xf, 0xc);
+  RS_DPP_STEP(op_max, 0x142, 0xa, 0xf);
+  RS_DPP_STEP(op_max, 0x143, 0xc, 0xf);
+  return v;
+}
+
 /*
  * One std::__unguarded_partition per live sub-range and level, decided locally from stop counts.
  * In [lo, hi) = (f, l) with pivot key pk, an A-stop is an element with key <= pk (where the upward scan
@@ -597,7 +609,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
                               kCv.n_seg, kCv.n_items}
                        : Offs{p.off_avgk, p.off_rcp, p.off_tab, p.off_slice, p.off_tx, p.off_misc, p.off_tbs, p.off_elems,
                               p.off_sorted, p.off_items, p.off_sortx, p.off_cqi, p.Upad, p.n_seg, p.n_items};
-  constexpr bool kTransport = (SCHED == 8 || SCHED == 9);
+  constexpr bool kTransport = (SCHED == 8 || SCHED == 9 || SCHED == 103);
   const int quota_wave = nwaves - 1; /* P2 runs on the last wave, beside the other waves' P3 */
 
   double* s_avg = (double*)lds;
@@ -642,6 +654,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     m->mcs_of_cqi[tid] = tab->mcs_of_cqi[tid];
     m->itbs_of_cqi[tid] = tab->itbs_of_cqi[tid];
     m->ones16[tid] = 1.0f;
+    m->eff16[tid] = tab->eff[tid];
   }
   if (tid < S) {
     s_w[tid] = p.weight[tid];
@@ -1064,6 +1077,93 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           int u = s_best_user[my_slice * R + lane];
           owner = u == 0xFFFF ? -1 : u;
         }
+      } else if (SCHED == 103) {
+        /* VogelApproximate, ref: downlink-transport-scheduler.cpp:378-451.  R rounds; in each one every free RBG (lanes = RBGs)
+         * looks for its best and "second" slice among the slices under quota, every such slice (lanes = slices) for its best and
+         * "second" free RBG, and the candidate with the largest difference gets assigned.  Three details of the reference are
+         * kept: (1) a new best does not demote the old best to second -- second is the largest value that was not a new best
+         * when it was met; (2) `max_diff` is an int: a candidate wins when its (double) difference exceeds the TRUNCATED
+         * running maximum, so the LAST candidate above the running truncated maximum wins, horizontal candidates (RBG
+         * ascending) before vertical ones (slice ascending); (3) comparisons are on efficiencies, which are strictly
+         * increasing in the CQI key (0 = no user), so keys are compared and only the differences use the doubles. */
+        const int quota = lane < S ? m->quota[lane] : 0;
+        int my_slice = -1; /* lane r: slice that got RBG r */
+        for (int round = 0; round < R; ++round) {
+          const unsigned long long elig = __ballot(lane < S && got < quota);
+          const unsigned long long freeb = __ballot(lane < R && my_slice < 0);
+          /* horizontal search: lane j = free RBG j, slices ascending (four LDS reads in flight per step) */
+          int h1 = -1, h2 = -1, hs = -1;
+          {
+            const uint32_t* row = s_elems + (lane < R ? lane : 0) * S;
+            for (int k0 = 0; k0 < S; k0 += 4) {
+              uint32_t e4[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) e4[q] = row[k0 + q < S ? k0 + q : S - 1];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int k = k0 + q;
+                if (k < S && ((elig >> k) & 1ull)) {
+                  const int key = (int)(e4[q] >> 16);
+                  if (h1 < 0 || key > h1) { hs = k; h1 = key; }
+                  else if (h2 < 0 || key > h2) h2 = key;
+                }
+              }
+            }
+          }
+          /* vertical search: lane k = slice k under quota, free RBGs ascending */
+          int v1 = -1, v2 = -1, vr = -1;
+          {
+            const uint32_t* col = s_elems + (lane < S ? lane : 0);
+            for (int j0 = 0; j0 < R; j0 += 4) {
+              uint32_t e4[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) e4[q] = col[(j0 + q < R ? j0 + q : R - 1) * S];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int j = j0 + q;
+                if (j < R && ((freeb >> j) & 1ull)) {
+                  const int key = (int)(e4[q] >> 16);
+                  if (v1 < 0 || key > v1) { vr = j; v1 = key; }
+                  else if (v2 < 0 || key > v2) v2 = key;
+                }
+              }
+            }
+          }
+          const bool hpart = (freeb >> lane) & 1ull, vpart = (elig >> lane) & 1ull;
+          const double hd = (h1 < 0 ? -1.0 : m->eff16[h1]) - (h2 < 0 ? -1.0 : m->eff16[h2]);
+          const double vd = (v1 < 0 ? -1.0 : m->eff16[v1]) - (v2 < 0 ? -1.0 : m->eff16[v2]);
+          /* running truncated maximum before each candidate (-1 at the start), candidates in the reference's order */
+          const int ht = hpart ? (int)hd : -1, vt = vpart ? (int)vd : -1;
+          const int hinc = wave_scan_max_incl(ht);
+          int hexc = __shfl_up(hinc, 1, 64);
+          if (lane == 0) hexc = -1;
+          const int hall = __builtin_amdgcn_readlane(hinc, 63);
+          const int vinc = wave_scan_max_incl(vt);
+          int vexc = __shfl_up(vinc, 1, 64);
+          if (lane == 0) vexc = -1;
+          if (vexc < hall) vexc = hall;
+          if (hexc < -1) hexc = -1;
+          if (vexc < -1) vexc = -1;
+          const unsigned long long hacc = __ballot(hpart && hd > (double)hexc);
+          const unsigned long long vacc = __ballot(vpart && vd > (double)vexc);
+          int pick_rbg = -1, pick_slice = -1;
+          if (vacc) {
+            const int k = 63 - __clzll((long long)vacc);
+            pick_slice = k;
+            pick_rbg = __builtin_amdgcn_readlane(vr, k);
+          } else if (hacc) {
+            const int j = 63 - __clzll((long long)hacc);
+            pick_rbg = j;
+            pick_slice = __builtin_amdgcn_readlane(hs, j);
+          }
+          if (pick_rbg < 0 || pick_slice < 0) break; /* reference: uninitialised coordinates (undefined behaviour) */
+          if (lane == pick_rbg) my_slice = pick_slice;
+          if (lane == pick_slice) got++;
+        }
+        if (lane < R && my_slice >= 0) {
+          int u = s_best_user[my_slice * R + lane];
+          owner = u == 0xFFFF ? -1 : u;
+        }
       } else if (SCHED == 1) {
         /* ref: downlink-packet-scheduler.cpp:221-237 -- per RBG the first maximum over all flows,
          * here over the segment winners in ascending segment order */
@@ -1280,6 +1380,7 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
     case 1: hipLaunchKernelGGL((rs_cell_kernel<1, 0>), grid, block, p->lds_bytes, stream, *p); break;
     case 7: hipLaunchKernelGGL((rs_cell_kernel<7, 0>), grid, block, p->lds_bytes, stream, *p); break;
     case 8: hipLaunchKernelGGL((rs_cell_kernel<8, 0>), grid, block, p->lds_bytes, stream, *p); break;
+    case 103: hipLaunchKernelGGL((rs_cell_kernel<103, 0>), grid, block, p->lds_bytes, stream, *p); break;
     case 9:
       if (ept <= 1) hipLaunchKernelGGL((rs_cell_kernel<9, 1>), grid, block, p->lds_bytes, stream, *p);
       else if (ept <= 2) hipLaunchKernelGGL((rs_cell_kernel<9, 2>), grid, block, p->lds_bytes, stream, *p);
@@ -1293,7 +1394,7 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
 }
 
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes) {
-  const void* fns[] = {(const void*)rs_cell_kernel<1, 0>, (const void*)rs_cell_kernel<7, 0>, (const void*)rs_cell_kernel<8, 0>,
+  const void* fns[] = {(const void*)rs_cell_kernel<1, 0>, (const void*)rs_cell_kernel<7, 0>, (const void*)rs_cell_kernel<8, 0>, (const void*)rs_cell_kernel<103, 0>,
                        (const void*)rs_cell_kernel<9, 0>, (const void*)rs_cell_kernel<9, 1>, (const void*)rs_cell_kernel<9, 2>, (const void*)rs_cell_kernel<9, 3>,
                        (const void*)rs_cell_kernel<9, 4>};
   for (const void* f : fns) {

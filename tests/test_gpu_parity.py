@@ -223,7 +223,7 @@ def test_device_synth_grids_in_range_and_runs(rs, oracle):
     b.close()
 
 
-@pytest.mark.parametrize("sched", [9, 8, 1, 7])
+@pytest.mark.parametrize("sched", [9, 8, 1, 7, 103])
 def test_drop_in_single_tti(rs, oracle, sched):
     """rs_schedule_tti == RBsAllocation() of the oracle, carrying slice_rbs_offset_ across calls."""
     ues, R, G = [5] * 20, 64, 8
@@ -432,7 +432,7 @@ def test_random_shapes_all_schedulers(rs, oracle, seed):
         R, G = [(25, 4), (64, 8), (12, 2), (50, 2), (17, 3), (33, 3)][int(rng.integers(0, 6))]
         w = rng.uniform(0.2, 1.0, S)
         w = [float(x) for x in w / w.sum()]
-        sched = [9, 9, 9, 8, 7, 1][int(rng.integers(0, 6))]
+        sched = [9, 9, 9, 8, 7, 1, 103][int(rng.integers(0, 7))]
         threads = [0, 64, 128, 256, 512][int(rng.integers(0, 5))]
         psi = [int(x) for x in rng.integers(0, 2, S)] if sched != 1 else None
         eps = [1] * S if sched != 1 else None
@@ -449,3 +449,15 @@ def test_maximum_sizes(rs, oracle):
     _check_batch(rs, oracle, 8, [512, 512], 64, 8, n_cells=1, n_ttis=45)          # U = 1024 x 64 RBGs
     _check_batch(rs, oracle, 1, [512, 512], 64, 8, n_cells=1, n_ttis=45)
     _check_batch(rs, oracle, 7, [1024], 64, 8, n_cells=1, n_ttis=45)
+
+
+def test_vogel_policy_on_the_device(rs, oracle):
+    """N4: VogelApproximate (ref: downlink-transport-scheduler.cpp:378-451).  The oracle's Vogel is pinned against the
+    reference's own unit code (tests/test_oracle_pins.py); here the device against the oracle, whole TTI loops."""
+    _check_batch(rs, oracle, 103, [5] * 20, 25, 4, n_cells=3, n_ttis=90)
+    _check_batch(rs, oracle, 103, [5] * 20, 64, 8, n_cells=2, n_ttis=50)
+    _check_batch(rs, oracle, 103, [3, 7, 0, 1, 12], 25, 4, n_cells=2, n_ttis=50)                 # ragged, one empty slice
+    _check_batch(rs, oracle, 103, [10] * 5, 25, 4, n_cells=2, n_ttis=90, weights=[0.62, 0.3, 0.05, 0.02, 0.01])
+    _check_batch(rs, oracle, 103, [2] * 64, 33, 3, n_cells=1, n_ttis=45, jit=True)                # 64 slices
+    _check_batch(rs, oracle, 103, [25] * 20, 25, 4, n_cells=1, n_ttis=45, jit=True)
+
