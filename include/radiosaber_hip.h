@@ -45,6 +45,10 @@ enum {
   RS_SCHED_NVS = 7,        /* DownlinkNVSScheduler (ref: downlink-nvs-scheduler.cpp:94-142,275-358) */
   RS_SCHED_SEQUENTIAL = 8, /* DownlinkTransportScheduler + GreedyByRow (ref: downlink-transport-scheduler.cpp:249-272) */
   RS_SCHED_MAXCELL = 9,    /* DownlinkTransportScheduler + MaximizeCell = RadioSaber (ref: :351-376) */
+  RS_SCHED_UPPERBOUND = 10, /* DownlinkTransportScheduler + UpperBound (ref: :223-246, apply step :603-616): every slice takes
+                              its own best quota RBGs whatever the others take -- an upper bound, not an allocation: several
+                              UEs may hold one RBG.  rbg_to_user then reports the UE of the lowest-numbered slice holding
+                              the RBG; user_nprb / user_tbs_bits / ... are complete.  Needs n_rbgs*n_slices <= 2048. */
   RS_SCHED_VOGEL = 103     /* DownlinkTransportScheduler + VogelApproximate (ref: :378-451; inter_sched_ = 3, which no CLI
                               scheduler number of the reference selects -- ENodeB::DLScheduler_VOGEL exists, ENodeB.cpp:375) */
 };

@@ -189,7 +189,7 @@ class GpuDownlinkScheduler {
     }
     in.hol_delay = in_hol_.data();
     in.prio_has_data = in_prio_.data();
-    if (sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL || sched_ == RS_SCHED_VOGEL) {
+    if (sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL || sched_ == RS_SCHED_VOGEL || sched_ == RS_SCHED_UPPERBOUND) {
       in.rand0 = rand();
       in.rand1 = rand();
     }

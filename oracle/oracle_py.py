@@ -14,7 +14,7 @@ HERE = Path(__file__).resolve().parent
 LIB = HERE / "librs_oracle.so"
 REF_DIR = HERE / "_ref"
 
-SCHED_PF, SCHED_NVS, SCHED_SEQUENTIAL, SCHED_MAXCELL, SCHED_VOGEL = 1, 7, 8, 9, 103
+SCHED_PF, SCHED_NVS, SCHED_SEQUENTIAL, SCHED_MAXCELL, SCHED_VOGEL, SCHED_UPPERBOUND = 1, 7, 8, 9, 103, 10
 
 
 def build(quiet=True):

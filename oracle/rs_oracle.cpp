@@ -362,6 +362,26 @@ void link_adaptation(const rso_cell* c, const int* rbg_to_user, rso_tti_out* out
   }
 }
 
+/* the same tail when the PRBs of a user are not in RBG-ascending order (UpperBound pushes every slice's RBGs in that
+ * slice's sorted order, :603-616): lists[u] = the user's RBGs in push order */
+void link_adaptation_lists(const rso_cell* c, const std::vector<std::vector<int>>& lists, rso_tti_out* out) {
+  const int U = c->U, G = c->rbg_size;
+  std::vector<uint8_t> prb;
+  for (int u = 0; u < U; u++) {
+    out->user_nprb[u] = 0; out->user_final_cqi[u] = 0; out->user_mcs[u] = 0; out->user_tbs_bits[u] = 0;
+    if (lists[u].empty()) continue;
+    prb.clear();
+    for (int r : lists[u])
+      for (int k = 0; k < G; k++) prb.push_back(prb_cqi(c, u, r, k));
+    int fc = rso_final_cqi(prb.data(), (int)prb.size());
+    int mcs = kCqiToMcs[fc - 1];
+    out->user_nprb[u] = (int)prb.size();
+    out->user_final_cqi[u] = fc;
+    out->user_mcs[u] = mcs;
+    out->user_tbs_bits[u] = rso_tbs_bits(mcs, (int)prb.size());
+  }
+}
+
 /* DownlinkTransportScheduler::RBsAllocation, ref: downlink-transport-scheduler.cpp:453-675 */
 int allocate_transport(rso_cell* c, const double* avg, int rand0, int rand1, rso_tti_out* out,
                        bool commit) {
@@ -420,6 +440,37 @@ int allocate_transport(rso_cell* c, const double* avg, int rand0, int rand1, rso
         slice_eff[(size_t)i * S + s] = c->eff_of_cqi[c->cqi[(size_t)j * R + i]];
       }
     }
+  }
+  if (c->sched == RSO_SCHED_UPPERBOUND) {
+    /* UpperBound, ref: :223-246 and the inter_sched_ >= 4 branch of the apply step :603-616.  Every slice with a positive
+     * quota sorts ITS R (rbg, eff) pairs with the same unstable std::sort call and takes its first quota[j] RBGs,
+     * whatever the other slices take: several slices may hold one RBG (it is an upper bound, not an allocation).
+     * The reference walks an unordered_map of slices; users of different slices are distinct, so the walk order
+     * does not reach any result.  quota[j] > R would read past the vector in the reference; clamped here. */
+    std::vector<std::vector<int>> lists(U);
+    for (int i = 0; i < R; i++) out->rbg_to_user[i] = -1;
+    for (int j = 0; j < S; j++) {
+      if (quota[j] <= 0) continue;
+      std::vector<std::pair<int, double>> v;
+      for (int i = 0; i < R; i++) v.emplace_back(i, slice_eff[(size_t)i * S + j]);
+      std::sort(v.begin(), v.end(), [](std::pair<int, double> a, std::pair<int, double> b) { return a.second > b.second; });
+      int take = std::min(quota[j], R);
+      for (int k = 0; k < take; k++) {
+        int rbg = v[k].first;
+        int u = user_index[(size_t)rbg * S + j];
+        if (u < 0) return -5; /* reference: assert(uindex != -1) */
+        lists[u].push_back(rbg);
+        /* reporting convention of this restatement (the reference has no RBG -> UE map here): the user of the
+         * lowest-numbered slice that took the RBG */
+        if (out->rbg_to_user[rbg] < 0) out->rbg_to_user[rbg] = u;
+      }
+      final_rbgs[j] += take;
+    }
+    if (commit)
+      for (int s2 = 0; s2 < S; s2++) c->offset[s2] = target[s2] - final_rbgs[s2] * G;
+    link_adaptation_lists(c, lists, out);
+    out->served_slice = -1;
+    return 0;
   }
   /* :570-586 */
   std::vector<int> rbg_to_slice(R, -1);
@@ -576,7 +627,9 @@ int rso_cell_step(rso_cell* c, double now, int rand0, int rand1, rso_tti_out* ou
   return rc;
 }
 
-static bool uses_rand(int sched) { return sched == RSO_SCHED_SEQUENTIAL || sched == RSO_SCHED_MAXCELL || sched == RSO_SCHED_VOGEL; }
+static bool uses_rand(int sched) {
+  return sched == RSO_SCHED_SEQUENTIAL || sched == RSO_SCHED_MAXCELL || sched == RSO_SCHED_VOGEL || sched == RSO_SCHED_UPPERBOUND;
+}
 
 int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_map, int* log_fcqi, int* log_quota,
                   int* log_target, int* log_tbs) {

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-RS_SCHED_PF, RS_SCHED_NVS, RS_SCHED_SEQUENTIAL, RS_SCHED_MAXCELL, RS_SCHED_VOGEL = 1, 7, 8, 9, 103
+RS_SCHED_PF, RS_SCHED_NVS, RS_SCHED_SEQUENTIAL, RS_SCHED_MAXCELL, RS_SCHED_UPPERBOUND, RS_SCHED_VOGEL = 1, 7, 8, 9, 10, 103
 
 # CQI histogram (CQI 1..15) of the reference's whole cqi-traces-noise0 corpus (158 traces x 475 rows
 # x 512 PRBs; SURVEY.md 8d, re-counted by tools/make_trace_fixture.py)

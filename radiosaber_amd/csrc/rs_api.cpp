@@ -205,7 +205,7 @@ int validate(const rs_config* c, bool direct) {
   if (c->rbg_size < 1 || c->rbg_size > 8) return fail(RS_ERR_INVALID, "rbg_size %d outside 1..8", c->rbg_size);
   if (c->n_rbgs * c->rbg_size > 512) return fail(RS_ERR_INVALID, "more than 512 PRBs (reference get_rbg_size throws)");
   if (c->sched != RS_SCHED_PF && c->sched != RS_SCHED_NVS && c->sched != RS_SCHED_SEQUENTIAL && c->sched != RS_SCHED_MAXCELL &&
-      c->sched != RS_SCHED_VOGEL)
+      c->sched != RS_SCHED_VOGEL && c->sched != RS_SCHED_UPPERBOUND)
     return fail(RS_ERR_INVALID, "sched %d not supported (1, 7, 8, 9)", c->sched);
   if (!c->slice_weight || !c->algo_alpha || !c->algo_epsilon || !c->algo_psi || !c->user_to_slice)
     return fail(RS_ERR_INVALID, "null slice/user array");
@@ -371,6 +371,16 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
     threads = (!direct && cfg->n_cells >= 4 * cus) ? 256 : 512;
   }
   if (threads % 64 || threads < 64 || threads > 512) { fail(RS_ERR_INVALID, "threads_per_cell %d", threads); return nullptr; }
+  if (cfg->cell.sched == RS_SCHED_UPPERBOUND) {
+    /* the per-slice sorts use the register form of the sort emulation: at most four array positions per thread */
+    const int N = cfg->cell.n_rbgs * cfg->cell.n_slices;
+    if (cfg->threads_per_cell == 0)
+      while (threads < 512 && N > 4 * threads) threads += 64;
+    if (N > 4 * threads) {
+      fail(RS_ERR_INVALID, "RS_SCHED_UPPERBOUND: n_rbgs * n_slices = %d exceeds 4 * threads_per_cell = %d", N, 4 * threads);
+      return nullptr;
+    }
+  }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { fail(RS_ERR_NO_DEVICE, "no HIP device"); return nullptr; }
   if (cfg->cell.device < 0 || cfg->cell.device >= n) { fail(RS_ERR_NO_DEVICE, "device %d of %d", cfg->cell.device, n); return nullptr; }
@@ -652,6 +662,10 @@ const char* rs_batch_kernel_name(rs_batch* b) {
     case 7: return "rs_cell_kernel<7, 0>";
     case 8: return "rs_cell_kernel<8, 0>";
     case RS_SCHED_VOGEL: return "rs_cell_kernel<103, 0>";
+    case RS_SCHED_UPPERBOUND: {
+      const int ept = (b->R * b->S + b->threads - 1) / b->threads;
+      return ept <= 1 ? "rs_cell_kernel<10, 1>" : ept <= 2 ? "rs_cell_kernel<10, 2>" : ept <= 3 ? "rs_cell_kernel<10, 3>" : "rs_cell_kernel<10, 4>";
+    }
     default: {
       const int ept = (b->R * b->S + b->threads - 1) / b->threads;
       return ept <= 1 ? "rs_cell_kernel<9, 1>" : ept <= 2 ? "rs_cell_kernel<9, 2>" : ept <= 3 ? "rs_cell_kernel<9, 3>" : ept <= 4 ? "rs_cell_kernel<9, 4>" : "rs_cell_kernel<9, 0>";

@@ -73,7 +73,7 @@ constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads) {
   c.off_sorted = off; off += rs_round_up(4 * R * S, 16);
   c.off_items = off; off += rs_round_up(2 * c.n_items, 16);
   /* level-synchronous introsort scratch: cut per sub-range (+ bounds/pivots when the state lives in LDS) */
-  c.off_sortx = off; off += sched == 9 ? rs_round_up((c.ept <= 4 ? 2 : 8) * R * S, 16) : 0;
+  c.off_sortx = off; off += (sched == 9 || sched == 10) ? rs_round_up((c.ept <= 4 ? 2 : 8) * R * S, 16) : 0;
   c.off_cqi = off; off += rs_round_up(c.Upad * R, 16);
   c.lds_bytes = off;
   return c;

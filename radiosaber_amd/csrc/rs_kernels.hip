@@ -315,8 +315,8 @@ __device__ __forceinline__ int wave_scan_max_incl(int v) {
  * than 16, so their slots differ).  Counts come from per-chunk ballots + one prefix scan per wave.
  */
 template <int EPT>
-__device__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t* cuts, Misc* m,
-                                     unsigned long long* sub) {
+__device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t* cuts, Misc* m,
+                                     unsigned long long* sub, int seg_len = 0) {
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
 #ifdef RS_STAMPS
   unsigned long long sub_prev = __builtin_readcyclecounter();
@@ -329,11 +329,18 @@ __device__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t
   for (int i = 0; i < EPT; ++i) {
     const int x = i * nt + tid;
     e[i] = x < N ? v[x] : 0u;
-    F[i] = 0;
-    L[i] = (x < N && N > 16) ? N : 0;
+    if (seg_len == 0) {
+      F[i] = 0;
+      L[i] = (x < N && N > 16) ? N : 0;
+    } else {
+      /* seg_len > 0: the array is a row of independent std::sort calls, seg_len elements each (UpperBound) */
+      F[i] = idiv_small(x, seg_len) * seg_len;
+      L[i] = (x < N && seg_len > 16) ? F[i] + seg_len : 0;
+    }
   }
-  if (tid < 48) m->n_level[tid] = (tid == 0 && N > 16) ? 1 : 0;
-  int depth = 2 * rs_sort::floor_log2(N > 1 ? N : 1);
+  const int n_first = seg_len == 0 ? N : seg_len; /* length every std::sort call starts from */
+  if (tid < 48) m->n_level[tid] = (tid == 0 && n_first > 16) ? 1 : 0;
+  int depth = 2 * rs_sort::floor_log2(n_first > 1 ? n_first : 1);
   __syncthreads();
   for (int level = 0; level < 47; ++level, --depth) {
     if (depth == 0) {
@@ -509,7 +516,7 @@ __device__ void counting_sort_desc(const uint32_t* v, uint32_t* out, int N, Misc
  * equal keys in its chunk; after one barrier every wave derives the output offsets of its own chunks
  * from the count table (lane q = key q), so there is no single-wave step and no second barrier. */
 template <int CPW>
-__device__ void counting_sort_desc_owned(const uint32_t* v, uint32_t* out, int N, Misc* m) {
+__device__ __forceinline__ void counting_sort_desc_owned(const uint32_t* v, uint32_t* out, int N, Misc* m) {
   const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
   const int n_chunks = (N + 63) >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -609,7 +616,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
                               kCv.n_seg, kCv.n_items}
                        : Offs{p.off_avgk, p.off_rcp, p.off_tab, p.off_slice, p.off_tx, p.off_misc, p.off_tbs, p.off_elems,
                               p.off_sorted, p.off_items, p.off_sortx, p.off_cqi, p.Upad, p.n_seg, p.n_items};
-  constexpr bool kTransport = (SCHED == 8 || SCHED == 9 || SCHED == 103);
+  constexpr bool kTransport = (SCHED == 8 || SCHED == 9 || SCHED == 103 || SCHED == 10);
   const int quota_wave = nwaves - 1; /* P2 runs on the last wave, beside the other waves' P3 */
 
   double* s_avg = (double*)lds;
@@ -969,7 +976,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           }
         }
         s_best_user[it] = (uint16_t)bu;
-        if (kTransport) {
+        if (SCHED == 10) {
+          /* UpperBound sorts one vector per slice (:229-233): slice-major */
+          s_elems[sg * R + r] = ((uint32_t)bkey << 16) | ((uint32_t)r << 8) | (uint32_t)sg;
+        } else if (kTransport) {
           /* MaximizeCell's vector is RBG-major, slice-minor (:357-360) */
           s_elems[r * S + sg] = ((uint32_t)bkey << 16) | ((uint32_t)r << 8) | (uint32_t)sg;
         } else if (SCHED == 1) {
@@ -1011,9 +1021,108 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       else counting_sort_desc(s_elems, s_sorted, N, m);
       RS_STAMP(4);
     }
+    if constexpr (SCHED == 10) {
+      /* ---------------- UpperBound, ref: :223-246 and the inter_sched_ >= 4 branch of :603-616 ----------------
+       * Every slice with a positive quota sorts its own R (rbg, eff) pairs (the same unstable std::sort) and takes its
+       * first quota RBGs whatever the other slices take.  The S sorts run as ONE level-synchronous pass over the
+       * slice-major array (sub-ranges of a level are disjoint anyway); the final insertion sort of each call is a stable
+       * rank inside its segment.  Then one thread per taken (slice, k) entry: the first entry of a UE is its leader and
+       * sums E[cqi] over the UE's entries in push order (the slice's sorted order, not RBG order). */
+      static_assert(EPT > 0, "UpperBound uses the register form of the sort (R*S <= 4 * threads)");
+      const int N = R * S;
+      introsort_levels_reg<EPT>(s_elems, N, s_sorted, (int32_t*)(lds + o.sortx), m, sort_sub, R);
+      int32_t* low_owner = (int32_t*)m->hist; /* per RBG: (slice << 16 | UE) of the lowest slice holding it */
+      for (int x = tid; x < N; x += nt) {
+        const int f = idiv_small(x, R) * R;
+        const uint32_t e = s_elems[x];
+        const int k = (int)(e >> 16);
+        int rank = 0;
+        for (int y = f; y < f + R; ++y) {
+          const int ky = (int)(s_elems[y] >> 16);
+          rank += (ky > k || (ky == k && y < x)) ? 1 : 0;
+        }
+        s_sorted[f + rank] = e;
+      }
+      if (tid < R) low_owner[tid] = 0x7fffffff;
+      if (tid == 0) m->served = 0;
+      __syncthreads();
+      uint16_t* ent_user = (uint16_t*)s_elems; /* s_elems is dead: UE of entry (slice, k), 0xFFFF = not taken */
+      for (int x = tid; x < N; x += nt) {
+        const int sl = idiv_small(x, R), k = x - sl * R;
+        const int q = m->quota[sl];
+        int u = 0xFFFF;
+        if (k < q) { /* q <= 0: nothing; q > R cannot index past the segment (the reference would read past its vector) */
+          const int rbg = (int)((s_sorted[x] >> 8) & 63u);
+          u = s_best_user[sl * R + rbg];
+          if (u != 0xFFFF) atomicMin(&low_owner[rbg], (sl << 16) | u);
+        }
+        ent_user[x] = (uint16_t)u;
+      }
+      __syncthreads();
+      for (int x = tid; x < N; x += nt) {
+        const int sl = idiv_small(x, R), f = sl * R, k = x - f;
+        const int u = ent_user[x];
+        int q = m->quota[sl];
+        q = q > R ? R : q;
+        bool leader = u != 0xFFFF;
+        for (int y = f; y < x && leader; ++y) leader = ent_user[y] != u;
+        if (!leader) continue;
+        double sum = 0;
+        int nprb = 0;
+        for (int y = x; y < f + q; ++y) {
+          if (ent_user[y] != u) continue;
+          const int r2 = (int)((s_sorted[y] >> 8) & 63u);
+          if (p.prb_cqi) {
+            const uint8_t* pr = p.prb_cqi + ((size_t)u * R + r2) * G;
+            for (int g = 0; g < G; ++g) sum += s_e[pr[g]];
+          } else {
+            const double ev = s_e[s_cqi[r2 * Upad + u]];
+            for (int g = 0; g < G; ++g) sum += ev;
+          }
+          nprb += G;
+        }
+        const double xm = sum / (double)nprb;
+        int fcqi;
+        if (xm == 0) {
+          fcqi = 15;
+        } else {
+          fcqi = 1;
+          for (int t = 1; t <= 13; ++t) fcqi += (xm <= s_x[t]) ? 1 : 0;
+        }
+        const int mcs = m->mcs_of_cqi[fcqi];
+        const int tbs = s_tbs[(nprb / G) * 27 + m->itbs_of_cqi[fcqi]];
+        int bytes = tbs / 8;
+        if (bytes > 100000000) bytes = 100000000;
+        if (bytes > 0) {
+          s_tx[u] += bytes;
+          atomicAdd((unsigned long long*)&p.cum_bytes[(size_t)cell * U + u], (unsigned long long)bytes);
+          atomicAdd((unsigned long long*)&p.cum_rbs[(size_t)cell * U + u], (unsigned long long)nprb);
+        }
+        atomicAdd(&m->served, 1);
+        if (p.log_map) {
+          const size_t row = (size_t)cell * p.n_ttis + tti;
+          if (p.log_tbs) p.log_tbs[row * U + u] = tbs;
+          if (p.log_uinfo) p.log_uinfo[row * U + u] = nprb | (fcqi << 16) | (mcs << 24);
+        }
+      }
+      if (tid < S) {
+        /* ref: :618-620 with slice_final_rbgs = size of the slice's list */
+        int q = m->quota[tid];
+        q = q < 0 ? 0 : (q > R ? R : q);
+        s_sstate[tid] = (double)(m->target[tid] - q * G);
+      }
+      if (p.log_map) {
+        const size_t row = (size_t)cell * p.n_ttis + tti;
+        if (tid < R) p.log_map[row * R + tid] = (int16_t)(low_owner[tid] == 0x7fffffff ? -1 : (low_owner[tid] & 0xffff));
+        if (tid < S) {
+          if (p.log_quota) p.log_quota[row * S + tid] = (int16_t)m->quota[tid];
+          if (p.log_target) p.log_target[row * S + tid] = (int16_t)m->target[tid];
+        }
+      }
+    }
     /* the rest of the TTI runs on wave 0: lanes = slices for the quota counters, lanes = RBGs for
      * the allocation; the RBG->slice map stays in registers */
-    if (wave == 0) {
+    if (SCHED != 10 && wave == 0) {
       /* the only running wave of this cell until the end-of-TTI barrier: ask the SIMD's arbiter to prefer it
        * over the co-resident cell's waves (measured +3 % with two cells per CU) */
       __builtin_amdgcn_s_setprio(3);
@@ -1301,7 +1410,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
 extern "C" __global__ void __launch_bounds__(RS_JIT_NT, 4) rs_cell_kernel_jit(RsLaunch p) {
   constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT);
   __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
-  constexpr int kEpt = RS_JIT_SCHED != 9 ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);
+  constexpr int kEpt = (RS_JIT_SCHED != 9 && RS_JIT_SCHED != 10) ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);
   rs_cell_body<RS_JIT_SCHED, kEpt, true>(p, lds);
 }
 #endif
@@ -1381,6 +1490,13 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
     case 7: hipLaunchKernelGGL((rs_cell_kernel<7, 0>), grid, block, p->lds_bytes, stream, *p); break;
     case 8: hipLaunchKernelGGL((rs_cell_kernel<8, 0>), grid, block, p->lds_bytes, stream, *p); break;
     case 103: hipLaunchKernelGGL((rs_cell_kernel<103, 0>), grid, block, p->lds_bytes, stream, *p); break;
+    case 10:
+      if (ept <= 1) hipLaunchKernelGGL((rs_cell_kernel<10, 1>), grid, block, p->lds_bytes, stream, *p);
+      else if (ept <= 2) hipLaunchKernelGGL((rs_cell_kernel<10, 2>), grid, block, p->lds_bytes, stream, *p);
+      else if (ept <= 3) hipLaunchKernelGGL((rs_cell_kernel<10, 3>), grid, block, p->lds_bytes, stream, *p);
+      else if (ept <= 4) hipLaunchKernelGGL((rs_cell_kernel<10, 4>), grid, block, p->lds_bytes, stream, *p);
+      else return hipErrorInvalidValue;
+      break;
     case 9:
       if (ept <= 1) hipLaunchKernelGGL((rs_cell_kernel<9, 1>), grid, block, p->lds_bytes, stream, *p);
       else if (ept <= 2) hipLaunchKernelGGL((rs_cell_kernel<9, 2>), grid, block, p->lds_bytes, stream, *p);
@@ -1395,6 +1511,8 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
 
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes) {
   const void* fns[] = {(const void*)rs_cell_kernel<1, 0>, (const void*)rs_cell_kernel<7, 0>, (const void*)rs_cell_kernel<8, 0>, (const void*)rs_cell_kernel<103, 0>,
+                       (const void*)rs_cell_kernel<10, 1>, (const void*)rs_cell_kernel<10, 2>, (const void*)rs_cell_kernel<10, 3>,
+                       (const void*)rs_cell_kernel<10, 4>,
                        (const void*)rs_cell_kernel<9, 0>, (const void*)rs_cell_kernel<9, 1>, (const void*)rs_cell_kernel<9, 2>, (const void*)rs_cell_kernel<9, 3>,
                        (const void*)rs_cell_kernel<9, 4>};
   for (const void* f : fns) {

@@ -223,7 +223,7 @@ def test_device_synth_grids_in_range_and_runs(rs, oracle):
     b.close()
 
 
-@pytest.mark.parametrize("sched", [9, 8, 1, 7, 103])
+@pytest.mark.parametrize("sched", [9, 8, 1, 7, 103, 10])
 def test_drop_in_single_tti(rs, oracle, sched):
     """rs_schedule_tti == RBsAllocation() of the oracle, carrying slice_rbs_offset_ across calls."""
     ues, R, G = [5] * 20, 64, 8
@@ -432,8 +432,10 @@ def test_random_shapes_all_schedulers(rs, oracle, seed):
         R, G = [(25, 4), (64, 8), (12, 2), (50, 2), (17, 3), (33, 3)][int(rng.integers(0, 6))]
         w = rng.uniform(0.2, 1.0, S)
         w = [float(x) for x in w / w.sum()]
-        sched = [9, 9, 9, 8, 7, 1, 103][int(rng.integers(0, 7))]
+        sched = [9, 9, 9, 8, 7, 1, 103, 10][int(rng.integers(0, 8))]
         threads = [0, 64, 128, 256, 512][int(rng.integers(0, 5))]
+        if sched == 10 and threads and R * S > 4 * threads:
+            threads = 0  # UpperBound needs R*S <= 4 * threads; 0 lets the library choose
         psi = [int(x) for x in rng.integers(0, 2, S)] if sched != 1 else None
         eps = [1] * S if sched != 1 else None
         _check_batch(rs, oracle, sched, ues, R, G, n_cells=2, n_ttis=int(rng.integers(41, 90)), threads=threads,
@@ -461,3 +463,19 @@ def test_vogel_policy_on_the_device(rs, oracle):
     _check_batch(rs, oracle, 103, [2] * 64, 33, 3, n_cells=1, n_ttis=45, jit=True)                # 64 slices
     _check_batch(rs, oracle, 103, [25] * 20, 25, 4, n_cells=1, n_ttis=45, jit=True)
 
+
+
+def test_upper_bound_policy_on_the_device(rs, oracle):
+    """N4: UpperBound (sched 10; ref: downlink-transport-scheduler.cpp:223-246, :603-616): one unstable std::sort per
+    slice (run as one segmented level-synchronous pass on the device), the top-quota RBGs per slice, link adaptation over
+    each UE's RBGs in push order.  Ties at the quota boundary are the norm with 16 key levels, so per-UE PRB counts, TBS
+    and the cumulative counters pin the sort order.  Oracle restated from the cited lines (no reference output exists)."""
+    _check_batch(rs, oracle, 10, [5] * 20, 25, 4, n_cells=3, n_ttis=90)
+    _check_batch(rs, oracle, 10, [5] * 20, 64, 8, n_cells=2, n_ttis=60)                  # R = 64: real introsort levels
+    _check_batch(rs, oracle, 10, [3, 7, 0, 1, 12], 64, 8, n_cells=2, n_ttis=50)           # ragged, one empty slice
+    _check_batch(rs, oracle, 10, [10] * 5, 33, 3, n_cells=2, n_ttis=90, weights=[0.62, 0.3, 0.05, 0.02, 0.01])
+    _check_batch(rs, oracle, 10, [2] * 32, 64, 8, n_cells=1, n_ttis=45, jit=True)         # 2 048 records
+    _check_batch(rs, oracle, 10, [25] * 20, 25, 4, n_cells=1, n_ttis=45, jit=True)
+    _check_batch(rs, oracle, 10, [4] * 6, 64, 8, n_cells=2, n_ttis=45, threads=128)       # three positions per thread
+    with pytest.raises(rs.RadioSaberError, match="exceeds"):
+        rs.BatchScheduler(rs.SliceConfig([2] * 64), 64, 8, 1, sched=10)                   # 4 096 records
