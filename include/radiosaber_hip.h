@@ -45,6 +45,8 @@ enum {
   RS_SCHED_NVS = 7,        /* DownlinkNVSScheduler (ref: downlink-nvs-scheduler.cpp:94-142,275-358) */
   RS_SCHED_SEQUENTIAL = 8, /* DownlinkTransportScheduler + GreedyByRow (ref: downlink-transport-scheduler.cpp:249-272) */
   RS_SCHED_MAXCELL = 9,    /* DownlinkTransportScheduler + MaximizeCell = RadioSaber (ref: :351-376) */
+  RS_SCHED_NVS_NONGREEDY = 11, /* DownlinkNVSScheduler with is_nongreedy_ (the CLI's scheduler 11): RBsAllocationNonGreedyPF +
+                              AssignRBsGivenMCS (ref: downlink-nvs-scheduler.cpp:405-528), 300 sampled CQI-index vectors per TTI */
   RS_SCHED_UPPERBOUND = 10, /* DownlinkTransportScheduler + UpperBound (ref: :223-246, apply step :603-616): every slice takes
                               its own best quota RBGs whatever the others take -- an upper bound, not an allocation: several
                               UEs may hold one RBG.  rbg_to_user then reports the UE of the lowest-numbered slice holding
@@ -120,6 +122,9 @@ typedef struct rs_tti_in {
    * downlink-nvs-scheduler.cpp:375-387; both may be NULL when every slice has algo_alpha = 0 */
   const double* hol_delay;       /* [n] GetHeadOfLinePacketDelay() of the user's slice-priority bearer     */
   const uint8_t* prio_has_data;  /* [n] m_dataToTransmit[slice_priority_[slice]] != 0; NULL = all 1        */
+  const int32_t* rand_draws;     /* RS_SCHED_NVS_NONGREEDY only: the 300 * n values rand() returns to
+                                    RBsAllocationNonGreedyPF, in draw order (sample-major, user-minor;
+                                    downlink-nvs-scheduler.cpp:431-441); NULL for every other scheduler     */
 } rs_tti_in;
 
 /* What RBsAllocation() leaves behind (ref: :589-620 allocation lists + slice_rbs_offset_,

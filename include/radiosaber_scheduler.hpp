@@ -106,7 +106,7 @@ class GpuDownlinkScheduler {
    * now = Simulator::Init()->Now() */
   void DoSchedule(double now) {
     int slice_serve = -1;
-    if (sched_ == RS_SCHED_NVS) slice_serve = SelectSliceToServe(); /* before the EWMA update (nvs :207-208) */
+    if (sched_ == RS_SCHED_NVS || sched_ == RS_SCHED_NVS_NONGREEDY) slice_serve = SelectSliceToServe(); /* before the EWMA update (nvs :207-208) */
     UpdateAverageTransmissionRate(now);
     SelectFlowsToSchedule(slice_serve);
     allocations_.clear();
@@ -193,6 +193,12 @@ class GpuDownlinkScheduler {
       in.rand0 = rand();
       in.rand1 = rand();
     }
+    if (sched_ == RS_SCHED_NVS_NONGREEDY) {
+      /* RBsAllocationNonGreedyPF draws 300 x users values from libc rand(), sample-major (nvs :431-441) */
+      in_draws_.resize((size_t)300 * n);
+      for (int& d : in_draws_) d = rand();
+      in.rand_draws = in_draws_.data();
+    }
     target_.assign(num_slices_, 0);
     quota_.assign(num_slices_, 0);
     rbg_to_user_.assign(nb_rbgs_, -1);
@@ -232,6 +238,7 @@ class GpuDownlinkScheduler {
   std::vector<uint8_t> cqi_, in_cqi_, cqi_prb_, in_prb_;
   std::vector<double> in_avg_, in_hol_;
   std::vector<uint8_t> in_prio_;
+  std::vector<int> in_draws_;
   std::vector<int> users_, target_, quota_, rbg_to_user_, nprb_, fcqi_, mcs_, tbs_;
   std::vector<Allocation> allocations_;
   unsigned long ts_ = 0;

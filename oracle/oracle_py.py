@@ -14,7 +14,7 @@ HERE = Path(__file__).resolve().parent
 LIB = HERE / "librs_oracle.so"
 REF_DIR = HERE / "_ref"
 
-SCHED_PF, SCHED_NVS, SCHED_SEQUENTIAL, SCHED_MAXCELL, SCHED_VOGEL, SCHED_UPPERBOUND = 1, 7, 8, 9, 103, 10
+SCHED_PF, SCHED_NVS, SCHED_SEQUENTIAL, SCHED_MAXCELL, SCHED_VOGEL, SCHED_UPPERBOUND, SCHED_NVS_NONGREEDY = 1, 7, 8, 9, 103, 10, 11
 
 
 def build(quiet=True):
@@ -80,6 +80,8 @@ def lib():
         L.rso_cell_set_avg_rate.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.rso_cell_step.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(_TtiOut)]
         L.rso_cell_allocate.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(_TtiOut)]
+        L.rso_cell_allocate_nongreedy.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.c_int,
+                                                  C.POINTER(_TtiOut)]
         L.rso_cell_get_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         L.rso_run_trace.argtypes = [C.c_void_p, C.POINTER(_TraceRun)] + [C.POINTER(C.c_int)] * 5
@@ -227,6 +229,12 @@ class Cell:
     def allocate(self, avg_rate, rand0, rand1, out):
         a = np.ascontiguousarray(avg_rate, np.float64)
         return lib().rso_cell_allocate(self.h, _p(a, C.c_double), rand0, rand1, C.byref(out.c))
+
+    def allocate_nongreedy(self, avg_rate, slice_id, draws, out):
+        """sched 11: RBsAllocationNonGreedyPF for the users of `slice_id` with the rand() values in draw order."""
+        a = np.ascontiguousarray(avg_rate, np.float64)
+        d = np.ascontiguousarray(draws, np.int32)
+        return lib().rso_cell_allocate_nongreedy(self.h, _p(a, C.c_double), slice_id, _p(d, C.c_int), d.size, C.byref(out.c))
 
     def state(self):
         avg = np.zeros(self.U, np.float64)

@@ -296,7 +296,7 @@ void rso_cell_get_state(const rso_cell* c, double* avg, int64_t* cum_bytes, int6
   if (cum_bytes) memcpy(cum_bytes, c->cum_bytes.data(), sizeof(int64_t) * c->U);
   if (cum_rbs) memcpy(cum_rbs, c->cum_rbs.data(), sizeof(int64_t) * c->U);
   if (slice_state)
-    memcpy(slice_state, (c->sched == RSO_SCHED_NVS ? c->ewma : c->offset).data(), sizeof(double) * c->S);
+    memcpy(slice_state, ((c->sched == RSO_SCHED_NVS || c->sched == RSO_SCHED_NVS_NONGREEDY) ? c->ewma : c->offset).data(), sizeof(double) * c->S);
 }
 
 }  // extern "C"
@@ -595,9 +595,75 @@ void account(rso_cell* c, const rso_tti_out* out) {
   }
 }
 
+/* DownlinkNVSScheduler::RBsAllocationNonGreedyPF + AssignRBsGivenMCS, ref: downlink-nvs-scheduler.cpp:405-528.
+ * 300 times: every user of the served slice draws an "MCS" (a CQI index) max(highest_cqi - rand() % 4, 1); with those,
+ * every RBG goes to the first user with the largest  eff(mcs) * 180000 / (1 + avg)  among the users whose CQI on the RBG
+ * reaches their MCS (0 otherwise; strict '<' from -1: first maximum wins), and the sample's score is the sum of the
+ * winners' metrics in RBG order.  The first sample with the strictly largest score (from 0) is applied.  Restated from
+ * the cited lines; no reference output exists for this scheduler here. */
+int allocate_nvs_nongreedy(rso_cell* c, const double* avg, int slice, const int* draws, int n_draws, rso_tti_out* out) {
+  const int U = c->U, R = c->R;
+  for (int s = 0; s < c->S; s++) { out->target_rbs[s] = 0; out->quota_rbgs[s] = 0; }
+  std::vector<int> users;
+  for (int u = 0; u < U; u++)
+    if (c->u2s[u] == slice) users.push_back(u);
+  const int n = (int)users.size();
+  if (n_draws != RSO_NONGREEDY_SAMPLES * n) return -6;
+  std::vector<int> highest(n, 0);
+  for (int i = 0; i < n; i++)
+    for (int r = 0; r < R; r++) highest[i] = std::max(highest[i], (int)prb_cqi(c, users[i], r, 0)); /* :417-424 */
+  std::vector<int> best_assign;
+  double best = 0;
+  std::vector<int> mcs(n), assign(R);
+  for (int smp = 0; smp < RSO_NONGREEDY_SAMPLES; smp++) {
+    for (int i = 0; i < n; i++) mcs[i] = std::max(highest[i] - draws[(size_t)smp * n + i] % 4, 1); /* :436-440 */
+    double pf = 0;
+    for (int r = 0; r < R; r++) { /* AssignRBsGivenMCS :508-527 */
+      double highest_metric = -1;
+      assign[r] = -1;
+      for (int i = 0; i < n; i++) {
+        int cqi = prb_cqi(c, users[i], r, 0);
+        double metric = 0;
+        if (mcs[i] <= cqi) {
+          double sEff = c->eff_of_cqi[mcs[i]];
+          double rate = 1;  /* UserToSchedule::GetAverageTransmissionRate, packet-scheduler.cpp:424-433 */
+          rate += avg[users[i]];
+          metric = sEff * 180000 / rate;
+        }
+        if (highest_metric < metric) { highest_metric = metric; assign[r] = users[i]; }
+      }
+      pf += highest_metric;
+    }
+    if (best < pf) { best = pf; best_assign = assign; }
+  }
+  /* :451-459 -- nothing is allocated when no sample scored above 0 (the best assignment stays empty) */
+  for (int r = 0; r < R; r++) out->rbg_to_user[r] = best_assign.empty() ? -1 : best_assign[r];
+  link_adaptation(c, out->rbg_to_user, out);
+  out->served_slice = slice;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int rso_cell_allocate_nongreedy(rso_cell* c, const double* avg_rate, int slice, const int* draws, int n_draws,
+                                rso_tti_out* out) {
+  return allocate_nvs_nongreedy(c, avg_rate, slice, draws, n_draws, out);
+}
+
+int rso_cell_step_rng(rso_cell* c, double now, rso_rng* g, rso_tti_out* out) {
+  if (c->sched != RSO_SCHED_NVS_NONGREEDY) return -7;
+  int slice = nvs_select_slice(c); /* same DoSchedule as sched 7 (downlink-nvs-scheduler.cpp:196-218) */
+  update_average_rate(c, now);
+  int n = 0;
+  for (int u = 0; u < c->U; u++) n += c->u2s[u] == slice;
+  std::vector<int> draws((size_t)RSO_NONGREEDY_SAMPLES * n);
+  for (size_t i = 0; i < draws.size(); i++) draws[i] = rso_rand(g);
+  int rc = allocate_nvs_nongreedy(c, c->avg.data(), slice, draws.data(), (int)draws.size(), out);
+  if (rc == 0) account(c, out);
+  return rc;
+}
 
 int rso_cell_allocate(rso_cell* c, const double* avg, int rand0, int rand1, rso_tti_out* out) {
   for (int s = 0; s < c->S; s++)
@@ -605,6 +671,7 @@ int rso_cell_allocate(rso_cell* c, const double* avg, int rand0, int rand1, rso_
   switch (c->sched) {
     case RSO_SCHED_PF: return allocate_pf(c, avg, out);
     case RSO_SCHED_NVS: return -4; /* needs the slice choice: use rso_cell_step */
+    case RSO_SCHED_NVS_NONGREEDY: return -4; /* rso_cell_allocate_nongreedy / rso_cell_step_rng */
     default: return allocate_transport(c, avg, rand0, rand1, out, true);
   }
 }
@@ -666,7 +733,7 @@ int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_map, int* log_
     }
     int r0 = 0, r1 = 0;
     if (uses_rand(c->sched)) { r0 = rso_rand(&g); r1 = rso_rand(&g); }
-    int rc = rso_cell_step(c, t, r0, r1, &out);
+    int rc = c->sched == RSO_SCHED_NVS_NONGREEDY ? rso_cell_step_rng(c, t, &g, &out) : rso_cell_step(c, t, r0, r1, &out);
     if (rc) return rc;
     served_prev = 0;
     for (int u = 0; u < U; u++) served_prev += nprb[u] > 0;
@@ -701,7 +768,7 @@ int rso_run_synth(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refr
     }
     int r0 = 0, r1 = 0;
     if (uses_rand(c->sched)) { r0 = rso_rand(&g); r1 = rso_rand(&g); }
-    int rc = rso_cell_step(c, t, r0, r1, &out);
+    int rc = c->sched == RSO_SCHED_NVS_NONGREEDY ? rso_cell_step_rng(c, t, &g, &out) : rso_cell_step(c, t, r0, r1, &out);
     if (rc) return rc;
     served_prev = 0;
     for (int u = 0; u < U; u++) served_prev += nprb[u] > 0;

@@ -39,6 +39,7 @@ enum {
   RSO_SCHED_SEQUENTIAL = 8, /* DownlinkTransportScheduler, inter_sched_=0 GreedyByRow          */
   RSO_SCHED_MAXCELL = 9,    /* DownlinkTransportScheduler, inter_sched_=2 MaximizeCell         */
   RSO_SCHED_UPPERBOUND = 10,/* inter_sched_=4 UpperBound (not in the sweep)                     */
+  RSO_SCHED_NVS_NONGREEDY = 11, /* DownlinkNVSScheduler with is_nongreedy_: RBsAllocationNonGreedyPF          */
   RSO_SCHED_SUBOPT = 101,   /* inter_sched_=1 SubOpt   (no CLI number reaches it)               */
   RSO_SCHED_VOGEL = 103     /* inter_sched_=3 VogelApproximate (no CLI number reaches it)       */
 };
@@ -115,6 +116,12 @@ void rso_cell_set_queue_state(rso_cell* c, const double* hol, const uint8_t* pri
 int rso_cell_step(rso_cell* c, double now, int rand0, int rand1, rso_tti_out* out);
 /* RBsAllocation() alone on caller-provided PF state (no EWMA / accounting): mirrors rs_schedule_tti */
 int rso_cell_allocate(rso_cell* c, const double* avg_rate, int rand0, int rand1, rso_tti_out* out);
+/* sched 11: RBsAllocationNonGreedyPF for the users of `slice` with the rand() values it would draw, in draw order
+ * (RSO_NONGREEDY_SAMPLES x users-of-the-slice values); and the whole DoSchedule() drawing from a generator */
+#define RSO_NONGREEDY_SAMPLES 300
+int rso_cell_allocate_nongreedy(rso_cell* c, const double* avg_rate, int slice, const int* draws, int n_draws,
+                                rso_tti_out* out);
+int rso_cell_step_rng(rso_cell* c, double now, rso_rng* g, rso_tti_out* out);
 /* state access */
 void rso_cell_get_state(const rso_cell* c, double* avg_rate, int64_t* cum_bytes, int64_t* cum_rbs,
                         double* slice_offset_or_ewma);

@@ -17,7 +17,8 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-RS_SCHED_PF, RS_SCHED_NVS, RS_SCHED_SEQUENTIAL, RS_SCHED_MAXCELL, RS_SCHED_UPPERBOUND, RS_SCHED_VOGEL = 1, 7, 8, 9, 10, 103
+RS_SCHED_PF, RS_SCHED_NVS, RS_SCHED_SEQUENTIAL, RS_SCHED_MAXCELL, RS_SCHED_UPPERBOUND, RS_SCHED_NVS_NONGREEDY, RS_SCHED_VOGEL = \
+    1, 7, 8, 9, 10, 11, 103
 
 # CQI histogram (CQI 1..15) of the reference's whole cqi-traces-noise0 corpus (158 traces x 475 rows
 # x 512 PRBs; SURVEY.md 8d, re-counted by tools/make_trace_fixture.py)
@@ -53,7 +54,8 @@ class _TtiIn(C.Structure):
     _fields_ = [("n_users", C.c_int32), ("user_id", C.POINTER(C.c_int32)),
                 ("cqi", C.POINTER(C.c_uint8)), ("avg_rate", C.POINTER(C.c_double)),
                 ("rand0", C.c_int32), ("rand1", C.c_int32), ("cqi_prb", C.POINTER(C.c_uint8)),
-                ("hol_delay", C.POINTER(C.c_double)), ("prio_has_data", C.POINTER(C.c_uint8))]
+                ("hol_delay", C.POINTER(C.c_double)), ("prio_has_data", C.POINTER(C.c_uint8)),
+                ("rand_draws", C.POINTER(C.c_int32))]
 
 
 class _TtiOut(C.Structure):
@@ -300,8 +302,9 @@ class TtiScheduler:
     __del__ = close
 
     def schedule_tti(self, cqi, avg_rate, rand0=0, rand1=0, user_id: Optional[Sequence[int]] = None,
-                     cqi_prb=None, hol_delay=None, prio_has_data=None) -> TtiResult:
-        """cqi [n][R] per-RBG CQI, or cqi_prb [n][R*rbg_size] per-PRB CQI (then cqi may be None)."""
+                     cqi_prb=None, hol_delay=None, prio_has_data=None, rand_draws=None) -> TtiResult:
+        """cqi [n][R] per-RBG CQI, or cqi_prb [n][R*rbg_size] per-PRB CQI (then cqi may be None).
+        rand_draws (RS_SCHED_NVS_NONGREEDY): the 300 * n rand() values of RBsAllocationNonGreedyPF, in draw order."""
         prb = None
         if cqi_prb is not None:
             prb = np.ascontiguousarray(cqi_prb, np.uint8)
@@ -317,6 +320,8 @@ class TtiScheduler:
         uid = None if user_id is None else np.ascontiguousarray(user_id, np.int32)
         hol = None if hol_delay is None else np.ascontiguousarray(hol_delay, np.float64)
         prio = None if prio_has_data is None else np.ascontiguousarray(prio_has_data, np.uint8)
+        draws = None if rand_draws is None else np.ascontiguousarray(rand_draws, np.int32)
+        assert draws is None or draws.size == 300 * n
         S = self.slices.n_slices
         res = TtiResult(np.zeros(S, np.int32), np.zeros(S, np.int32), np.zeros(self.R, np.int32),
                         np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32))
@@ -324,7 +329,8 @@ class TtiScheduler:
                      _p(cqi, C.c_uint8) if cqi is not None else None, _p(avg, C.c_double), rand0, rand1,
                      _p(prb, C.c_uint8) if prb is not None else None,
                      _p(hol, C.c_double) if hol is not None else None,
-                     _p(prio, C.c_uint8) if prio is not None else None)
+                     _p(prio, C.c_uint8) if prio is not None else None,
+                     _p(draws, C.c_int32) if draws is not None else None)
         tout = _TtiOut(_p(res.target_rbs, C.c_int32), _p(res.quota_rbgs, C.c_int32),
                        _p(res.rbg_to_user, C.c_int32), _p(res.user_nprb, C.c_int32),
                        _p(res.user_final_cqi, C.c_int32), _p(res.user_mcs, C.c_int32),

@@ -205,7 +205,7 @@ int validate(const rs_config* c, bool direct) {
   if (c->rbg_size < 1 || c->rbg_size > 8) return fail(RS_ERR_INVALID, "rbg_size %d outside 1..8", c->rbg_size);
   if (c->n_rbgs * c->rbg_size > 512) return fail(RS_ERR_INVALID, "more than 512 PRBs (reference get_rbg_size throws)");
   if (c->sched != RS_SCHED_PF && c->sched != RS_SCHED_NVS && c->sched != RS_SCHED_SEQUENTIAL && c->sched != RS_SCHED_MAXCELL &&
-      c->sched != RS_SCHED_VOGEL && c->sched != RS_SCHED_UPPERBOUND)
+      c->sched != RS_SCHED_VOGEL && c->sched != RS_SCHED_UPPERBOUND && c->sched != RS_SCHED_NVS_NONGREEDY)
     return fail(RS_ERR_INVALID, "sched %d not supported (1, 7, 8, 9)", c->sched);
   if (!c->slice_weight || !c->algo_alpha || !c->algo_epsilon || !c->algo_psi || !c->user_to_slice)
     return fail(RS_ERR_INVALID, "null slice/user array");
@@ -662,6 +662,7 @@ const char* rs_batch_kernel_name(rs_batch* b) {
     case 7: return "rs_cell_kernel<7, 0>";
     case 8: return "rs_cell_kernel<8, 0>";
     case RS_SCHED_VOGEL: return "rs_cell_kernel<103, 0>";
+    case RS_SCHED_NVS_NONGREEDY: return "rs_cell_kernel<11, 0>";
     case RS_SCHED_UPPERBOUND: {
       const int ept = (b->R * b->S + b->threads - 1) / b->threads;
       return ept <= 1 ? "rs_cell_kernel<10, 1>" : ept <= 2 ? "rs_cell_kernel<10, 2>" : ept <= 3 ? "rs_cell_kernel<10, 3>" : "rs_cell_kernel<10, 4>";
@@ -692,16 +693,17 @@ struct rs_ctx {
 
 namespace {
 struct CtxLayout {
-  size_t grid, slice, avg, hol, prio, prb, in_total, tbs, uinfo, map, quota, target, out_total;
+  size_t grid, slice, avg, hol, prio, draws, prb, in_total, tbs, uinfo, map, quota, target, out_total;
 };
-CtxLayout ctx_layout(int n, int R, int S, int G) {
+CtxLayout ctx_layout(int n, int R, int S, int G, bool with_draws) {
   CtxLayout l;
   l.grid = 0;
   l.slice = round_up(n * R, 16);
   l.avg = l.slice + round_up(n, 16);
   l.hol = l.avg + 8 * (size_t)n;
   l.prio = l.hol + 8 * (size_t)n;
-  l.prb = l.prio + round_up(n, 16);
+  l.draws = l.prio + round_up(n, 16);
+  l.prb = l.draws + (with_draws ? round_up(RS_NVS_SAMPLES * n, 16) : 0);
   l.in_total = l.prb + round_up(n * R * G, 16);
   l.tbs = 0;
   l.uinfo = 4 * (size_t)n;
@@ -727,7 +729,7 @@ rs_ctx* rs_create(const rs_config* cfg) {
   rs_ctx* c = new (std::nothrow) rs_ctx();
   if (!c) { rs_batch_destroy(b); fail(RS_ERR_INVALID, "out of memory"); return nullptr; }
   c->b = b;
-  const CtxLayout l = ctx_layout(b->U, b->R, b->S, b->G);
+  const CtxLayout l = ctx_layout(b->U, b->R, b->S, b->G, b->sched == RS_SCHED_NVS_NONGREEDY);
   c->in_bytes = l.in_total;
   c->out_bytes = l.out_total;
   bool ok = hipMalloc(&c->d_in, c->in_bytes) == hipSuccess && hipMalloc(&c->d_out, c->out_bytes) == hipSuccess &&
@@ -764,15 +766,15 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   if (n < 1 || n > b->U) return fail(RS_ERR_INVALID, "n_users %d outside 1..%d", n, b->U);
   if ((!in->cqi && !in->cqi_prb) || !in->avg_rate) return fail(RS_ERR_INVALID, "null cqi/avg_rate");
   if (!out->rbg_to_user || !out->user_tbs_bits) return fail(RS_ERR_INVALID, "null output array");
-  const CtxLayout l = ctx_layout(n, R, S, b->G);
+  const CtxLayout l = ctx_layout(n, R, S, b->G, b->sched == RS_SCHED_NVS_NONGREEDY);
   uint8_t* h_slice = c->h_in + l.slice;
   for (int i = 0; i < n; i++) {
     int id = in->user_id ? in->user_id[i] : i;
     if (id < 0 || id >= b->U) return fail(RS_ERR_INVALID, "user id %d out of range", id);
     if (i && in->user_id && in->user_id[i] <= in->user_id[i - 1]) return fail(RS_ERR_INVALID, "user_id must ascend");
     h_slice[i] = (uint8_t)b->u2s[id];
-    if (b->sched == RS_SCHED_NVS && h_slice[i] != h_slice[0])
-      return fail(RS_ERR_INVALID, "RS_SCHED_NVS: pass only the users of the served slice");
+    if ((b->sched == RS_SCHED_NVS || b->sched == RS_SCHED_NVS_NONGREEDY) && h_slice[i] != h_slice[0])
+      return fail(RS_ERR_INVALID, "RS_SCHED_NVS*: pass only the users of the served slice");
   }
   const int G = b->G;
   size_t in_bytes = l.prb; /* the per-PRB block travels only when given */
@@ -791,11 +793,19 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   }
   memset(c->h_in + l.grid + (size_t)n * R, 0, l.slice - (size_t)n * R);
   memcpy(c->h_in + l.avg, in->avg_rate, 8 * (size_t)n);
+  if (b->sched == RS_SCHED_NVS_NONGREEDY) {
+    if (!in->rand_draws) return fail(RS_ERR_INVALID, "RS_SCHED_NVS_NONGREEDY needs rand_draws (%d x n_users values)", RS_NVS_SAMPLES);
+    const size_t nd = (size_t)RS_NVS_SAMPLES * n;
+    for (size_t i = 0; i < nd; i++) {
+      if (in->rand_draws[i] < 0) return fail(RS_ERR_INVALID, "rand_draws[%zu] = %d is not a rand() value", i, in->rand_draws[i]);
+      c->h_in[l.draws + i] = (uint8_t)(in->rand_draws[i] % 4); /* downlink-nvs-scheduler.cpp:438 */
+    }
+  }
   if (b->any_alpha) {
     bool need_hol = false;
     for (int i = 0; i < n; i++) {
       const int sl = h_slice[i];
-      need_hol |= b->alpha[sl] && (b->sched == RS_SCHED_NVS || b->beta[sl]);
+      need_hol |= b->alpha[sl] && (b->sched == RS_SCHED_NVS || b->sched == RS_SCHED_NVS_NONGREEDY || b->beta[sl]);
     }
     if (need_hol && !in->hol_delay) return fail(RS_ERR_INVALID, "hol_delay is required by a customised (alpha=1, beta=1) slice");
     if (in->hol_delay) memcpy(c->h_in + l.hol, in->hol_delay, 8 * (size_t)n);
@@ -827,6 +837,7 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   L.queue_mode = b->any_alpha ? 1 : 0;
   L.hol = (const double*)(dev_in + l.hol);
   L.prio = dev_in + l.prio;
+  L.draws = dev_in + l.draws;
   if (b->sched == RS_SCHED_PF) { L.n_seg = (n + RS_PF_SEG - 1) / RS_PF_SEG; L.n_items = R * L.n_seg; }
   L.log_tbs = (int32_t*)(dev_out + l.tbs);
   L.log_uinfo = (int32_t*)(dev_out + l.uinfo);

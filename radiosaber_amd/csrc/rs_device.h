@@ -55,10 +55,18 @@ constexpr int rs_upad_of(int U) {
   int k = (U + 7) / 8;
   return 8 * ((k & 1) ? k : k + 1);
 }
+/* sched 11 (NVS non-greedy sampler) scratch, at off_sortx: val f64[U][4] | hm f64[32][R] | draws u8[8192] |
+ * ha u16[32][R] | pad | high u8[U] */
+#define RS_NVS_SAMPLES 300      /* num_sample, downlink-nvs-scheduler.cpp:430 */
+#define RS_NVS_DRAW_BYTES 8192  /* draws of one batch of samples */
+#define RS_NVS_BATCH 32         /* samples per batch at most */
+constexpr int rs_nvs_scratch_bytes(int U, int R) {
+  return 32 * U + 8 * RS_NVS_BATCH * R + RS_NVS_DRAW_BYTES + 2 * RS_NVS_BATCH * R + 128 + (U + 15) / 16 * 16;
+}
 constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads) {
   RsCarve c{};
   c.Upad = rs_upad_of(U);
-  c.n_seg = sched == 1 ? (U + RS_PF_SEG - 1) / RS_PF_SEG : (sched == 7 ? 1 : S);
+  c.n_seg = sched == 1 ? (U + RS_PF_SEG - 1) / RS_PF_SEG : ((sched == 7 || sched == 11) ? 1 : S);
   c.n_items = R * c.n_seg;
   c.ept = (R * S + threads - 1) / threads;
   int off = 8 * U; /* avg */
@@ -73,7 +81,8 @@ constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads) {
   c.off_sorted = off; off += rs_round_up(4 * R * S, 16);
   c.off_items = off; off += rs_round_up(2 * c.n_items, 16);
   /* level-synchronous introsort scratch: cut per sub-range (+ bounds/pivots when the state lives in LDS) */
-  c.off_sortx = off; off += (sched == 9 || sched == 10) ? rs_round_up((c.ept <= 4 ? 2 : 8) * R * S, 16) : 0;
+  c.off_sortx = off; off += (sched == 9 || sched == 10) ? rs_round_up((c.ept <= 4 ? 2 : 8) * R * S, 16)
+                                                           : (sched == 11 ? rs_round_up(rs_nvs_scratch_bytes(U, R), 16) : 0);
   c.off_cqi = off; off += rs_round_up(c.Upad * R, 16);
   c.lds_bytes = off;
   return c;
@@ -128,6 +137,7 @@ struct RsLaunch {
   const int32_t* beta;       /* [S] */
   const double* hol;         /* [U] head-of-line delay of the slice-priority bearer */
   const uint8_t* prio;       /* [U] prioritized bearer has data (NULL = all) */
+  const uint8_t* draws;      /* sched 11, drop-in mode: rand() % 4 of the RS_NVS_SAMPLES x U draws, in draw order */
   const int32_t* tbs_eff;    /* [R+1][27] TBS bits of n RBGs (n*G PRBs) at itbs, incl. the >110-PRB rule */
   /* state */
   double* avg;               /* [cells][U] */

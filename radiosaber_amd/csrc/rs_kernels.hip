@@ -110,6 +110,31 @@ struct WaveRng {
     if (++b >= 31) b = 0;
     return (int)(v >> 1);
   }
+  /* The next `count` (1..31) ring words at once: lane j < count returns x_j (rand() = x_j >> 1).  With the ring read in
+   * age order old[0..30], x_j = old[j] + x_{j-3}, and x_{j-3} is an old word for j < 3: the new words are prefix sums of
+   * the old ones along the three chains j mod 3, plus the chain's last old word old[28 + j mod 3].  Every lane of the
+   * wave must call it (lane reads are ds_bpermute). */
+  __device__ __forceinline__ uint32_t next_block(int count) {
+    const int lane = (int)(threadIdx.x & 63);
+    int src = f + lane;
+    src = src >= 31 ? src - 31 : src;
+    const uint32_t old = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)r);
+    uint32_t s = lane < 31 ? old : 0u;
+#pragma unroll
+    for (int d = 3; d <= 24; d <<= 1) {
+      const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - d) << 2, (int)s);
+      if (lane >= d) s += t;
+    }
+    const int m3 = lane - 3 * ((lane * 43) >> 7); /* lane mod 3 for lane < 64 */
+    const uint32_t nw = s + (uint32_t)__builtin_amdgcn_ds_bpermute((28 + m3) << 2, (int)old);
+    /* the ring in age order again: the 31 - count youngest old words, then the new ones */
+    const uint32_t keep = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + count) << 2, (int)old);
+    const uint32_t fresh = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - (31 - count)) << 2, (int)nw);
+    r = lane < 31 - count ? keep : fresh;
+    f = 0;
+    b = 28;
+    return nw;
+  }
 };
 
 struct LdsArr {
@@ -654,10 +679,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   for (int i = tid; i < (R * Upad) >> 2; i += nt) ((uint32_t*)s_cqi)[i] = 0;
   for (int i = tid; i < Upad; i += nt) s_rcp32[i] = 0.0f;
   if (tid < 16) {
-    s_num[tid] = SCHED == 1 ? tab->pfnum[tid] : tab->kbps[tid];
+    s_num[tid] = (SCHED == 1 || SCHED == 11) ? tab->pfnum[tid] : tab->kbps[tid];
     s_e[tid] = tab->eesm_e[tid];
     s_x[tid] = tab->eesm_x[tid];
-    s_num32[tid] = (float)(SCHED == 1 ? tab->pfnum[tid] : tab->kbps[tid]);
+    s_num32[tid] = (float)((SCHED == 1 || SCHED == 11) ? tab->pfnum[tid] : tab->kbps[tid]);
     m->mcs_of_cqi[tid] = tab->mcs_of_cqi[tid];
     m->itbs_of_cqi[tid] = tab->itbs_of_cqi[tid];
     m->ones16[tid] = 1.0f;
@@ -778,7 +803,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             const int sl = p.user_slice[u];
             if (p.alpha[sl]) {
               const bool has = p.prio ? p.prio[u] != 0 : true;
-              const bool use_hol = SCHED == 7 || p.beta[sl] != 0;
+              const bool use_hol = SCHED == 7 || SCHED == 11 || p.beta[sl] != 0;
               r32 = !has ? 0.0f : (use_hol ? r32 * (float)p.hol[u] : r32);
             }
           }
@@ -835,7 +860,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
         m->target[lane] = target;
         m->quota[lane] = quota;
-      } else if (SCHED == 7) {
+      } else if (SCHED == 7 || SCHED == 11) {
         /* SelectSliceToServe, ref: downlink-nvs-scheduler.cpp:94-142 */
         int pick;
         if (p.direct) {
@@ -876,14 +901,103 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       }
     }
     int seg_lo = 0; /* NVS: the served slice */
-    if (SCHED == 7) {
+    if (SCHED == 7 || SCHED == 11) {
       __syncthreads(); /* P3 scans the slice P2 picked */
       seg_lo = p.direct ? 0 : m->nvs_slice;
     }
     RS_STAMP(1);
 
+    if constexpr (SCHED == 11) {
+      /* ---------------- NVS non-greedy sampler, ref: downlink-nvs-scheduler.cpp:405-528 ----------------
+       * RS_NVS_SAMPLES times every UE of the served slice draws a CQI index max(highest_cqi - rand() % 4, 1); per sample
+       * every RBG goes to the first UE with the largest eff(index)*180000/(1+avg) among the UEs whose CQI on the RBG
+       * reaches their index (metric 0 otherwise, strict '<' from -1), the sample scores the sum of the winners' metrics
+       * in RBG order, and the first sample with the strictly largest score (from 0) is applied.  The 4 possible metrics
+       * of a UE are computed once; samples run in batches: the generator wave draws a batch (31 ring words per step),
+       * one thread per (sample, RBG) scans the slice, one lane per sample adds up, wave 0 keeps the best. */
+      unsigned char* nv = lds + o.sortx;
+      double* nv_val = (double*)nv;
+      double* nv_hm = (double*)(nv + 32 * U);
+      uint8_t* nv_draw = nv + 32 * U + 8 * RS_NVS_BATCH * R;
+      uint16_t* nv_ha = (uint16_t*)(nv_draw + RS_NVS_DRAW_BYTES);
+      uint8_t* nv_high = (uint8_t*)(nv_ha + RS_NVS_BATCH * R) + 128;
+      int ub = m->seg_begin[seg_lo], ue = m->seg_begin[seg_lo + 1];
+      if (p.direct) { ub = 0; ue = U; }
+      const int n = ue - ub;
+      for (int i = tid; i < n; i += nt) {
+        const int u = ub + i;
+        int h = 0;
+        for (int r = 0; r < R; ++r) { /* :417-424 */
+          const int c = s_cqi[r * Upad + u];
+          h = c > h ? c : h;
+        }
+        nv_high[i] = (uint8_t)h;
+        double rate = 1; /* UserToSchedule::GetAverageTransmissionRate, packet-scheduler.cpp:424-433 */
+        rate += s_avg[u];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int mc = h - k > 1 ? h - k : 1;
+          nv_val[i * 4 + k] = s_num[mc] / rate; /* sEff * 180000 / rate (:519-520) */
+        }
+      }
+      if (tid < R) s_best_user[tid] = 0xFFFF;
+      int bs = RS_NVS_DRAW_BYTES / (n > 0 ? n : 1);
+      bs = bs > RS_NVS_BATCH ? RS_NVS_BATCH : bs;
+      double best = 0; /* wave 0 */
+      for (int b0 = 0; b0 < RS_NVS_SAMPLES; b0 += bs) {
+        const int nb = RS_NVS_SAMPLES - b0 < bs ? RS_NVS_SAMPLES - b0 : bs;
+        const int total = nb * n;
+        if (p.direct) {
+          /* drop-in: the caller passes the rand() values it drew, in draw order */
+          for (int j = tid; j < total; j += nt) nv_draw[j] = (uint8_t)(p.draws[(size_t)b0 * n + j] & 3);
+        } else if (wave == quota_wave) {
+          for (int d0 = 0; d0 < total; d0 += 31) {
+            const int cnt = total - d0 < 31 ? total - d0 : 31;
+            const uint32_t x = rng.next_block(cnt);
+            if (lane < cnt) nv_draw[d0 + lane] = (uint8_t)((x >> 1) & 3u); /* rand() % 4 */
+          }
+        }
+        __syncthreads();
+        for (int it = tid; it < nb * R; it += nt) {
+          const int sl = idiv_small(it, R), r = it - sl * R;
+          const uint8_t* row = s_cqi + r * Upad + ub;
+          const uint8_t* dr = nv_draw + sl * n;
+          double hm = -1.0;
+          int ha = 0xFFFF;
+          for (int i = 0; i < n; ++i) { /* AssignRBsGivenMCS :508-527 */
+            const int d = dr[i], h = nv_high[i];
+            const int mc = h - d > 1 ? h - d : 1;
+            const double metric = mc <= (int)row[i] ? nv_val[i * 4 + d] : 0.0;
+            if (hm < metric) { hm = metric; ha = ub + i; }
+          }
+          nv_hm[it] = hm;
+          nv_ha[it] = (uint16_t)ha;
+        }
+        __syncthreads();
+        if (wave == 0) {
+          double pf = -1.0;
+          if (lane < nb) {
+            pf = 0;
+            for (int r = 0; r < R; ++r) pf += nv_hm[lane * R + r];
+          }
+          double mx = pf;
+#pragma unroll
+          for (int o2 = 32; o2 > 0; o2 >>= 1) {
+            const double ot = __shfl_xor(mx, o2, 64);
+            mx = ot > mx ? ot : mx;
+          }
+          if (best < mx) { /* :442-446: the first sample that reaches the new maximum */
+            best = mx;
+            const int win = __ffsll((long long)__ballot(lane < nb && pf == mx)) - 1;
+            if (lane < R) s_best_user[lane] = nv_ha[win * R + lane];
+          }
+        }
+        __syncthreads();
+      }
+    }
+
     /* ---------------- P3: best user of every (RBG, segment) ---------------- */
-    {
+    if constexpr (SCHED != 11) {
       const int n_items = o.n_items;
       for (int it = tid; it < n_items; it += nt) {
         int sg = it / R, r = it - sg * R; /* r fastest: neighbouring lanes read neighbouring CQI bytes */
@@ -1490,6 +1604,7 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
     case 7: hipLaunchKernelGGL((rs_cell_kernel<7, 0>), grid, block, p->lds_bytes, stream, *p); break;
     case 8: hipLaunchKernelGGL((rs_cell_kernel<8, 0>), grid, block, p->lds_bytes, stream, *p); break;
     case 103: hipLaunchKernelGGL((rs_cell_kernel<103, 0>), grid, block, p->lds_bytes, stream, *p); break;
+    case 11: hipLaunchKernelGGL((rs_cell_kernel<11, 0>), grid, block, p->lds_bytes, stream, *p); break;
     case 10:
       if (ept <= 1) hipLaunchKernelGGL((rs_cell_kernel<10, 1>), grid, block, p->lds_bytes, stream, *p);
       else if (ept <= 2) hipLaunchKernelGGL((rs_cell_kernel<10, 2>), grid, block, p->lds_bytes, stream, *p);
@@ -1511,6 +1626,7 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
 
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes) {
   const void* fns[] = {(const void*)rs_cell_kernel<1, 0>, (const void*)rs_cell_kernel<7, 0>, (const void*)rs_cell_kernel<8, 0>, (const void*)rs_cell_kernel<103, 0>,
+                       (const void*)rs_cell_kernel<11, 0>,
                        (const void*)rs_cell_kernel<10, 1>, (const void*)rs_cell_kernel<10, 2>, (const void*)rs_cell_kernel<10, 3>,
                        (const void*)rs_cell_kernel<10, 4>,
                        (const void*)rs_cell_kernel<9, 0>, (const void*)rs_cell_kernel<9, 1>, (const void*)rs_cell_kernel<9, 2>, (const void*)rs_cell_kernel<9, 3>,

@@ -432,7 +432,7 @@ def test_random_shapes_all_schedulers(rs, oracle, seed):
         R, G = [(25, 4), (64, 8), (12, 2), (50, 2), (17, 3), (33, 3)][int(rng.integers(0, 6))]
         w = rng.uniform(0.2, 1.0, S)
         w = [float(x) for x in w / w.sum()]
-        sched = [9, 9, 9, 8, 7, 1, 103, 10][int(rng.integers(0, 8))]
+        sched = [9, 9, 9, 8, 7, 1, 103, 10, 11][int(rng.integers(0, 9))]
         threads = [0, 64, 128, 256, 512][int(rng.integers(0, 5))]
         if sched == 10 and threads and R * S > 4 * threads:
             threads = 0  # UpperBound needs R*S <= 4 * threads; 0 lets the library choose
@@ -479,3 +479,43 @@ def test_upper_bound_policy_on_the_device(rs, oracle):
     _check_batch(rs, oracle, 10, [4] * 6, 64, 8, n_cells=2, n_ttis=45, threads=128)       # three positions per thread
     with pytest.raises(rs.RadioSaberError, match="exceeds"):
         rs.BatchScheduler(rs.SliceConfig([2] * 64), 64, 8, 1, sched=10)                   # 4 096 records
+
+
+def test_nvs_nongreedy_sampler_on_the_device(rs, oracle):
+    """N4: the CLI's scheduler 11 (DownlinkNVSScheduler, is_nongreedy_; ref: downlink-nvs-scheduler.cpp:405-528): 300 sampled
+    CQI-index vectors per TTI from the libc rand() stream (generated on the device 31 ring words per step), per sample a
+    per-RBG first-maximum scan, the first best sample applied.  Oracle restated from the cited lines (no reference output
+    exists); the device must reproduce it bit for bit, rand() coupling with the error-model draws included."""
+    _check_batch(rs, oracle, 11, [5] * 20, 25, 4, n_cells=3, n_ttis=60)
+    _check_batch(rs, oracle, 11, [5] * 20, 64, 8, n_cells=2, n_ttis=45, phy=1)
+    _check_batch(rs, oracle, 11, [10, 20, 30], 25, 4, n_cells=2, n_ttis=45, phy=1)       # the exp-nongreedy slice sizes
+    _check_batch(rs, oracle, 11, [3, 7, 0, 1, 12], 33, 3, n_cells=2, n_ttis=45)          # ragged, one empty slice
+    _check_batch(rs, oracle, 11, [70, 300], 25, 4, n_cells=1, n_ttis=42, jit=True)       # a batch holds 27 samples of 300 UEs
+    _check_batch(rs, oracle, 11, [30] * 4, 25, 4, n_cells=2, n_ttis=45, jit=True, threads=256)
+
+
+def test_nvs_nongreedy_drop_in(rs, oracle):
+    ues, R, G = [6] * 5, 25, 4
+    sc = rs.SliceConfig(ues)
+    ts = rs.TtiScheduler(sc, R, G, sched=11)
+    cell = oracle.Cell(ues, R, G, 11)
+    rng = np.random.default_rng(21)
+    for it in range(8):
+        cqi = synth_cqi(500 + it, (sc.n_users, R), HIST)
+        avg = rng.uniform(1e3, 5e6, sc.n_users)
+        if it % 3 == 0:
+            avg[:] = 98000.0
+        sl = it % 5
+        ids = np.arange(sl * 6, sl * 6 + 6)
+        draws = rng.integers(0, 2**31 - 1, 300 * len(ids)).astype(np.int32)
+        cell.set_cqi(cqi)
+        out = cell.new_out()
+        assert cell.allocate_nongreedy(avg, sl, draws, out) == 0
+        res = ts.schedule_tti(cqi[ids], avg[ids], user_id=ids, rand_draws=draws)
+        np.testing.assert_array_equal(res.rbg_to_user, out.rbg_to_user)
+        np.testing.assert_array_equal(res.user_nprb, out.user_nprb[ids])
+        np.testing.assert_array_equal(res.user_final_cqi, out.user_final_cqi[ids])
+        np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits[ids])
+    with pytest.raises(rs.RadioSaberError, match="rand_draws"):
+        ts.schedule_tti(cqi[ids], avg[ids], user_id=ids)
+    ts.close()
