@@ -116,9 +116,12 @@ struct WaveRng {
    * wave must call it (lane reads are ds_bpermute). */
   __device__ __forceinline__ uint32_t next_block(int count) {
     const int lane = (int)(threadIdx.x & 63);
-    int src = f + lane;
-    src = src >= 31 ? src - 31 : src;
-    const uint32_t old = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)r);
+    uint32_t old = r;
+    if (f != 0) { /* wave-uniform: only after single draws moved the ring's start */
+      int src = f + lane;
+      src = src >= 31 ? src - 31 : src;
+      old = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)r);
+    }
     uint32_t s = lane < 31 ? old : 0u;
 #pragma unroll
     for (int d = 3; d <= 24; d <<= 1) {
@@ -128,9 +131,13 @@ struct WaveRng {
     const int m3 = lane - 3 * ((lane * 43) >> 7); /* lane mod 3 for lane < 64 */
     const uint32_t nw = s + (uint32_t)__builtin_amdgcn_ds_bpermute((28 + m3) << 2, (int)old);
     /* the ring in age order again: the 31 - count youngest old words, then the new ones */
-    const uint32_t keep = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + count) << 2, (int)old);
-    const uint32_t fresh = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - (31 - count)) << 2, (int)nw);
-    r = lane < 31 - count ? keep : fresh;
+    if (count == 31) { /* wave-uniform */
+      r = nw;
+    } else {
+      const uint32_t keep = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + count) << 2, (int)old);
+      const uint32_t fresh = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - (31 - count)) << 2, (int)nw);
+      r = lane < 31 - count ? keep : fresh;
+    }
     f = 0;
     b = 28;
     return nw;
@@ -941,37 +948,70 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
       }
       if (tid < R) s_best_user[tid] = 0xFFFF;
-      int bs = RS_NVS_DRAW_BYTES / (n > 0 ? n : 1);
+      /* the generator wave draws batch b+1 into the other half of the draw buffer while the other waves scan batch b */
+      const bool overlap = !p.direct && nwaves > 1;
+      const int half = RS_NVS_DRAW_BYTES / 2;
+      int bs = (overlap ? half : RS_NVS_DRAW_BYTES) / (n > 0 ? n : 1);
       bs = bs > RS_NVS_BATCH ? RS_NVS_BATCH : bs;
+      auto draw_batch = [&](int b0, uint8_t* dst) { /* generator wave only */
+        const int nbb = RS_NVS_SAMPLES - b0 < bs ? RS_NVS_SAMPLES - b0 : bs;
+        const int total = nbb * n;
+        for (int d0 = 0; d0 < total; d0 += 31) {
+          const int cnt = total - d0 < 31 ? total - d0 : 31;
+          const uint32_t x = rng.next_block(cnt);
+          if (lane < cnt) dst[d0 + lane] = (uint8_t)((x >> 1) & 3u); /* rand() % 4 */
+        }
+      };
+      if (overlap && wave == quota_wave) draw_batch(0, nv_draw);
+      __syncthreads();
       double best = 0; /* wave 0 */
-      for (int b0 = 0; b0 < RS_NVS_SAMPLES; b0 += bs) {
+      int flip = 0;
+      for (int b0 = 0; b0 < RS_NVS_SAMPLES; b0 += bs, flip ^= 1) {
         const int nb = RS_NVS_SAMPLES - b0 < bs ? RS_NVS_SAMPLES - b0 : bs;
         const int total = nb * n;
+        const uint8_t* cur = overlap ? nv_draw + flip * half : nv_draw;
         if (p.direct) {
           /* drop-in: the caller passes the rand() values it drew, in draw order */
           for (int j = tid; j < total; j += nt) nv_draw[j] = (uint8_t)(p.draws[(size_t)b0 * n + j] & 3);
-        } else if (wave == quota_wave) {
-          for (int d0 = 0; d0 < total; d0 += 31) {
-            const int cnt = total - d0 < 31 ? total - d0 : 31;
-            const uint32_t x = rng.next_block(cnt);
-            if (lane < cnt) nv_draw[d0 + lane] = (uint8_t)((x >> 1) & 3u); /* rand() % 4 */
-          }
+          __syncthreads();
+        } else if (!overlap) {
+          if (wave == quota_wave) draw_batch(b0, nv_draw);
+          __syncthreads();
         }
-        __syncthreads();
-        for (int it = tid; it < nb * R; it += nt) {
-          const int sl = idiv_small(it, R), r = it - sl * R;
-          const uint8_t* row = s_cqi + r * Upad + ub;
-          const uint8_t* dr = nv_draw + sl * n;
-          double hm = -1.0;
-          int ha = 0xFFFF;
-          for (int i = 0; i < n; ++i) { /* AssignRBsGivenMCS :508-527 */
-            const int d = dr[i], h = nv_high[i];
-            const int mc = h - d > 1 ? h - d : 1;
-            const double metric = mc <= (int)row[i] ? nv_val[i * 4 + d] : 0.0;
-            if (hm < metric) { hm = metric; ha = ub + i; }
+        if (overlap && wave == quota_wave) {
+          if (b0 + bs < RS_NVS_SAMPLES) draw_batch(b0 + bs, nv_draw + (flip ^ 1) * half);
+        } else {
+          const int first = tid, step = overlap ? nt - 64 : nt; /* the generator is the last wave */
+          for (int it = first; it < nb * R; it += step) {
+            const int sl = idiv_small(it, R), r = it - sl * R;
+            const uint8_t* row = s_cqi + r * Upad + ub;
+            const uint8_t* dr = cur + sl * n;
+            double hm = -1.0;
+            int ha = 0xFFFF;
+            int i = 0;
+            for (; i + 4 <= n; i += 4) { /* AssignRBsGivenMCS :508-527, four users per step: the loads first */
+              int d[4], h[4], cq[4];
+              double vv[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { d[q] = dr[i + q]; h[q] = nv_high[i + q]; cq[q] = row[i + q]; }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) vv[q] = nv_val[(i + q) * 4 + d[q]];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int mc = h[q] - d[q] > 1 ? h[q] - d[q] : 1;
+                const double metric = mc <= cq[q] ? vv[q] : 0.0;
+                if (hm < metric) { hm = metric; ha = ub + i + q; }
+              }
+            }
+            for (; i < n; ++i) {
+              const int d = dr[i], h = nv_high[i];
+              const int mc = h - d > 1 ? h - d : 1;
+              const double metric = mc <= (int)row[i] ? nv_val[i * 4 + d] : 0.0;
+              if (hm < metric) { hm = metric; ha = ub + i; }
+            }
+            nv_hm[it] = hm;
+            nv_ha[it] = (uint16_t)ha;
           }
-          nv_hm[it] = hm;
-          nv_ha[it] = (uint16_t)ha;
         }
         __syncthreads();
         if (wave == 0) {
