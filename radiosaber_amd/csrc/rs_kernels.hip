@@ -33,571 +33,10 @@
 
 #include "rs_device.h"
 #include "rs_sort_emul.h"
+#include "rs_wave.h"
+#include "rs_sort_device.h"
 
 namespace {
-
-typedef RsMisc Misc;
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
-
-/* wave64 reductions on the DPP network (row_shr 1/2/4/8 inside rows of 16, then row_bcast15 and
- * row_bcast31 across rows); the total lands in lane 63 and is broadcast with v_readlane.
- * A lane masked off by the bank/row mask contributes the identity. */
-#define RS_DPP_STEP(OP, ctrl, rmask, bmask) \
-  v = OP(v, __builtin_amdgcn_update_dpp(identity, v, ctrl, rmask, bmask, false))
-__device__ __forceinline__ int op_add(int a, int b) { return a + b; }
-__device__ __forceinline__ int op_max(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int op_min(int a, int b) { return a < b ? a : b; }
-#define RS_DEFINE_WAVE_REDUCE(NAME, OP, IDENT)                 \
-  __device__ __forceinline__ int NAME(int v) {                 \
-    const int identity = IDENT;                                \
-    RS_DPP_STEP(OP, 0x111, 0xf, 0xf); /* row_shr:1 */          \
-    RS_DPP_STEP(OP, 0x112, 0xf, 0xf); /* row_shr:2 */          \
-    RS_DPP_STEP(OP, 0x114, 0xf, 0xe); /* row_shr:4 */          \
-    RS_DPP_STEP(OP, 0x118, 0xf, 0xc); /* row_shr:8 */          \
-    RS_DPP_STEP(OP, 0x142, 0xa, 0xf); /* row_bcast:15 */       \
-    RS_DPP_STEP(OP, 0x143, 0xc, 0xf); /* row_bcast:31 */       \
-    return __builtin_amdgcn_readlane(v, 63);                   \
-  }
-RS_DEFINE_WAVE_REDUCE(wave_sum, op_add, 0)
-RS_DEFINE_WAVE_REDUCE(wave_max, op_max, (int)0x80000000)
-RS_DEFINE_WAVE_REDUCE(wave_min, op_min, 0x7fffffff)
-
-/* lanes that hold the same BITS-bit value as this lane (valid lanes only): one ballot per bit */
-template <int BITS>
-struct BitBallots {
-  unsigned long long valid, b[BITS];
-  __device__ __forceinline__ void gather(int v, bool is_valid) {
-    valid = __ballot(is_valid);
-#pragma unroll
-    for (int i = 0; i < BITS; ++i) b[i] = __ballot(((v >> i) & 1) != 0);
-  }
-  __device__ __forceinline__ unsigned long long lanes_with(int v) const {
-    unsigned long long mk = valid;
-#pragma unroll
-    for (int i = 0; i < BITS; ++i) mk &= ((v >> i) & 1) ? b[i] : ~b[i];
-    return mk;
-  }
-};
-
-/* C integer division (truncation toward zero) for |a| < 2^20, 1 <= b <= 512: one correctly rounded
- * FP32 division instead of the ~35-instruction integer sequence; the fix-up makes it exact whatever
- * the rounding did. */
-__device__ __forceinline__ int idiv_small(int a, int b) {
-  int q = (int)((float)a / (float)b);
-  int r = a - q * b;
-  if (a >= 0) {
-    if (r < 0) q--; else if (r >= b) q++;
-  } else {
-    if (r > 0) q++; else if (r <= -b) q--;
-  }
-  return q;
-}
-
-/* glibc TYPE_3 rand(): ring of 31 words held one per lane of one wave (lane l = r[l]); f, b uniform.
- * (glibc 2.35 stdlib/random_r.c __random_r; the reference draws from libc rand():
- *  downlink-transport-scheduler.cpp:490,511) */
-struct WaveRng {
-  uint32_t r; /* this lane's ring word */
-  int f, b;   /* wave-uniform */
-  __device__ __forceinline__ int next() {
-    uint32_t vf = __builtin_amdgcn_readlane(r, f);
-    uint32_t vb = __builtin_amdgcn_readlane(r, b);
-    uint32_t v = vf + vb;
-    r = ((int)(threadIdx.x & 63) == f) ? v : r;
-    if (++f >= 31) f = 0;
-    if (++b >= 31) b = 0;
-    return (int)(v >> 1);
-  }
-  /* The next `count` (1..31) ring words at once: lane j < count returns x_j (rand() = x_j >> 1).  With the ring read in
-   * age order old[0..30], x_j = old[j] + x_{j-3}, and x_{j-3} is an old word for j < 3: the new words are prefix sums of
-   * the old ones along the three chains j mod 3, plus the chain's last old word old[28 + j mod 3].  Every lane of the
-   * wave must call it (lane reads are ds_bpermute). */
-  __device__ __forceinline__ uint32_t next_block(int count) {
-    const int lane = (int)(threadIdx.x & 63);
-    uint32_t old = r;
-    if (f != 0) { /* wave-uniform: only after single draws moved the ring's start */
-      int src = f + lane;
-      src = src >= 31 ? src - 31 : src;
-      old = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)r);
-    }
-    uint32_t s = lane < 31 ? old : 0u;
-#pragma unroll
-    for (int d = 3; d <= 24; d <<= 1) {
-      const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - d) << 2, (int)s);
-      if (lane >= d) s += t;
-    }
-    const int m3 = lane - 3 * ((lane * 43) >> 7); /* lane mod 3 for lane < 64 */
-    const uint32_t nw = s + (uint32_t)__builtin_amdgcn_ds_bpermute((28 + m3) << 2, (int)old);
-    /* the ring in age order again: the 31 - count youngest old words, then the new ones */
-    if (count == 31) { /* wave-uniform */
-      r = nw;
-    } else {
-      const uint32_t keep = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + count) << 2, (int)old);
-      const uint32_t fresh = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - (31 - count)) << 2, (int)nw);
-      r = lane < 31 - count ? keep : fresh;
-    }
-    f = 0;
-    b = 28;
-    return nw;
-  }
-};
-
-struct LdsArr {
-  uint32_t* p;
-  __device__ __forceinline__ uint32_t& operator[](int i) { return p[i]; }
-};
-struct LdsInt {
-  int32_t* p;
-  __device__ __forceinline__ int32_t& operator[](int i) { return p[i]; }
-};
-
-}  // namespace
-
-/*
- * std::__introsort_loop, level-synchronous over the whole workgroup (the default path).
- * All sub-ranges of one recursion level are partitioned at once, one array position per lane:
- *   M  the lane sitting on a sub-range's first position moves the median of 3 there and publishes
- *      the pivot key (depth 0: it heap-sorts the sub-range instead, as the library does)
- *   F  every position compares with ITS sub-range's pivot; per 64-position chunk two ballots
- *      ("left-scan stop" key <= pivot, "right-scan stop" key >= pivot) go to LDS
- *   R  popcounts over the chunk masks give each stop its rank inside its sub-range:
- *      posA[first + rank from the left] / posB[first + rank from the right]  (= L and Rr)
- *   S  lane j of a sub-range swaps (L[j], Rr[j]) while L[j] < Rr[j]; the lane at the boundary
- *      publishes the cut  L[0] | min(L[k], Rr[k-1])
- *   U  every position moves to its child sub-range [first,cut) or [cut,last); children of at
- *      most 16 elements retire
- * Four workgroup barriers per level, no queue, cost independent of the number of sub-ranges.
- */
-__device__ __forceinline__ int count_bits_in(const unsigned long long* masks, int lo, int hi) {
-  /* number of set mask bits at positions [lo, hi) */
-  if (hi <= lo) return 0;
-  const int c0 = lo >> 6, c1 = (hi - 1) >> 6;
-  int total = 0;
-  for (int c = c0; c <= c1; ++c) {
-    unsigned long long mk = masks[c];
-    if (c == c0) mk &= ~0ull << (lo & 63);
-    if (c == c1) {
-      const int h = ((hi - 1) & 63) + 1;
-      if (h < 64) mk &= (1ull << h) - 1ull;
-    }
-    total += __popcll(mk);
-  }
-  return total;
-}
-
-__device__ void introsort_loop_levels(uint32_t* v, int N, uint16_t* posA, uint16_t* posB, uint16_t* segF,
-                                      uint16_t* segL, uint16_t* pkbuf, uint16_t* cutbuf, Misc* m) {
-  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
-  const int n_chunks = (N + 63) >> 6;
-  for (int x = tid; x < N; x += nt) {
-    segF[x] = 0;
-    segL[x] = (uint16_t)(N > 16 ? N : 0);
-  }
-  if (tid < 48) m->n_level[tid] = (tid == 0 && N > 16) ? 1 : 0;
-  int depth = 2 * rs_sort::floor_log2(N > 1 ? N : 1);
-  for (int level = 0; level < 47; ++level, --depth) {
-    /* M */
-    for (int x = tid; x < N; x += nt) {
-      const int L = segL[x];
-      if (L != 0 && segF[x] == x) {
-        LdsArr a{v};
-        if (depth == 0) {
-          rs_sort::heap_sort(a, x, L);
-        } else {
-          rs_sort::median_to_first(a, x, x + 1, x + (L - x) / 2, L - 1);
-          pkbuf[x] = (uint16_t)(v[x] >> 16);
-        }
-      }
-    }
-    __syncthreads();
-    if (m->n_level[level] == 0 || depth == 0) break;
-    /* F */
-    for (int c = wave; c < n_chunks; c += nwaves) {
-      const int x = (c << 6) + lane;
-      const int L = x < N ? (int)segL[x] : 0;
-      const int F = x < N ? (int)segF[x] : 0;
-      const int k = x < N ? (int)(v[x] >> 16) : 0;
-      const bool in = L != 0 && x > F;
-      const int pk = in ? (int)pkbuf[F] : 0;
-      const unsigned long long mA = __ballot(in && k <= pk), mB = __ballot(in && k >= pk);
-      if (lane == 0) {
-        m->maskA[c] = mA;
-        m->maskB[c] = mB;
-      }
-      if (x < N) {
-        posA[x] = 0xFFFF;
-        posB[x] = 0xFFFF;
-      }
-    }
-    __syncthreads();
-    /* R */
-    for (int c = wave; c < n_chunks; c += nwaves) {
-      const int x = (c << 6) + lane;
-      const int L = x < N ? (int)segL[x] : 0;
-      const int F = x < N ? (int)segF[x] : 0;
-      const int k = x < N ? (int)(v[x] >> 16) : 0;
-      const bool in = L != 0 && x > F;
-      const int pk = in ? (int)pkbuf[F] : 0;
-      if (in && k <= pk) posA[F + count_bits_in(m->maskA, F + 1, x)] = (uint16_t)x;
-      if (in && k >= pk) posB[F + count_bits_in(m->maskB, x + 1, L)] = (uint16_t)x;
-    }
-    __syncthreads();
-    /* S */
-    for (int x = tid; x < N; x += nt) {
-      const int L = segL[x], F = segF[x];
-      if (L != 0 && x > F) {
-        const int j = x - F - 1;
-        const int l = posA[F + j], r = posB[F + j];
-        const int l1 = posA[F + j + 1], r1 = posB[F + j + 1]; /* index <= L-1: inside the sub-range */
-        const bool sw = l != 0xFFFF && r != 0xFFFF && l < r;
-        const bool sw1 = l1 != 0xFFFF && r1 != 0xFFFF && l1 < r1;
-        if (sw) {
-          const uint32_t a = v[l], b = v[r];
-          v[l] = b;
-          v[r] = a;
-          if (!sw1) cutbuf[F] = (uint16_t)((l1 != 0xFFFF && l1 < r) ? l1 : r);
-        } else if (j == 0) {
-          cutbuf[F] = (uint16_t)l;
-        }
-      }
-    }
-    __syncthreads();
-    /* U */
-    bool any = false;
-    for (int x = tid; x < N; x += nt) {
-      const int L = segL[x];
-      if (L != 0) {
-        const int F = segF[x];
-        const int cut = cutbuf[F];
-        const int nF = x < cut ? F : cut;
-        int nL = x < cut ? cut : L;
-        if (nL - nF <= 16) nL = 0;
-        segF[x] = (uint16_t)nF;
-        segL[x] = (uint16_t)nL;
-        any |= nL != 0;
-      }
-    }
-    if (__ballot(any) && lane == 0) atomicAdd(&m->n_level[level + 1], 1);
-  }
-}
-
-/*
- * The same level-synchronous loop with the per-position state (element, sub-range bounds) held in
- * registers: EPT positions per thread, position x = i*blockDim + tid (so a wave still covers one
- * 64-position chunk per i).  Every lane of a sub-range reads the three median samples itself, so
- * the pivot is known without a publishing step; three workgroup barriers per level.
- */
-__device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
-  /* bits [lo, hi) of a 64-bit mask, 0 <= lo, hi <= 64 */
-  if (hi <= lo) return 0ull;
-  const unsigned long long upto_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
-  return upto_hi & (~0ull << lo);
-}
-
-#ifdef RS_STAMPS
-#define RS_SUBSTAMP(i)                                            \
-  do {                                                            \
-    if (tid == 0) {                                               \
-      unsigned long long now_ = __builtin_readcyclecounter();     \
-      sub[i] += now_ - sub_prev;                                  \
-      sub_prev = now_;                                            \
-    }                                                             \
-  } while (0)
-#else
-#define RS_SUBSTAMP(i) do { } while (0)
-#endif
-
-/* inclusive wave64 prefix sum (same DPP ladder as the reductions; every lane keeps its partial) */
-__device__ __forceinline__ int wave_scan_incl(int v) {
-  const int identity = 0;
-  RS_DPP_STEP(op_add, 0x111, 0xf, 0xf); /* row_shr:1 */
-  RS_DPP_STEP(op_add, 0x112, 0xf, 0xf); /* row_shr:2 */
-  RS_DPP_STEP(op_add, 0x114, 0xf, 0xe); /* row_shr:4 */
-  RS_DPP_STEP(op_add, 0x118, 0xf, 0xc); /* row_shr:8 */
-  RS_DPP_STEP(op_add, 0x142, 0xa, 0xf); /* row_bcast:15 */
-  RS_DPP_STEP(op_add, 0x143, 0xc, 0xf); /* row_bcast:31 */
-  return v;
-}
-
-/* inclusive wave64 prefix maximum */
-__device__ __forceinline__ int wave_scan_max_incl(int v) {
-  const int identity = (int)0x80000000;
-  RS_DPP_STEP(op_max, 0x111, 0xf, 0xf);
-  RS_DPP_STEP(op_max, 0x112, 0xf, 0xf);
-  RS_DPP_STEP(op_max, 0x114, 0xf, 0xe);
-  RS_DPP_STEP(op_max, 0x118, 0xf, 0xc);
-  RS_DPP_STEP(op_max, 0x142, 0xa, 0xf);
-  RS_DPP_STEP(op_max, 0x143, 0xc, 0xf);
-  return v;
-}
-
-/*
- * One std::__unguarded_partition per live sub-range and level, decided locally from stop counts.
- * In [lo, hi) = (f, l) with pivot key pk, an A-stop is an element with key <= pk (where the upward scan
- * halts), a B-stop one with key >= pk (downward scan).  With A(x) = A-stops in [lo, x) and B(x) = B-stops in
- * (x, hi): the library swaps the j-th A-stop from the left with the j-th B-stop from the right while the
- * former lies left of the latter, so
- *     an A-stop x is swapped  <=>  B(x) > A(x)   (it receives the element of B-stop number A(x) from the right)
- *     a  B-stop x is swapped  <=>  A(x) > B(x)   (it receives the element of A-stop number B(x) from the left)
- * and the returned cut is the leftmost position that is an unswapped A-stop or a swapped B-stop.
- * Swapped elements travel through `xbuf` (A-stop number a at f+a, B-stop number b at l-1-b: they cannot
- * meet, a + b <= len - 3); the cut is an LDS atomicMin per sub-range (slot f>>4: live sub-ranges are longer
- * than 16, so their slots differ).  Counts come from per-chunk ballots + one prefix scan per wave.
- */
-template <int EPT>
-__device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t* cuts, Misc* m,
-                                     unsigned long long* sub, int seg_len = 0) {
-  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
-#ifdef RS_STAMPS
-  unsigned long long sub_prev = __builtin_readcyclecounter();
-#endif
-  const int n_chunks = (N + 63) >> 6;
-  const unsigned long long lt_lane = (1ull << lane) - 1ull, le_lane = ~0ull >> (63 - lane);
-  uint32_t e[EPT];
-  int F[EPT], L[EPT];
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    const int x = i * nt + tid;
-    e[i] = x < N ? v[x] : 0u;
-    if (seg_len == 0) {
-      F[i] = 0;
-      L[i] = (x < N && N > 16) ? N : 0;
-    } else {
-      /* seg_len > 0: the array is a row of independent std::sort calls, seg_len elements each (UpperBound) */
-      F[i] = idiv_small(x, seg_len) * seg_len;
-      L[i] = (x < N && seg_len > 16) ? F[i] + seg_len : 0;
-    }
-  }
-  const int n_first = seg_len == 0 ? N : seg_len; /* length every std::sort call starts from */
-  if (tid < 48) m->n_level[tid] = (tid == 0 && n_first > 16) ? 1 : 0;
-  int depth = 2 * rs_sort::floor_log2(n_first > 1 ? n_first : 1);
-  __syncthreads();
-  for (int level = 0; level < 47; ++level, --depth) {
-    if (depth == 0) {
-      /* std::__partial_sort fallback for every sub-range still longer than 16 */
-#pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        const int x = i * nt + tid;
-        if (L[i] != 0 && F[i] == x) {
-          LdsArr a{v};
-          rs_sort::heap_sort(a, x, L[i]);
-        }
-      }
-      __syncthreads();
-      break;
-    }
-    /* F: pivot of my sub-range (median of 3, std::__move_median_to_first), stop ballots */
-    unsigned long long mAi[EPT], mBi[EPT];
-    bool isA[EPT], isB[EPT], moved[EPT];
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int x = i * nt + tid;
-      const int c = i * nwaves + wave;
-      const bool active = L[i] != 0;
-      int pk = 0;
-      moved[i] = false;
-      if (active) {
-        const int f = F[i], l = L[i];
-        const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
-        uint32_t s0 = v[f];
-        const uint32_t sa = v[ia], sb = v[ib], sc = v[ic];
-        asm volatile("" : "+v"(s0)); /* keep the four LDS reads in one batch (one latency, not two) */
-        int pick;
-        uint32_t sp;
-        if (rs_sort::before(sa, sb)) {
-          if (rs_sort::before(sb, sc)) { pick = ib; sp = sb; }
-          else if (rs_sort::before(sa, sc)) { pick = ic; sp = sc; }
-          else { pick = ia; sp = sa; }
-        } else if (rs_sort::before(sa, sc)) { pick = ia; sp = sa; }
-        else if (rs_sort::before(sb, sc)) { pick = ic; sp = sc; }
-        else { pick = ib; sp = sb; }
-        pk = (int)(sp >> 16);
-        if (x == f) { e[i] = sp; moved[i] = true; cuts[f >> 4] = 0x7fffffff; }
-        else if (x == pick) { e[i] = s0; moved[i] = true; }
-      }
-      const int k = (int)(e[i] >> 16);
-      const bool in = active && x > F[i];
-      isA[i] = in && k <= pk;
-      isB[i] = in && k >= pk;
-      mAi[i] = __ballot(isA[i]);
-      mBi[i] = __ballot(isB[i]);
-      if (lane == 0 && c < n_chunks) {
-        m->maskA[c] = mAi[i];
-        m->maskB[c] = mBi[i];
-      }
-    }
-    RS_SUBSTAMP(0);
-    __syncthreads();
-    RS_SUBSTAMP(1);
-    if (m->n_level[level] == 0) break;
-    /* R: stop counts -> swap decision; swapped elements to the exchange buffer, cut candidates to the slot */
-    int pre; /* lane c: stops in chunks < c, A-stops in the low half, B-stops in the high half */
-    {
-      int cnt = 0;
-      if (lane < n_chunks) cnt = __popcll(m->maskA[lane]) | (__popcll(m->maskB[lane]) << 16);
-      pre = wave_scan_incl(cnt) - cnt;
-    }
-    int slot[EPT]; /* where my element went / where its replacement arrives; -1: not swapped */
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int x = i * nt + tid;
-      const int c = i * nwaves + wave;
-      if (moved[i]) v[x] = e[i];
-      /* counts are taken by every lane: ds_bpermute returns 0 for a source lane that is masked off */
-      const int lo = F[i] + 1, hm = L[i] != 0 ? L[i] - 1 : 0;
-      const int wlo = lo >> 6, whi = hm >> 6;
-      const int plo = __builtin_amdgcn_ds_bpermute(wlo << 2, pre) & 0xffff;
-      const int phi = (int)((unsigned)__builtin_amdgcn_ds_bpermute(whi << 2, pre) >> 16);
-      const unsigned long long mlo = m->maskA[wlo], mhi = m->maskB[whi];
-      const int pc = __builtin_amdgcn_readlane(pre, c & 63);
-      const int a = (pc & 0xffff) + __popcll(mAi[i] & lt_lane) - plo - __popcll(mlo & ((1ull << (lo & 63)) - 1ull));
-      const int b = phi + __popcll(mhi & (~0ull >> (63 - (hm & 63)))) - (int)((unsigned)pc >> 16) - __popcll(mBi[i] & le_lane);
-      const bool swA = isA[i] & (b > a), swB = isB[i] & (a > b); /* never both: b > a excludes a > b */
-      slot[i] = (swA | swB) ? (swA ? F[i] + a : hm - b) : -1;
-      if (swA | swB) xbuf[slot[i]] = e[i];
-      const bool cand = (isA[i] & !swA) | swB;
-      /* leftmost candidate of its sub-range inside this chunk reports */
-      const unsigned long long mC = __ballot(cand);
-      const int lo_in = lo - (c << 6);
-      if (cand && (mC & bit_range(lo_in > 0 ? lo_in : 0, lane)) == 0ull) atomicMin(&cuts[F[i] >> 4], x);
-    }
-    RS_SUBSTAMP(2);
-    __syncthreads();
-    RS_SUBSTAMP(3);
-    /* S: receive the swapped element, then move to the child sub-range; sub-ranges of at most 16 retire */
-    bool any = false;
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int x = i * nt + tid;
-      if (L[i] != 0) {
-        const int cut = cuts[F[i] >> 4];
-        if (slot[i] >= 0) {
-          /* an A-stop's slot f+a pairs with B-stop slot l-1-a and vice versa */
-          e[i] = xbuf[F[i] + L[i] - 1 - slot[i]];
-          v[x] = e[i];
-        }
-        if (x < cut) L[i] = cut; else F[i] = cut;
-        if (L[i] - F[i] <= 16) L[i] = 0;
-        any |= L[i] != 0;
-      }
-    }
-    if (__ballot(any) && lane == 0) atomicAdd(&m->n_level[level + 1], 1);
-    RS_SUBSTAMP(4);
-    __syncthreads();
-    RS_SUBSTAMP(5);
-#ifdef RS_STAMPS
-    if (tid == 0) sub[7] += 1;
-#endif
-  }
-}
-
-/*
- * std::__final_insertion_sort == stable sort of the array the introsort loop leaves (a stable order
- * is unique): 16-bucket stable counting sort by DESCENDING key, all waves.
- *   A  every wave, for its 64-element chunks: per-key counts (lane q holds key q) -> hist[chunk][q]
- *   B  wave 0: hist[chunk][q] <- first output slot of key q in that chunk
- *   C  every wave: slot = hist[chunk][key] + (same-key lanes below me); scatter to `out`
- */
-__device__ void counting_sort_desc(const uint32_t* v, uint32_t* out, int N, Misc* m) {
-  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
-  const int n_chunks = (N + 63) >> 6;
-  for (int c = wave; c < n_chunks; c += nwaves) {
-    const int i = (c << 6) + lane;
-    const int k = i < N ? (int)(v[i] >> 16) : 0;
-    BitBallots<4> bb;
-    bb.gather(k, i < N);
-    if (lane < 16) m->hist[c * 16 + lane] = (uint16_t)__popcll(bb.lanes_with(lane));
-  }
-  __syncthreads();
-  if (wave == 0) {
-    int total = 0;
-    if (lane < 16)
-      for (int c = 0; c < n_chunks; ++c) total += m->hist[c * 16 + lane];
-    int run = 0, acc = 0;
-#pragma unroll
-    for (int q = 15; q >= 0; --q) {
-      int tq = __builtin_amdgcn_readlane(total, q);
-      if (lane == q) run = acc;
-      acc += tq;
-    }
-    if (lane < 16)
-      for (int c = 0; c < n_chunks; ++c) {
-        int h = m->hist[c * 16 + lane];
-        m->hist[c * 16 + lane] = (uint16_t)run;
-        run += h;
-      }
-  }
-  __syncthreads();
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int c = wave; c < n_chunks; c += nwaves) {
-    const int i = (c << 6) + lane;
-    const uint32_t e = i < N ? v[i] : 0;
-    const int k = (int)(e >> 16);
-    BitBallots<4> bb;
-    bb.gather(k, i < N);
-    const int rank = __popcll(bb.lanes_with(k) & lt);
-    if (i < N) out[m->hist[c * 16 + k] + rank] = e;
-  }
-  __syncthreads();
-}
-
-/* The same stable counting sort when every wave owns at most CPW chunks (chunk j*nwaves + wave, like the
- * register introsort): one ballot pass gives both the per-chunk counts and every element's rank among
- * equal keys in its chunk; after one barrier every wave derives the output offsets of its own chunks
- * from the count table (lane q = key q), so there is no single-wave step and no second barrier. */
-template <int CPW>
-__device__ __forceinline__ void counting_sort_desc_owned(const uint32_t* v, uint32_t* out, int N, Misc* m) {
-  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
-  const int n_chunks = (N + 63) >> 6;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  uint32_t e[CPW];
-  int rank[CPW];
-#pragma unroll
-  for (int j = 0; j < CPW; ++j) {
-    const int c = j * nwaves + wave, i = (c << 6) + lane;
-    const bool valid = c < n_chunks && i < N;
-    e[j] = valid ? v[i] : 0u;
-    BitBallots<4> bb;
-    bb.gather((int)(e[j] >> 16), valid);
-    rank[j] = __popcll(bb.lanes_with((int)(e[j] >> 16)) & lt);
-    if (lane < 16 && c < n_chunks) m->hist[c * 16 + lane] = (uint16_t)__popcll(bb.lanes_with(lane));
-  }
-  __syncthreads();
-  int total = 0, below[CPW];
-#pragma unroll
-  for (int j = 0; j < CPW; ++j) below[j] = 0;
-  if (lane < 16)
-    for (int c = 0; c < n_chunks; ++c) {
-      const int h = m->hist[c * 16 + lane];
-#pragma unroll
-      for (int j = 0; j < CPW; ++j) below[j] += c < j * nwaves + wave ? h : 0;
-      total += h;
-    }
-  /* elements with a larger key come first: lane q needs the sum of total over keys > q */
-  int inc = total;
-  {
-    int v_ = inc;
-    const int identity = 0;
-#define RS_ROW_STEP(ctrl, bmask) v_ = v_ + __builtin_amdgcn_update_dpp(identity, v_, ctrl, 0xf, bmask, false)
-    RS_ROW_STEP(0x111, 0xf);
-    RS_ROW_STEP(0x112, 0xf);
-    RS_ROW_STEP(0x114, 0xe);
-    RS_ROW_STEP(0x118, 0xc);
-#undef RS_ROW_STEP
-    inc = v_;
-  }
-  const int all = __builtin_amdgcn_readlane(inc, 15);
-#pragma unroll
-  for (int j = 0; j < CPW; ++j) {
-    const int c = j * nwaves + wave, i = (c << 6) + lane;
-    const int base_q = all - inc + below[j]; /* lane q < 16 */
-    const int base = __builtin_amdgcn_ds_bpermute((int)(e[j] >> 16) << 2, base_q); /* every lane: no branch around it */
-    if (c < n_chunks && i < N) out[base + rank[j]] = e[j];
-  }
-  __syncthreads();
-}
 
 #ifndef RS_P3_BLOCK
 #define RS_P3_BLOCK 32 /* users ranked per stage-1 block (multiple of 8, <= 32) */
@@ -1552,6 +991,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     scal->rng_b = rng.b;
   }
 }
+
+}  // namespace
 
 #ifndef RS_JIT_BUILD
 template <int SCHED, int EPT>

@@ -1,0 +1,440 @@
+/*
+ * rs_sort_device.h -- the device side of the exact std::sort emulation: the level-synchronous
+ * std::__introsort_loop over a whole workgroup (state in LDS for any size, or in registers with EPT array positions per
+ * thread) and the stable 16-bucket counting sort that stands for std::__final_insertion_sort.  The serial pieces
+ * (median of three, heap-sort fallback) come from rs_sort_emul.h, which the CPU tests run against the real std::sort.
+ * Device-only fragment of rs_kernels.hip.
+ */
+#ifndef RS_SORT_DEVICE_H_
+#define RS_SORT_DEVICE_H_
+
+#include "rs_sort_emul.h"
+#include "rs_wave.h"
+
+namespace {
+
+/*
+ * std::__introsort_loop, level-synchronous over the whole workgroup (the default path).
+ * All sub-ranges of one recursion level are partitioned at once, one array position per lane:
+ *   M  the lane sitting on a sub-range's first position moves the median of 3 there and publishes
+ *      the pivot key (depth 0: it heap-sorts the sub-range instead, as the library does)
+ *   F  every position compares with ITS sub-range's pivot; per 64-position chunk two ballots
+ *      ("left-scan stop" key <= pivot, "right-scan stop" key >= pivot) go to LDS
+ *   R  popcounts over the chunk masks give each stop its rank inside its sub-range:
+ *      posA[first + rank from the left] / posB[first + rank from the right]  (= L and Rr)
+ *   S  lane j of a sub-range swaps (L[j], Rr[j]) while L[j] < Rr[j]; the lane at the boundary
+ *      publishes the cut  L[0] | min(L[k], Rr[k-1])
+ *   U  every position moves to its child sub-range [first,cut) or [cut,last); children of at
+ *      most 16 elements retire
+ * Four workgroup barriers per level, no queue, cost independent of the number of sub-ranges.
+ */
+__device__ __forceinline__ int count_bits_in(const unsigned long long* masks, int lo, int hi) {
+  /* number of set mask bits at positions [lo, hi) */
+  if (hi <= lo) return 0;
+  const int c0 = lo >> 6, c1 = (hi - 1) >> 6;
+  int total = 0;
+  for (int c = c0; c <= c1; ++c) {
+    unsigned long long mk = masks[c];
+    if (c == c0) mk &= ~0ull << (lo & 63);
+    if (c == c1) {
+      const int h = ((hi - 1) & 63) + 1;
+      if (h < 64) mk &= (1ull << h) - 1ull;
+    }
+    total += __popcll(mk);
+  }
+  return total;
+}
+
+__device__ void introsort_loop_levels(uint32_t* v, int N, uint16_t* posA, uint16_t* posB, uint16_t* segF,
+                                      uint16_t* segL, uint16_t* pkbuf, uint16_t* cutbuf, Misc* m) {
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+  const int n_chunks = (N + 63) >> 6;
+  for (int x = tid; x < N; x += nt) {
+    segF[x] = 0;
+    segL[x] = (uint16_t)(N > 16 ? N : 0);
+  }
+  if (tid < 48) m->n_level[tid] = (tid == 0 && N > 16) ? 1 : 0;
+  int depth = 2 * rs_sort::floor_log2(N > 1 ? N : 1);
+  for (int level = 0; level < 47; ++level, --depth) {
+    /* M */
+    for (int x = tid; x < N; x += nt) {
+      const int L = segL[x];
+      if (L != 0 && segF[x] == x) {
+        LdsArr a{v};
+        if (depth == 0) {
+          rs_sort::heap_sort(a, x, L);
+        } else {
+          rs_sort::median_to_first(a, x, x + 1, x + (L - x) / 2, L - 1);
+          pkbuf[x] = (uint16_t)(v[x] >> 16);
+        }
+      }
+    }
+    __syncthreads();
+    if (m->n_level[level] == 0 || depth == 0) break;
+    /* F */
+    for (int c = wave; c < n_chunks; c += nwaves) {
+      const int x = (c << 6) + lane;
+      const int L = x < N ? (int)segL[x] : 0;
+      const int F = x < N ? (int)segF[x] : 0;
+      const int k = x < N ? (int)(v[x] >> 16) : 0;
+      const bool in = L != 0 && x > F;
+      const int pk = in ? (int)pkbuf[F] : 0;
+      const unsigned long long mA = __ballot(in && k <= pk), mB = __ballot(in && k >= pk);
+      if (lane == 0) {
+        m->maskA[c] = mA;
+        m->maskB[c] = mB;
+      }
+      if (x < N) {
+        posA[x] = 0xFFFF;
+        posB[x] = 0xFFFF;
+      }
+    }
+    __syncthreads();
+    /* R */
+    for (int c = wave; c < n_chunks; c += nwaves) {
+      const int x = (c << 6) + lane;
+      const int L = x < N ? (int)segL[x] : 0;
+      const int F = x < N ? (int)segF[x] : 0;
+      const int k = x < N ? (int)(v[x] >> 16) : 0;
+      const bool in = L != 0 && x > F;
+      const int pk = in ? (int)pkbuf[F] : 0;
+      if (in && k <= pk) posA[F + count_bits_in(m->maskA, F + 1, x)] = (uint16_t)x;
+      if (in && k >= pk) posB[F + count_bits_in(m->maskB, x + 1, L)] = (uint16_t)x;
+    }
+    __syncthreads();
+    /* S */
+    for (int x = tid; x < N; x += nt) {
+      const int L = segL[x], F = segF[x];
+      if (L != 0 && x > F) {
+        const int j = x - F - 1;
+        const int l = posA[F + j], r = posB[F + j];
+        const int l1 = posA[F + j + 1], r1 = posB[F + j + 1]; /* index <= L-1: inside the sub-range */
+        const bool sw = l != 0xFFFF && r != 0xFFFF && l < r;
+        const bool sw1 = l1 != 0xFFFF && r1 != 0xFFFF && l1 < r1;
+        if (sw) {
+          const uint32_t a = v[l], b = v[r];
+          v[l] = b;
+          v[r] = a;
+          if (!sw1) cutbuf[F] = (uint16_t)((l1 != 0xFFFF && l1 < r) ? l1 : r);
+        } else if (j == 0) {
+          cutbuf[F] = (uint16_t)l;
+        }
+      }
+    }
+    __syncthreads();
+    /* U */
+    bool any = false;
+    for (int x = tid; x < N; x += nt) {
+      const int L = segL[x];
+      if (L != 0) {
+        const int F = segF[x];
+        const int cut = cutbuf[F];
+        const int nF = x < cut ? F : cut;
+        int nL = x < cut ? cut : L;
+        if (nL - nF <= 16) nL = 0;
+        segF[x] = (uint16_t)nF;
+        segL[x] = (uint16_t)nL;
+        any |= nL != 0;
+      }
+    }
+    if (__ballot(any) && lane == 0) atomicAdd(&m->n_level[level + 1], 1);
+  }
+}
+
+/*
+ * The same level-synchronous loop with the per-position state (element, sub-range bounds) held in
+ * registers: EPT positions per thread, position x = i*blockDim + tid (so a wave still covers one
+ * 64-position chunk per i).  Every lane of a sub-range reads the three median samples itself, so
+ * the pivot is known without a publishing step; three workgroup barriers per level.
+ */
+__device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
+  /* bits [lo, hi) of a 64-bit mask, 0 <= lo, hi <= 64 */
+  if (hi <= lo) return 0ull;
+  const unsigned long long upto_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+  return upto_hi & (~0ull << lo);
+}
+
+#ifdef RS_STAMPS
+#define RS_SUBSTAMP(i)                                            \
+  do {                                                            \
+    if (tid == 0) {                                               \
+      unsigned long long now_ = __builtin_readcyclecounter();     \
+      sub[i] += now_ - sub_prev;                                  \
+      sub_prev = now_;                                            \
+    }                                                             \
+  } while (0)
+#else
+#define RS_SUBSTAMP(i) do { } while (0)
+#endif
+
+
+
+/*
+ * One std::__unguarded_partition per live sub-range and level, decided locally from stop counts.
+ * In [lo, hi) = (f, l) with pivot key pk, an A-stop is an element with key <= pk (where the upward scan
+ * halts), a B-stop one with key >= pk (downward scan).  With A(x) = A-stops in [lo, x) and B(x) = B-stops in
+ * (x, hi): the library swaps the j-th A-stop from the left with the j-th B-stop from the right while the
+ * former lies left of the latter, so
+ *     an A-stop x is swapped  <=>  B(x) > A(x)   (it receives the element of B-stop number A(x) from the right)
+ *     a  B-stop x is swapped  <=>  A(x) > B(x)   (it receives the element of A-stop number B(x) from the left)
+ * and the returned cut is the leftmost position that is an unswapped A-stop or a swapped B-stop.
+ * Swapped elements travel through `xbuf` (A-stop number a at f+a, B-stop number b at l-1-b: they cannot
+ * meet, a + b <= len - 3); the cut is an LDS atomicMin per sub-range (slot f>>4: live sub-ranges are longer
+ * than 16, so their slots differ).  Counts come from per-chunk ballots + one prefix scan per wave.
+ */
+template <int EPT>
+__device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t* cuts, Misc* m,
+                                     unsigned long long* sub, int seg_len = 0) {
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+#ifdef RS_STAMPS
+  unsigned long long sub_prev = __builtin_readcyclecounter();
+#endif
+  const int n_chunks = (N + 63) >> 6;
+  const unsigned long long lt_lane = (1ull << lane) - 1ull, le_lane = ~0ull >> (63 - lane);
+  uint32_t e[EPT];
+  int F[EPT], L[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int x = i * nt + tid;
+    e[i] = x < N ? v[x] : 0u;
+    if (seg_len == 0) {
+      F[i] = 0;
+      L[i] = (x < N && N > 16) ? N : 0;
+    } else {
+      /* seg_len > 0: the array is a row of independent std::sort calls, seg_len elements each (UpperBound) */
+      F[i] = idiv_small(x, seg_len) * seg_len;
+      L[i] = (x < N && seg_len > 16) ? F[i] + seg_len : 0;
+    }
+  }
+  const int n_first = seg_len == 0 ? N : seg_len; /* length every std::sort call starts from */
+  if (tid < 48) m->n_level[tid] = (tid == 0 && n_first > 16) ? 1 : 0;
+  int depth = 2 * rs_sort::floor_log2(n_first > 1 ? n_first : 1);
+  __syncthreads();
+  for (int level = 0; level < 47; ++level, --depth) {
+    if (depth == 0) {
+      /* std::__partial_sort fallback for every sub-range still longer than 16 */
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int x = i * nt + tid;
+        if (L[i] != 0 && F[i] == x) {
+          LdsArr a{v};
+          rs_sort::heap_sort(a, x, L[i]);
+        }
+      }
+      __syncthreads();
+      break;
+    }
+    /* F: pivot of my sub-range (median of 3, std::__move_median_to_first), stop ballots */
+    unsigned long long mAi[EPT], mBi[EPT];
+    bool isA[EPT], isB[EPT], moved[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int x = i * nt + tid;
+      const int c = i * nwaves + wave;
+      const bool active = L[i] != 0;
+      int pk = 0;
+      moved[i] = false;
+      if (active) {
+        const int f = F[i], l = L[i];
+        const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
+        uint32_t s0 = v[f];
+        const uint32_t sa = v[ia], sb = v[ib], sc = v[ic];
+        asm volatile("" : "+v"(s0)); /* keep the four LDS reads in one batch (one latency, not two) */
+        int pick;
+        uint32_t sp;
+        if (rs_sort::before(sa, sb)) {
+          if (rs_sort::before(sb, sc)) { pick = ib; sp = sb; }
+          else if (rs_sort::before(sa, sc)) { pick = ic; sp = sc; }
+          else { pick = ia; sp = sa; }
+        } else if (rs_sort::before(sa, sc)) { pick = ia; sp = sa; }
+        else if (rs_sort::before(sb, sc)) { pick = ic; sp = sc; }
+        else { pick = ib; sp = sb; }
+        pk = (int)(sp >> 16);
+        if (x == f) { e[i] = sp; moved[i] = true; cuts[f >> 4] = 0x7fffffff; }
+        else if (x == pick) { e[i] = s0; moved[i] = true; }
+      }
+      const int k = (int)(e[i] >> 16);
+      const bool in = active && x > F[i];
+      isA[i] = in && k <= pk;
+      isB[i] = in && k >= pk;
+      mAi[i] = __ballot(isA[i]);
+      mBi[i] = __ballot(isB[i]);
+      if (lane == 0 && c < n_chunks) {
+        m->maskA[c] = mAi[i];
+        m->maskB[c] = mBi[i];
+      }
+    }
+    RS_SUBSTAMP(0);
+    __syncthreads();
+    RS_SUBSTAMP(1);
+    if (m->n_level[level] == 0) break;
+    /* R: stop counts -> swap decision; swapped elements to the exchange buffer, cut candidates to the slot */
+    int pre; /* lane c: stops in chunks < c, A-stops in the low half, B-stops in the high half */
+    {
+      int cnt = 0;
+      if (lane < n_chunks) cnt = __popcll(m->maskA[lane]) | (__popcll(m->maskB[lane]) << 16);
+      pre = wave_scan_incl(cnt) - cnt;
+    }
+    int slot[EPT]; /* where my element went / where its replacement arrives; -1: not swapped */
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int x = i * nt + tid;
+      const int c = i * nwaves + wave;
+      if (moved[i]) v[x] = e[i];
+      /* counts are taken by every lane: ds_bpermute returns 0 for a source lane that is masked off */
+      const int lo = F[i] + 1, hm = L[i] != 0 ? L[i] - 1 : 0;
+      const int wlo = lo >> 6, whi = hm >> 6;
+      const int plo = __builtin_amdgcn_ds_bpermute(wlo << 2, pre) & 0xffff;
+      const int phi = (int)((unsigned)__builtin_amdgcn_ds_bpermute(whi << 2, pre) >> 16);
+      const unsigned long long mlo = m->maskA[wlo], mhi = m->maskB[whi];
+      const int pc = __builtin_amdgcn_readlane(pre, c & 63);
+      const int a = (pc & 0xffff) + __popcll(mAi[i] & lt_lane) - plo - __popcll(mlo & ((1ull << (lo & 63)) - 1ull));
+      const int b = phi + __popcll(mhi & (~0ull >> (63 - (hm & 63)))) - (int)((unsigned)pc >> 16) - __popcll(mBi[i] & le_lane);
+      const bool swA = isA[i] & (b > a), swB = isB[i] & (a > b); /* never both: b > a excludes a > b */
+      slot[i] = (swA | swB) ? (swA ? F[i] + a : hm - b) : -1;
+      if (swA | swB) xbuf[slot[i]] = e[i];
+      const bool cand = (isA[i] & !swA) | swB;
+      /* leftmost candidate of its sub-range inside this chunk reports */
+      const unsigned long long mC = __ballot(cand);
+      const int lo_in = lo - (c << 6);
+      if (cand && (mC & bit_range(lo_in > 0 ? lo_in : 0, lane)) == 0ull) atomicMin(&cuts[F[i] >> 4], x);
+    }
+    RS_SUBSTAMP(2);
+    __syncthreads();
+    RS_SUBSTAMP(3);
+    /* S: receive the swapped element, then move to the child sub-range; sub-ranges of at most 16 retire */
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int x = i * nt + tid;
+      if (L[i] != 0) {
+        const int cut = cuts[F[i] >> 4];
+        if (slot[i] >= 0) {
+          /* an A-stop's slot f+a pairs with B-stop slot l-1-a and vice versa */
+          e[i] = xbuf[F[i] + L[i] - 1 - slot[i]];
+          v[x] = e[i];
+        }
+        if (x < cut) L[i] = cut; else F[i] = cut;
+        if (L[i] - F[i] <= 16) L[i] = 0;
+        any |= L[i] != 0;
+      }
+    }
+    if (__ballot(any) && lane == 0) atomicAdd(&m->n_level[level + 1], 1);
+    RS_SUBSTAMP(4);
+    __syncthreads();
+    RS_SUBSTAMP(5);
+#ifdef RS_STAMPS
+    if (tid == 0) sub[7] += 1;
+#endif
+  }
+}
+
+/*
+ * std::__final_insertion_sort == stable sort of the array the introsort loop leaves (a stable order
+ * is unique): 16-bucket stable counting sort by DESCENDING key, all waves.
+ *   A  every wave, for its 64-element chunks: per-key counts (lane q holds key q) -> hist[chunk][q]
+ *   B  wave 0: hist[chunk][q] <- first output slot of key q in that chunk
+ *   C  every wave: slot = hist[chunk][key] + (same-key lanes below me); scatter to `out`
+ */
+__device__ void counting_sort_desc(const uint32_t* v, uint32_t* out, int N, Misc* m) {
+  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
+  const int n_chunks = (N + 63) >> 6;
+  for (int c = wave; c < n_chunks; c += nwaves) {
+    const int i = (c << 6) + lane;
+    const int k = i < N ? (int)(v[i] >> 16) : 0;
+    BitBallots<4> bb;
+    bb.gather(k, i < N);
+    if (lane < 16) m->hist[c * 16 + lane] = (uint16_t)__popcll(bb.lanes_with(lane));
+  }
+  __syncthreads();
+  if (wave == 0) {
+    int total = 0;
+    if (lane < 16)
+      for (int c = 0; c < n_chunks; ++c) total += m->hist[c * 16 + lane];
+    int run = 0, acc = 0;
+#pragma unroll
+    for (int q = 15; q >= 0; --q) {
+      int tq = __builtin_amdgcn_readlane(total, q);
+      if (lane == q) run = acc;
+      acc += tq;
+    }
+    if (lane < 16)
+      for (int c = 0; c < n_chunks; ++c) {
+        int h = m->hist[c * 16 + lane];
+        m->hist[c * 16 + lane] = (uint16_t)run;
+        run += h;
+      }
+  }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int c = wave; c < n_chunks; c += nwaves) {
+    const int i = (c << 6) + lane;
+    const uint32_t e = i < N ? v[i] : 0;
+    const int k = (int)(e >> 16);
+    BitBallots<4> bb;
+    bb.gather(k, i < N);
+    const int rank = __popcll(bb.lanes_with(k) & lt);
+    if (i < N) out[m->hist[c * 16 + k] + rank] = e;
+  }
+  __syncthreads();
+}
+
+/* The same stable counting sort when every wave owns at most CPW chunks (chunk j*nwaves + wave, like the
+ * register introsort): one ballot pass gives both the per-chunk counts and every element's rank among
+ * equal keys in its chunk; after one barrier every wave derives the output offsets of its own chunks
+ * from the count table (lane q = key q), so there is no single-wave step and no second barrier. */
+template <int CPW>
+__device__ __forceinline__ void counting_sort_desc_owned(const uint32_t* v, uint32_t* out, int N, Misc* m) {
+  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
+  const int n_chunks = (N + 63) >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t e[CPW];
+  int rank[CPW];
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int c = j * nwaves + wave, i = (c << 6) + lane;
+    const bool valid = c < n_chunks && i < N;
+    e[j] = valid ? v[i] : 0u;
+    BitBallots<4> bb;
+    bb.gather((int)(e[j] >> 16), valid);
+    rank[j] = __popcll(bb.lanes_with((int)(e[j] >> 16)) & lt);
+    if (lane < 16 && c < n_chunks) m->hist[c * 16 + lane] = (uint16_t)__popcll(bb.lanes_with(lane));
+  }
+  __syncthreads();
+  int total = 0, below[CPW];
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) below[j] = 0;
+  if (lane < 16)
+    for (int c = 0; c < n_chunks; ++c) {
+      const int h = m->hist[c * 16 + lane];
+#pragma unroll
+      for (int j = 0; j < CPW; ++j) below[j] += c < j * nwaves + wave ? h : 0;
+      total += h;
+    }
+  /* elements with a larger key come first: lane q needs the sum of total over keys > q */
+  int inc = total;
+  {
+    int v_ = inc;
+    const int identity = 0;
+#define RS_ROW_STEP(ctrl, bmask) v_ = v_ + __builtin_amdgcn_update_dpp(identity, v_, ctrl, 0xf, bmask, false)
+    RS_ROW_STEP(0x111, 0xf);
+    RS_ROW_STEP(0x112, 0xf);
+    RS_ROW_STEP(0x114, 0xe);
+    RS_ROW_STEP(0x118, 0xc);
+#undef RS_ROW_STEP
+    inc = v_;
+  }
+  const int all = __builtin_amdgcn_readlane(inc, 15);
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int c = j * nwaves + wave, i = (c << 6) + lane;
+    const int base_q = all - inc + below[j]; /* lane q < 16 */
+    const int base = __builtin_amdgcn_ds_bpermute((int)(e[j] >> 16) << 2, base_q); /* every lane: no branch around it */
+    if (c < n_chunks && i < N) out[base + rank[j]] = e[j];
+  }
+  __syncthreads();
+}
+
+}  // namespace
+
+#endif /* RS_SORT_DEVICE_H_ */
