@@ -519,3 +519,42 @@ def test_nvs_nongreedy_drop_in(rs, oracle):
     with pytest.raises(rs.RadioSaberError, match="rand_draws"):
         ts.schedule_tti(cqi[ids], avg[ids], user_id=ids)
     ts.close()
+
+
+def _experiment_cases():
+    cfgs = json.loads((GOLDEN / "experiment_configs.json").read_text())
+    cases = []
+    for name, c in sorted(cfgs.items()):
+        if any(c["algo_alpha"]):
+            continue  # customised slices need per-TTI queue state: drop-in mode only (test_drop_in_customised_slices)
+        for sched in c["schedulers_in_run_scripts"]:
+            cases.append((name, sched))
+    return cfgs, cases
+
+
+def test_every_shipped_experiment_configuration(rs, oracle):
+    """The slice configurations of the reference's NSDI23-radiosaber-experiments directories (ues_per_slice, weights,
+    algo parameters; tests/golden/experiment_configs.json, distilled by tools/make_config_fixture.py) x the scheduler
+    numbers their run scripts pass, on the as-shipped 64-RBG grid: device == oracle, bit for bit."""
+    cfgs, cases = _experiment_cases()
+    assert len(cases) > 100
+    for k, (name, sched) in enumerate(cases):
+        c = cfgs[name]
+        S = len(c["ues_per_slice"])
+        sc = rs.SliceConfig(c["ues_per_slice"], weight=c["weight"], algo_epsilon=c["algo_epsilon"], algo_psi=c["algo_psi"])
+        U, R, G, n_ttis = sc.n_users, 64, 8, 42
+        grids = synth_cqi(900 + k, (1, 2, U, R), HIST)
+        seeds = np.array([805290992 + k], np.uint32)
+        b = rs.BatchScheduler(sc, R, G, 1, sched=sched, phy_error_draws=True)
+        b.seed(seeds)
+        b.upload_cqi_epochs(grids)
+        b.run(n_ttis)
+        st = b.state()
+        cell = oracle.Cell(c["ues_per_slice"], R, G, sched, weights=c["weight"], epsilon=c["algo_epsilon"], psi=c["algo_psi"])
+        cell.run_synth(grids[0], int(seeds[0]), n_ttis, phy_error_draws=1, log=False)
+        ost = cell.state()
+        assert (st["cum_bytes"][0] == ost["cum_bytes"]).all(), (name, sched)
+        assert (st["cum_rbs"][0] == ost["cum_rbs"]).all(), (name, sched)
+        assert st["avg_rate"][0].tobytes() == ost["avg_rate"].tobytes(), (name, sched)
+        assert st["slice_state"][0].tobytes() == ost["slice_state"].tobytes(), (name, sched)
+        b.close()
