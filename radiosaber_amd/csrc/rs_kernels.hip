@@ -105,7 +105,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   uint32_t* s_elems = (uint32_t*)(lds + o.elems);
   uint32_t* s_sorted = (uint32_t*)(lds + o.sorted);
   Misc* m = (Misc*)(lds + o.misc);
-  int32_t* s_tbs = (int32_t*)(lds + o.tbs); /* [R+1][27] TBS bits of n RBGs at itbs */
+  int32_t* s_tbs = (int32_t*)(lds + o.tbs); /* [R+1][16] TBS bits of n RBGs at a final CQI */
   uint8_t* s_cqi = lds + o.cqi; /* [R][Upad], Upad = 8 * odd >= U: conflict-free 8-byte column reads */
   const int Upad = o.Upad;
 
@@ -121,7 +121,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       if (p.log_uinfo) p.log_uinfo[u] = 0;
     }
   }
-  for (int i = tid; i < (R + 1) * 27; i += nt) s_tbs[i] = p.tbs_eff[i];
+  /* TBS bits of n RBGs at a final CQI: the I_TBS step of CQI -> MCS -> I_TBS -> TBS folded in ([R+1][16]) */
+  for (int i = tid; i < (R + 1) * 16; i += nt) s_tbs[i] = p.tbs_eff[(i >> 4) * 27 + tab->itbs_of_cqi[i & 15]];
   for (int i = tid; i < (R * Upad) >> 2; i += nt) ((uint32_t*)s_cqi)[i] = 0;
   for (int i = tid; i < Upad; i += nt) s_rcp32[i] = 0.0f;
   if (tid < 16) {
@@ -683,7 +684,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           for (int t = 1; t <= 13; ++t) fcqi += (xm <= s_x[t]) ? 1 : 0;
         }
         const int mcs = m->mcs_of_cqi[fcqi];
-        const int tbs = s_tbs[(nprb / G) * 27 + m->itbs_of_cqi[fcqi]];
+        const int tbs = s_tbs[(nprb / G) * 16 + fcqi];
         int bytes = tbs / 8;
         if (bytes > 100000000) bytes = 100000000;
         if (bytes > 0) {
@@ -890,6 +891,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       /* owner + 1 <= U <= 2047; a shape-specialised build knows how many bits that takes */
       constexpr int kOwnerBits = !FIXED ? 11 : RS_JIT_U < 63 ? 6 : RS_JIT_U < 127 ? 7 : RS_JIT_U < 255 ? 8
                                  : RS_JIT_U < 511 ? 9 : RS_JIT_U < 1023 ? 10 : 11;
+      const double xthr = s_x[lane & 15]; /* EESM decision thresholds X[1..13], one per lane */
       BitBallots<kOwnerBits> ob;
       ob.gather(owner + 1, lane < R && owner >= 0);
       const unsigned long long same = owner >= 0 ? ob.lanes_with(owner + 1) : 0ull;
@@ -922,10 +924,14 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           } else {
             fcqi = 1;
 #pragma unroll
-            for (int k = 1; k <= 13; ++k) fcqi += (x <= s_x[k]) ? 1 : 0;
+            for (int k = 1; k <= 13; ++k) { /* thresholds from lanes 1..13 of xthr: no LDS round trips on the serial path */
+              const double thr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xthr), k),
+                                                  __builtin_amdgcn_readlane(__double2loint(xthr), k));
+              fcqi += (x <= thr) ? 1 : 0;
+            }
           }
           mcs = m->mcs_of_cqi[fcqi];
-          tbs = s_tbs[(nprb / G) * 27 + m->itbs_of_cqi[fcqi]];
+          tbs = s_tbs[(nprb / G) * 16 + fcqi];
           /* DoStopSchedule, ref: :170-221 (bytes = bits/8, capped by dataToTransmit = 1e8) */
           int bytes = tbs / 8;
           if (bytes > 100000000) bytes = 100000000;
