@@ -396,10 +396,19 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       auto draw_batch = [&](int b0, uint8_t* dst) { /* generator wave only */
         const int nbb = RS_NVS_SAMPLES - b0 < bs ? RS_NVS_SAMPLES - b0 : bs;
         const int total = nbb * n;
-        for (int d0 = 0; d0 < total; d0 += 31) {
-          const int cnt = total - d0 < 31 ? total - d0 : 31;
-          const uint32_t x = rng.next_block(cnt);
-          if (lane < cnt) dst[d0 + lane] = (uint8_t)((x >> 1) & 3u); /* rand() % 4 */
+        int d0 = 0;
+        if (total >= 31) { /* whole blocks stream in the chain-major layout (row-local DPP scans, no LDS round trips) */
+          const int j = WaveRng::cm_index();
+          rng.to_chain_major();
+          for (; d0 + 31 <= total; d0 += 31) {
+            const uint32_t x = rng.next_block_chain_major();
+            if (j >= 0) dst[d0 + j] = (uint8_t)((x >> 1) & 3u); /* rand() % 4 */
+          }
+          rng.to_age_order();
+        }
+        if (d0 < total) {
+          const uint32_t x = rng.next_block(total - d0);
+          if (lane < total - d0) dst[d0 + lane] = (uint8_t)((x >> 1) & 3u);
         }
       };
       if (overlap && wave == quota_wave) draw_batch(0, nv_draw);

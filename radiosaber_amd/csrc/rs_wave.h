@@ -116,6 +116,43 @@ struct WaveRng {
     b = 28;
     return nw;
   }
+  /* Chain-major layout for streaming many blocks: age index j sits in lane 16*(j mod 3) + j/3, so each of the three chains
+   * j mod 3 (11, 10, 10 words) lies in its own 16-lane row and the chain prefix sums are row-local DPP scans -- a block of
+   * 31 words costs 4 DPP adds + 3 v_readlane, no LDS round trip.  cm_index() = the age index of this lane (-1: unused). */
+  __device__ __forceinline__ static int cm_index() {
+    const int lane = (int)(threadIdx.x & 63), row = lane >> 4, idx = lane & 15;
+    return (row < 3 && idx < (row == 0 ? 11 : 10)) ? 3 * idx + row : -1;
+  }
+  __device__ __forceinline__ void to_chain_major() { /* from the ring (any f) */
+    const int j = cm_index();
+    int src = f + (j < 0 ? 0 : j);
+    src = src >= 31 ? src - 31 : src;
+    r = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)r);
+    f = 0;
+    b = 28;
+  }
+  __device__ __forceinline__ void to_age_order() { /* back to the ring with f = 0 */
+    const int lane = (int)(threadIdx.x & 63);
+    const int j = lane < 31 ? lane : 0;
+    const int third = (j * 43) >> 7; /* j / 3 */
+    r = (uint32_t)__builtin_amdgcn_ds_bpermute((16 * (j - 3 * third) + third) << 2, (int)r);
+  }
+  __device__ __forceinline__ uint32_t next_block_chain_major() { /* 31 new words, in the same layout */
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t old = cm_index() >= 0 ? r : 0u;
+    int v = (int)old;
+    const int identity = 0;
+    RS_DPP_STEP(op_add, 0x111, 0xf, 0xf); /* row_shr:1 */
+    RS_DPP_STEP(op_add, 0x112, 0xf, 0xf); /* row_shr:2 */
+    RS_DPP_STEP(op_add, 0x114, 0xf, 0xe); /* row_shr:4 */
+    RS_DPP_STEP(op_add, 0x118, 0xf, 0xc); /* row_shr:8 */
+    /* chain c continues from old[28 + c]: age 28 = chain 1 index 9, 29 = chain 2 index 9, 30 = chain 0 index 10 */
+    const uint32_t b0 = __builtin_amdgcn_readlane(old, 16 + 9), b1 = __builtin_amdgcn_readlane(old, 32 + 9),
+                   b2 = __builtin_amdgcn_readlane(old, 10);
+    const int row = lane >> 4;
+    r = (uint32_t)v + (row == 0 ? b0 : row == 1 ? b1 : b2);
+    return r;
+  }
 };
 
 struct LdsArr {
