@@ -193,6 +193,29 @@ def test_trace_replay_500_ues_all_schedulers(rs, oracle, traces):
         b.close()
 
 
+def test_trace_replay_500_ues_25_rbgs(rs, oracle, traces):
+    """BASELINE configs[1] as written: 20 x 25 UEs x 25 RBGs on the real CQI traces.  A 100-PRB carrier reads the first 100
+    values of every trace line in RBGs of 4 (enb-mac-entity.cc:178-183, get_rbg_size); the traces are constant per 8 PRBs, so
+    RBG r of 4 carries the fixture's 8-PRB value r // 2.  Every scheduler the run scripts use, device vs oracle."""
+    ues = [25] * 20
+    sc = rs.SliceConfig(ues, weight=[0.05] * 20)
+    U = sc.n_users
+    cqi25 = np.ascontiguousarray(traces["cqi"][:, :, np.arange(25) // 2])
+    for sched, mapping in ((9, 0), (8, 1), (7, 2), (1, 3), (10, 0), (11, 1)):
+        b = rs.BatchScheduler(sc, 25, 4, 1, sched=sched, phy_error_draws=True)
+        b.seed(np.array([805290992], np.uint32), np.array([7000], np.int64))
+        b.set_trace(cqi25, traces["mapping"][mapping][np.arange(U) % 474][None, :])
+        got = b.run_logged(130)
+        st = b.state()
+        cell = oracle.Cell(ues, 25, 4, sched, weights=[0.05] * 20)
+        logs = cell.run_trace(cqi25, traces["mapping"][mapping], 805290992, 7000, 130)
+        np.testing.assert_array_equal(got["rbg_to_user"][0], logs["rbg_to_user"], err_msg=f"sched {sched}")
+        np.testing.assert_array_equal(got["tbs_bits"][0], logs["tbs_bits"], err_msg=f"sched {sched}")
+        np.testing.assert_array_equal(st["cum_bytes"][0], cell.state()["cum_bytes"])
+        assert st["avg_rate"][0].tobytes() == cell.state()["avg_rate"].tobytes()
+        b.close()
+
+
 def test_1000_ues_config3(rs, oracle):
     """BASELINE configs[2] shape: 20 slices x 50 UEs, schedulers 1/7/8/9 on synthetic sub-band CQI."""
     for sched in (9, 8, 7, 1):
