@@ -663,7 +663,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       }
       __syncthreads();
       for (int x = tid; x < N; x += nt) {
-        const int sl = idiv_small(x, R), f = sl * R, k = x - f;
+        const int sl = idiv_small(x, R), f = sl * R;
         const int u = ent_user[x];
         int q = m->quota[sl];
         q = q > R ? R : q;
@@ -756,7 +756,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         int left = lane < S ? m->quota[lane] : 0; /* lane s: quota[s] - granted[s] */
         int my_slice = -1;                        /* lane r: slice that got RBG r */
         int assigned = 0;
-        int scan_end = 0;
+#ifdef RS_STAMPS
+        int scan_end = 0; /* diagnostic: how deep the scan went */
+#endif
         for (int c0 = 0; c0 < N && assigned < R; c0 += 64) {
           const int i = c0 + lane;
           const uint32_t e = i < N ? s_sorted[i] : 0;
@@ -775,7 +777,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             if (lane == fsl) left--;
             if (lane == frbg) my_slice = fsl;
             assigned++;
+#ifdef RS_STAMPS
             scan_end = c0 + f;
+#endif
           }
         }
 #ifdef RS_STAMPS
