@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <ostream>
 #include <vector>
 
 #include "radiosaber_hip.h"
@@ -45,8 +46,9 @@ struct BearerState {
  * (downlink-transport-scheduler.cpp:661-668) */
 struct Allocation {
   int user_id;
-  std::vector<int> prbs; /* GetListOfAllocatedRBs(), RBG-ascending */
+  std::vector<int> prbs; /* GetListOfAllocatedRBs(), RBG-ascending (RS_SCHED_UPPERBOUND: only the RBGs rbg_to_user reports) */
   int final_cqi, mcs, tbs_bits;
+  int n_prbs;            /* size of the reference's list (complete for every scheduler) */
 };
 
 class GpuDownlinkScheduler {
@@ -207,11 +209,36 @@ class GpuDownlinkScheduler {
     if (rs_schedule_tti(ctx_, &in, &out) != RS_OK) throw std::runtime_error(std::string("rs_schedule_tti: ") + rs_last_error());
     for (int i = 0; i < n; ++i) {
       if (nprb_[i] == 0) continue;
-      Allocation a{users_[i], {}, fcqi_[i], mcs_[i], tbs_[i]};
+      Allocation a{users_[i], {}, fcqi_[i], mcs_[i], tbs_[i], nprb_[i]};
       for (int r = 0; r < nb_rbgs_; ++r)
         if (rbg_to_user_[r] == users_[i])
           for (int k = r * rbg_size_; k < (r + 1) * rbg_size_; ++k) a.prbs.push_back(k);
       allocations_.push_back(a);
+    }
+    if (log_out_) WriteAllocationLog(*log_out_);
+  }
+
+  /* the reference's stdout of RBsAllocation: downlink-transport-scheduler.cpp:523-527 (slice line, transport schedulers
+   * only), :631 / downlink-nvs-scheduler.cpp:330 (time stamp), :637-649 / nvs :334-348 (one line per served user).
+   * The PF scheduler prints no map.  UpperBound's per-user RBG lists are not recoverable from the ABI outputs. */
+  void WriteAllocationLog(std::ostream& os) const {
+    if (sched_ == RS_SCHED_PF || sched_ == RS_SCHED_UPPERBOUND) return;
+    const bool transport = sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL || sched_ == RS_SCHED_VOGEL;
+    if (transport) {
+      os << "slice_id, target_rbs, quota_rbgs: ";
+      for (int i = 0; i < num_slices_; ++i) os << "(" << i << ", " << target_[i] << ", " << quota_[i] << ") ";
+      os << std::endl;
+    }
+    os << ts_ << std::endl;
+    for (const Allocation& a : allocations_) {
+      os << "User(" << a.user_id << ") allocated RBGS:";
+      for (size_t k = 0; k < a.prbs.size(); k += (size_t)rbg_size_) {
+        const int prb = a.prbs[k];
+        const int cqi = cqi_prb_.empty() ? cqi_[(size_t)a.user_id * nb_rbgs_ + prb / rbg_size_]
+                                         : cqi_prb_[(size_t)a.user_id * nb_rbs_ + prb];
+        os << " " << prb / rbg_size_ << "(" << cqi << ")";
+      }
+      os << " final_cqi: " << a.final_cqi << std::endl;
     }
   }
 
@@ -224,10 +251,24 @@ class GpuDownlinkScheduler {
       BearerState& b = bearers_[a.user_id];
       b.transmitted_bytes += sent;
       b.cumulative_bytes += sent;
-      b.cumulative_rbs += a.prbs.size();
+      b.cumulative_rbs += a.n_prbs;
+      if (log_err_) {
+        /* downlink-transport-scheduler.cpp:192-199, downlink-nvs-scheduler.cpp:240-247 ("app:", with user and slice);
+         * downlink-packet-scheduler.cpp:140-145 ("flow:", without).  One bearer per user: application id == user id. */
+        std::ostream& es = *log_err_;
+        es << ts_ << (sched_ == RS_SCHED_PF ? " flow: " : " app: ") << a.user_id << " cumu_bytes: " << b.cumulative_bytes
+           << " cumu_rbs: " << b.cumulative_rbs << " hol_delay: " << b.hol_delay;
+        if (sched_ != RS_SCHED_PF) es << " user: " << a.user_id << " slice: " << user_to_slice_[a.user_id];
+        es << std::endl;
+      }
     }
     ts_++;
   }
+
+  /* the reference's scheduler counts every TTI from 0 (m_ts); a run that starts scheduling at TTI 100 sets 100 here */
+  void SetTimeStamp(unsigned long ts) { ts_ = ts; }
+  /* log compatibility with the reference's stdout / stderr (what NSDI23-radiosaber-experiments/ *\/plot_*.py parse); NULL = off */
+  void SetLogStreams(std::ostream* out, std::ostream* err) { log_out_ = out; log_err_ = err; }
 
  private:
   int num_slices_, rbg_size_, sched_, nb_rbs_ = 0, nb_rbgs_ = 0;
@@ -242,6 +283,7 @@ class GpuDownlinkScheduler {
   std::vector<int> users_, target_, quota_, rbg_to_user_, nprb_, fcqi_, mcs_, tbs_;
   std::vector<Allocation> allocations_;
   unsigned long ts_ = 0;
+  std::ostream *log_out_ = nullptr, *log_err_ = nullptr;
   rs_ctx* ctx_ = nullptr;
 };
 

@@ -5,6 +5,8 @@
 // Prints "cumu <user> <bytes> <rbs>" for users 1, 2, 5 and the first TTI's allocations.
 #include <cstdio>
 #include <cstdlib>
+#include <sstream>
+#include <string>
 #include <vector>
 
 #include "../../include/radiosaber_scheduler.hpp"
@@ -21,6 +23,9 @@ int main(int argc, char** argv) {
   std::vector<int> ues(20, 5), zeros(20, 0), ones(20, 1);
   std::vector<double> w(20, 0.05);
   radiosaber::GpuDownlinkScheduler sched(ues, w, zeros, zeros, ones, ones, 512, 8, RS_SCHED_MAXCELL);
+  std::ostringstream log_out, log_err;
+  sched.SetTimeStamp(100);  // the reference's m_ts has counted the 100 idle TTIs before the first allocation
+  sched.SetLogStreams(&log_out, &log_err);
   srand(805290992);  // seed.h commonSeed[0]
   for (long i = 0; i < skip; i++) (void)rand();
   double t = 0;
@@ -53,5 +58,15 @@ int main(int argc, char** argv) {
   }
   for (int u : {1, 2, 5}) printf("cumu %d %lu %lu\n", u, sched.Bearer(u).cumulative_bytes, sched.Bearer(u).cumulative_rbs);
   printf("ts %lu\n", sched.GetTimeStamp());
+  // the reference-format logs, for the golden lines of SURVEY.md Appendix A
+  {
+    std::istringstream is(log_out.str());
+    std::string line;
+    int n = 0;
+    while (std::getline(is, line) && n < 60) { printf("OUT %s\n", line.c_str()); n++; }
+    std::istringstream es(log_err.str());
+    while (std::getline(es, line))
+      if (line.rfind("100 ", 0) == 0 || line.rfind("299 ", 0) == 0) printf("ERR %s\n", line.c_str());
+  }
   return 0;
 }

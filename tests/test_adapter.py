@@ -42,4 +42,15 @@ def test_adapter_replays_the_reference_run(tmp_path, rs, traces):
     assert "served 34 quota16 37 4" in lines
     for u, (cb, cr) in ka["after_200_ttis"]["cumu"].items():
         assert f"cumu {u} {cb} {cr}" in lines
-    assert "ts 200" in lines
+    assert "ts 300" in lines  # 100 idle TTIs + 200 scheduled ones
+    # the reference's own output lines, written by the adapter's log streams
+    assert any(l.startswith("OUT slice_id, target_rbs, quota_rbgs: (0, 25, 3) ") and "(9, 25, 6) " in l and "(16, 37, 4) " in l
+               and l.endswith("(19, 25, 3) ") for l in lines)
+    assert "OUT 100" in lines
+    assert "OUT User(1) allocated RBGS: 57(15) final_cqi: 15" in lines
+    assert "OUT User(7) allocated RBGS: 17(15) 18(15) 29(15) final_cqi: 15" in lines
+    assert "OUT User(45) allocated RBGS: 46(7) 51(10) 60(7) final_cqi: 7" in lines
+    assert "OUT User(47) allocated RBGS: 42(11) 45(8) final_cqi: 8" in lines
+    assert "ERR 100 app: 1 cumu_bytes: 749 cumu_rbs: 8 hol_delay: 0 user: 1 slice: 0" in lines
+    assert "ERR 100 app: 7 cumu_bytes: 2196 cumu_rbs: 24 hol_delay: 0 user: 7 slice: 1" in lines
+    assert "ERR 299 app: 5 cumu_bytes: 110838 cumu_rbs: 1336 hol_delay: 0 user: 5 slice: 1" in lines
