@@ -53,6 +53,31 @@ int fail(int code, const char* fmt, ...) {
     if (e__ != hipSuccess) return fail(RS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__));   \
   } while (0)
 
+/* scratch device buffers / events of one call: released on every return path */
+struct ScratchBuffers {
+  std::vector<void*> ptrs;
+  ~ScratchBuffers() { for (void* q : ptrs) (void)hipFree(q); }
+  template <typename T> hipError_t alloc(T** out, size_t bytes) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes ? bytes : 1);
+    if (e == hipSuccess) { ptrs.push_back(q); *out = (T*)q; }
+    return e;
+  }
+};
+struct ScratchEvents {
+  std::vector<hipEvent_t> ev;
+  ~ScratchEvents() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+  hipError_t create(int n) {
+    for (int i = 0; i < n; i++) {
+      hipEvent_t e = nullptr;
+      hipError_t rc = hipEventCreate(&e);
+      if (rc != hipSuccess) return rc;
+      ev.push_back(e);
+    }
+    return hipSuccess;
+  }
+};
+
 const int kCqiToMcs[15] = {RS_AMC_CQI_TO_MCS};
 const double kSinrForCqi[15] = {RS_AMC_SINR_FOR_CQI};
 const int kMcsToItbs[29] = {RS_AMC_MCS_TO_ITBS};
@@ -574,11 +599,12 @@ int rs_batch_run_logged(rs_batch* b, int32_t n_ttis, int16_t* h_map, int32_t* h_
   const size_t rows = (size_t)b->n_cells * n_ttis;
   int16_t *d_map = nullptr, *d_quota = nullptr, *d_target = nullptr;
   int32_t *d_tbs = nullptr, *d_uinfo = nullptr;
-  HIP_TRY(hipMalloc(&d_map, 2 * rows * b->R));
-  HIP_TRY(hipMalloc(&d_quota, 2 * rows * b->S));
-  HIP_TRY(hipMalloc(&d_target, 2 * rows * b->S));
-  HIP_TRY(hipMalloc(&d_tbs, 4 * rows * b->U));
-  HIP_TRY(hipMalloc(&d_uinfo, 4 * rows * b->U));
+  ScratchBuffers scratch;
+  HIP_TRY(scratch.alloc(&d_map, 2 * rows * b->R));
+  HIP_TRY(scratch.alloc(&d_quota, 2 * rows * b->S));
+  HIP_TRY(scratch.alloc(&d_target, 2 * rows * b->S));
+  HIP_TRY(scratch.alloc(&d_tbs, 4 * rows * b->U));
+  HIP_TRY(scratch.alloc(&d_uinfo, 4 * rows * b->U));
   HIP_TRY(hipMemsetAsync(d_tbs, 0, 4 * rows * b->U, b->stream));
   HIP_TRY(hipMemsetAsync(d_uinfo, 0, 4 * rows * b->U, b->stream));
   int rc = launch(b, n_ttis, d_map, d_quota, d_target, d_tbs, d_uinfo);
@@ -590,19 +616,15 @@ int rs_batch_run_logged(rs_batch* b, int32_t n_ttis, int16_t* h_map, int32_t* h_
     if (h_tbs) HIP_TRY(hipMemcpy(h_tbs, d_tbs, 4 * rows * b->U, hipMemcpyDeviceToHost));
     if (h_uinfo) HIP_TRY(hipMemcpy(h_uinfo, d_uinfo, 4 * rows * b->U, hipMemcpyDeviceToHost));
   }
-  (void)hipFree(d_map);
-  (void)hipFree(d_quota);
-  (void)hipFree(d_target);
-  (void)hipFree(d_tbs);
-  (void)hipFree(d_uinfo);
   return rc;
 }
 
 int rs_batch_run_timed(rs_batch* b, int32_t n_ttis, int32_t launches, float* ms) {
   if (!b || !ms || launches < 1) return fail(RS_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
-  std::vector<hipEvent_t> ev(launches + 1);
-  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  ScratchEvents events;
+  HIP_TRY(events.create(launches + 1));
+  std::vector<hipEvent_t>& ev = events.ev;
   int rc = RS_OK;
   HIP_TRY(hipEventRecord(ev[0], b->stream));
   for (int i = 0; i < launches && !rc; i++) {
@@ -612,7 +634,6 @@ int rs_batch_run_timed(rs_batch* b, int32_t n_ttis, int32_t launches, float* ms)
   if (!rc) rc = rs_batch_sync(b);
   if (!rc)
     for (int i = 0; i < launches; i++) HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
-  for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
 }
 
