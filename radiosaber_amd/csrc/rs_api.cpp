@@ -545,6 +545,8 @@ int rs_batch_synthesize_cqi(rs_batch* b, uint64_t seed, const double* w, int32_t
 int rs_batch_download_cqi_epochs(rs_batch* b, int32_t cell, uint8_t* h_cqi) {
   if (!b || !h_cqi || cell < 0 || cell >= b->n_cells) return fail(RS_ERR_INVALID, "bad argument");
   if (b->cqi_mode != RS_CQI_EPOCHS) return fail(RS_ERR_STATE, "no epoch grids on the device");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
   const size_t grid = (size_t)b->U * b->R, stride = (size_t)b->grid_stride;
   std::vector<uint8_t> tmp((size_t)b->n_epochs * stride);
   HIP_TRY(hipMemcpy(tmp.data(), b->d_epochs + (size_t)cell * b->n_epochs * stride, tmp.size(), hipMemcpyDeviceToHost));
@@ -556,6 +558,7 @@ int rs_batch_set_trace(rs_batch* b, const uint8_t* h_trace, int32_t n_traces, in
                        const int32_t* h_user_trace) {
   if (!b || !h_trace || !h_user_trace || n_traces < 1 || n_rows < 1 || row_modulus < 1)
     return fail(RS_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
   const size_t tb = (size_t)n_traces * n_rows * b->R;
   for (size_t i = 0; i < tb; i++)
     if (h_trace[i] < 1 || h_trace[i] > 15) return fail(RS_ERR_INVALID, "trace CQI %d outside 1..15", h_trace[i]);
