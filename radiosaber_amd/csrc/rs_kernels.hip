@@ -736,12 +736,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
          * wins.  eff is strictly increasing in CQI (0 for an empty slice), so integer keys compare alike. */
         const int quota = lane < S ? m->quota[lane] : 0;
         int my_slice = -1;
+        /* the next RBG's keys are loaded while this one is decided */
+        const uint32_t* colp = s_elems + (lane < S ? lane : 0);
+        uint32_t e_next = colp[0];
         for (int r = 0; r < R; ++r) {
-          int key = lane < S ? (int)(s_elems[r * S + lane] >> 16) : -1;
-          bool ok = lane < S && got < quota;
-          int packed = ok ? (key << 6) | (63 - lane) : -1;
-          int bestp = wave_max(packed);
-          int sl = bestp < 0 ? -1 : 63 - (bestp & 63);
+          const int key = (int)(e_next >> 16);
+          e_next = colp[(r + 1 < R ? r + 1 : r) * S];
+          const bool ok = lane < S && got < quota;
+          const int packed = ok ? (key << 6) | (63 - lane) : -1;
+          const int bestp = wave_max(packed);
+          const int sl = bestp < 0 ? -1 : 63 - (bestp & 63);
           if (lane == sl) got++;
           if (lane == r) my_slice = sl;
         }
