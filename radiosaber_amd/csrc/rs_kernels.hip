@@ -889,7 +889,17 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
          * here over the segment winners in ascending segment order */
         if (lane < R) {
           double best = 0.0;
-          for (int sg = 0; sg < o.n_seg; ++sg) {
+          int sg = 0;
+          for (; sg + 4 <= o.n_seg; sg += 4) { /* four segments per step: the eight LDS reads first */
+            double v[4];
+            int u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = s_best_metric[(sg + q) * R + lane]; u[q] = s_best_user[(sg + q) * R + lane]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (u[q] != 0xFFFF && v[q] > best) { best = v[q]; owner = u[q]; }
+          }
+          for (; sg < o.n_seg; ++sg) {
             double v = s_best_metric[sg * R + lane];
             int u = s_best_user[sg * R + lane];
             if (u != 0xFFFF && v > best) { best = v; owner = u; }
