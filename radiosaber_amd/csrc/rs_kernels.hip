@@ -322,15 +322,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           if (zero) {
             pick = __ffsll((long long)zero) - 1;
           } else {
-            double best = has ? s_w[lane] / ew : -1.0;
-            int bl = has ? lane : -1;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-              double ob = __shfl_xor(best, o, 64);
-              int ol = __shfl_xor(bl, o, 64);
-              if (ob > best || (ob == best && ol > bl)) { best = ob; bl = ol; }
-            }
-            pick = hasm ? (bl < 0 ? 0 : bl) : 0;
+            /* scores are >= 0 (-1 for a slice without users), so they order like the integer pair (high word signed, low
+             * word unsigned): two DPP max reductions instead of a shuffle tree on doubles */
+            const double score = has ? s_w[lane] / ew : -1.0;
+            const int hi = __double2hiint(score);
+            const int lo = (int)((unsigned)__double2loint(score) ^ 0x80000000u);
+            const int mhi = wave_max(hi);
+            const int mlo = wave_max(hi == mhi ? lo : (int)0x80000000);
+            const unsigned long long top = __ballot(hi == mhi && lo == mlo) & hasm;
+            pick = top ? 63 - __clzll((long long)top) : 0;
           }
           const double beta = 0.01;
           if (has) {
