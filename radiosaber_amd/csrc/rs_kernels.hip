@@ -469,15 +469,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             pf = 0;
             for (int r = 0; r < R; ++r) pf += nv_hm[lane * R + r];
           }
-          double mx = pf;
-#pragma unroll
-          for (int o2 = 32; o2 > 0; o2 >>= 1) {
-            const double ot = __shfl_xor(mx, o2, 64);
-            mx = ot > mx ? ot : mx;
-          }
+          /* scores are >= 0 (-1 on unused lanes): they order like (high word signed, low word unsigned) */
+          const int hi = __double2hiint(pf);
+          const int lo = (int)((unsigned)__double2loint(pf) ^ 0x80000000u);
+          const int mhi = wave_max(hi);
+          const int mlo = wave_max(hi == mhi ? lo : (int)0x80000000);
+          const double mx = __hiloint2double(mhi, (int)((unsigned)mlo ^ 0x80000000u));
           if (best < mx) { /* :442-446: the first sample that reaches the new maximum */
             best = mx;
-            const int win = __ffsll((long long)__ballot(lane < nb && pf == mx)) - 1;
+            const int win = __ffsll((long long)__ballot(lane < nb && hi == mhi && lo == mlo)) - 1;
             if (lane < R) s_best_user[lane] = nv_ha[win * R + lane];
           }
         }
