@@ -255,6 +255,7 @@ int upad_of(int U) { return rs_upad_of(U); }
 void carve_lds(rs_batch* b, RsLaunch* L) {
   const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads);
   L->Upad = c.Upad;
+  L->nvs_seg = c.nvs_seg;
   L->off_avgk = c.off_avgk; L->off_rcp = c.off_rcp; L->off_tab = c.off_tab; L->off_slice = c.off_slice;
   L->off_tx = c.off_tx; L->off_misc = c.off_misc; L->off_tbs = c.off_tbs; L->off_elems = c.off_elems;
   L->off_sorted = c.off_sorted; L->off_items = c.off_items; L->off_sortx = c.off_sortx; L->off_cqi = c.off_cqi;

@@ -45,7 +45,7 @@ struct RsMisc {
 /* LDS carve of one cell (byte offsets from the dynamic LDS base), a pure function of the cell shape so
  * that the host and a shape-specialised kernel build agree on it */
 struct RsCarve {
-  int Upad, n_seg, n_items, ept;
+  int Upad, n_seg, n_items, ept, nvs_seg;
   int off_avgk, off_rcp, off_tab, off_slice, off_tx, off_misc, off_tbs, off_elems, off_sorted, off_items,
       off_sortx, off_cqi, lds_bytes;
 };
@@ -63,12 +63,19 @@ constexpr int rs_upad_of(int U) {
 constexpr int rs_nvs_scratch_bytes(int U, int R) {
   return 32 * U + 8 * RS_NVS_BATCH * R + RS_NVS_DRAW_BYTES + 2 * RS_NVS_BATCH * R + 128 + (U + 15) / 16 * 16;
 }
-constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads) {
+/* sched 7: the served slice is scanned in 8-aligned runs of nvs_seg users, one work item per (run, RBG); the run winners
+ * (user u16 + metric f64 per RBG) are reduced per RBG in ascending order afterwards.  With slices of more than 32 users on
+ * average rs_carve picks the smallest run length in {8, 16, 32} that keeps the cell at or under 80 KB of LDS (two cells per
+ * CU); otherwise nvs_seg = 0: one work item per RBG scans the whole slice (measured on 25-user slices: runs cost 8-10 %). */
+constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int nvs_seg) {
   RsCarve c{};
   c.Upad = rs_upad_of(U);
-  c.n_seg = sched == 1 ? (U + RS_PF_SEG - 1) / RS_PF_SEG : ((sched == 7 || sched == 11) ? 1 : S);
+  c.nvs_seg = nvs_seg;
+  c.n_seg = sched == 1 ? (U + RS_PF_SEG - 1) / RS_PF_SEG
+                     : (sched == 7 ? (nvs_seg ? (U + nvs_seg - 1) / nvs_seg + 1 : 1) : (sched == 11 ? 1 : S));
   c.n_items = R * c.n_seg;
   c.ept = (R * S + threads - 1) / threads;
+  const bool pf_like = sched == 1 || (sched == 7 && nvs_seg != 0); /* winner tables instead of sort records */
   int off = 8 * U; /* avg */
   c.off_avgk = off; off += 8 * U;
   c.off_rcp = off; off += rs_round_up(4 * c.Upad, 16);
@@ -77,8 +84,8 @@ constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads) {
   c.off_tx = off; off += rs_round_up(4 * U, 16);
   c.off_misc = off; off += rs_round_up((int)sizeof(RsMisc), 16);
   c.off_tbs = off; off += rs_round_up(4 * 27 * (R + 1), 16);
-  c.off_elems = off; off += rs_round_up(sched == 1 ? 8 * c.n_items : 4 * R * S, 16);
-  c.off_sorted = off; off += rs_round_up(4 * R * S, 16);
+  c.off_elems = off; off += rs_round_up(pf_like ? 8 * c.n_items : 4 * R * S, 16);
+  c.off_sorted = off; off += (sched == 7 && nvs_seg != 0) ? 0 : rs_round_up(4 * R * S, 16);
   c.off_items = off; off += rs_round_up(2 * c.n_items, 16);
   /* level-synchronous introsort scratch: cut per sub-range (+ bounds/pivots when the state lives in LDS) */
   c.off_sortx = off; off += (sched == 9 || sched == 10) ? rs_round_up((c.ept <= 4 ? 2 : 8) * R * S, 16)
@@ -86,6 +93,16 @@ constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads) {
   c.off_cqi = off; off += rs_round_up(c.Upad * R, 16);
   c.lds_bytes = off;
   return c;
+}
+constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads) {
+  if (sched == 7 && U > 32 * S) { /* slices of more than 32 users on average: one run per work item is too long */
+    for (int seg = 8; seg <= 16; seg *= 2) {
+      const RsCarve c = rs_carve_with(S, U, R, sched, threads, seg);
+      if (c.lds_bytes <= 80 * 1024) return c;
+    }
+  }
+  if (sched == 7 && U > 32 * S) return rs_carve_with(S, U, R, sched, threads, 32);
+  return rs_carve_with(S, U, R, sched, threads, 0); /* sched 7 with small slices: one work item per RBG scans the whole slice */
 }
 
 /* link-adaptation constants (host libm -> device), see rs_link_tables() in radiosaber_hip.h */
@@ -119,6 +136,7 @@ struct RsLaunch {
   /* geometry */
   int32_t S, U, R, G;        /* slices, users, RBGs, PRBs per RBG */
   int32_t Upad;              /* LDS row stride of the RBG-major CQI grid: 8 * odd >= U */
+  int32_t nvs_seg;           /* sched 7: users per scanned run of the served slice (rs_carve) */
   int32_t sched;
   int32_t n_cells, n_ttis;
   int32_t refresh, phy_draws;

@@ -347,7 +347,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         m->quota[lane] = 0;
       }
     }
-    int seg_lo = 0; /* NVS: the served slice */
+    int seg_lo = 0;   /* NVS: the served slice */
+    int nvs_runs = 1; /* sched 7: runs of the served slice scanned in P3 */
     if (SCHED == 7 || SCHED == 11) {
       __syncthreads(); /* P3 scans the slice P2 picked */
       seg_lo = p.direct ? 0 : m->nvs_slice;
@@ -487,12 +488,29 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 
     /* ---------------- P3: best user of every (RBG, segment) ---------------- */
     if constexpr (SCHED != 11) {
-      const int n_items = o.n_items;
+      /* sched 7: the served slice in 8-aligned runs of nvs_seg users, so that a slice of a few dozen users keeps several waves
+       * busy instead of R lanes; the run winners meet in P4 */
+      const int nvs_seg = FIXED ? kCv.nvs_seg : p.nvs_seg;
+      int nvs_lo = 0, nvs_hi = 0, nvs_first = 0;
+      const bool nvs_split = SCHED == 7 && nvs_seg != 0;
+      if (nvs_split) {
+        nvs_lo = p.direct ? 0 : m->seg_begin[seg_lo];
+        nvs_hi = p.direct ? U : m->seg_begin[seg_lo + 1];
+        nvs_first = nvs_lo & ~7;
+        nvs_runs = idiv_small(nvs_hi - nvs_first + nvs_seg - 1, nvs_seg);
+      }
+      const int n_items = nvs_split ? R * nvs_runs : o.n_items;
       for (int it = tid; it < n_items; it += nt) {
         int sg = it / R, r = it - sg * R; /* r fastest: neighbouring lanes read neighbouring CQI bytes */
         int seg = SCHED == 7 ? seg_lo : sg;
         int ub = m->seg_begin[seg], ue = m->seg_begin[seg + 1];
         if (SCHED == 7 && p.direct) { ub = 0; ue = U; }
+        if (nvs_split) {
+          ub = nvs_first + sg * nvs_seg;
+          ue = ub + nvs_seg;
+          ub = ub < nvs_lo ? nvs_lo : ub;
+          ue = ue > nvs_hi ? nvs_hi : ue;
+        }
         double best = SCHED == 1 ? 0.0 : (SCHED == 7 ? -1.7976931348623157e308 : -1.0);
         int bu = -1, bkey = 0;
         int sl_eps = 1, sl_psi = 1;
@@ -512,20 +530,22 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
          * Stage 1 reads 8 users per step (one 8-byte CQI load, two 16-byte reciprocal loads), keeps
          * the 32 products of a block in registers, takes their maximum, then marks the survivors. */
         const float kTol = 0x1.ffffcp-1f; /* 1 - 2^-19 */
+        /* sched 7 scans runs of 8..32 users: a shape-specialised build ranks exactly one run per block */
+        constexpr int kP3Block = (SCHED == 7 && FIXED && kCv.nvs_seg != 0) ? kCv.nvs_seg : RS_P3_BLOCK;
         const bool one_num = SCHED != 1 && !sl_eps;
         const float* numtab = one_num ? m->ones16 : s_num32; /* a table either way: no branch per user */
         const unsigned seg_len = (unsigned)(ue - ub);
 #ifdef RS_EXP_P3_SKIP
         bu = ub; bkey = rowp[ub]; best = 1.0; /* timing experiment only: wrong results */
-        for (int blk = ue; blk < ue; blk += RS_P3_BLOCK) {
+        for (int blk = ue; blk < ue; blk += kP3Block) {
 #else
-        for (int blk = ub & ~7; blk < ue; blk += RS_P3_BLOCK) {
+        for (int blk = ub & ~7; blk < ue; blk += kP3Block) {
 #endif
           /* a~ of the 32 users blk..blk+31 (0 for users outside [ub, ue) and for the padding) */
-          float av[RS_P3_BLOCK];
+          float av[kP3Block];
           float best_a = 0.0f;
 #pragma unroll
-          for (int g = 0; g < RS_P3_BLOCK / 8; ++g) {
+          for (int g = 0; g < kP3Block / 8; ++g) {
             const int u0 = blk + 8 * g;
             uint2 cw = make_uint2(0u, 0u);
             float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
@@ -555,7 +575,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           const float thr = best_a * kTol;
           uint32_t cand = 0;
 #pragma unroll
-          for (int k = 0; k < RS_P3_BLOCK; ++k) cand |= (av[k] >= thr && av[k] > 0.0f) ? (1u << k) : 0u;
+          for (int k = 0; k < kP3Block; ++k) cand |= (av[k] >= thr && av[k] > 0.0f) ? (1u << k) : 0u;
           /* customised slices can rank every user at 0 (no prioritized data): the reference's scan then
            * keeps the first user (0 > -1), so that user goes to stage 2 */
           if (sl_custom && !cand) cand = 1u << ((ub > blk ? ub : blk) - blk);
@@ -585,7 +605,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         } else if (kTransport) {
           /* MaximizeCell's vector is RBG-major, slice-minor (:357-360) */
           s_elems[r * S + sg] = ((uint32_t)bkey << 16) | ((uint32_t)r << 8) | (uint32_t)sg;
-        } else if (SCHED == 1) {
+        } else if (SCHED == 1 || nvs_split) {
           s_best_metric[it] = best;
         }
       }
@@ -903,6 +923,18 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             double v = s_best_metric[sg * R + lane];
             int u = s_best_user[sg * R + lane];
             if (u != 0xFFFF && v > best) { best = v; owner = u; }
+          }
+        }
+      } else if (SCHED == 7 && (FIXED ? kCv.nvs_seg : p.nvs_seg) != 0) {
+        /* ref: downlink-nvs-scheduler.cpp:283-297 -- per RBG the first maximum from lowest(), over the run winners in
+         * ascending run order */
+        if (lane < R) {
+          double best = -1.7976931348623157e308;
+          bool none = true;
+          for (int sg = 0; sg < nvs_runs; ++sg) {
+            const double v = s_best_metric[sg * R + lane];
+            const int u = s_best_user[sg * R + lane];
+            if (u != 0xFFFF && (none || v > best)) { best = v; owner = u; none = false; }
           }
         }
       } else {

@@ -581,3 +581,23 @@ def test_every_shipped_experiment_configuration(rs, oracle):
         assert st["avg_rate"][0].tobytes() == ost["avg_rate"].tobytes(), (name, sched)
         assert st["slice_state"][0].tobytes() == ost["slice_state"].tobytes(), (name, sched)
         b.close()
+
+
+def test_drop_in_nvs_big_slice(rs, oracle):
+    """sched 7 with slices of more than 32 users on average takes the split scan (runs of the served slice reduced per
+    RBG); here through the drop-in entry point, against the first-maximum rule written out in numpy."""
+    ues, R, G = [45, 40], 25, 4
+    sc = rs.SliceConfig(ues)
+    ts = rs.TtiScheduler(sc, R, G, sched=7)
+    rng = np.random.default_rng(31)
+    kb = rs.link_tables()["kbps"]
+    for it in range(6):
+        cqi = synth_cqi(700 + it, (sc.n_users, R), HIST)
+        avg = rng.uniform(1e3, 5e6, sc.n_users)
+        if it % 2 == 0:
+            avg[:] = 98000.0  # exact ties: the FIRST maximum must win across run boundaries
+        ids = np.arange(0, 45) if it % 2 else np.arange(45, 85)
+        res = ts.schedule_tti(cqi[ids], avg[ids], user_id=ids)
+        met = kb[cqi[ids]] / ((1 + avg[ids]) / 1000.0)[:, None]
+        np.testing.assert_array_equal(res.rbg_to_user, ids[np.argmax(met, axis=0)])
+    ts.close()
