@@ -75,6 +75,10 @@ namespace {
 template <int SCHED, int EPT, bool FIXED>
 __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* lds) {
   const int cell = blockIdx.x;
+  /* only the drop-in entry point uses these; the shape-specialised kernel serves batches, where they are constant */
+  const bool kDirect = FIXED ? false : (p.direct != 0);
+  const uint8_t* const prb_cqi_in = FIXED ? nullptr : p.prb_cqi;
+  const int queue_mode_in = FIXED ? 0 : p.queue_mode;
   const int tid = threadIdx.x;
   const int nt = FIXED ? RS_JIT_NT : (int)blockDim.x;
   const int lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
@@ -116,7 +120,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   for (int u = tid; u < U; u += nt) {
     s_avg[u] = p.avg[(size_t)cell * U + u];
     s_tx[u] = p.tx_bytes[(size_t)cell * U + u];
-    if (p.direct) { /* rs_schedule_tti: one row of per-user outputs, cleared here instead of by a memset */
+    if (kDirect) { /* rs_schedule_tti: one row of per-user outputs, cleared here instead of by a memset */
       if (p.log_tbs) p.log_tbs[u] = 0;
       if (p.log_uinfo) p.log_uinfo[u] = 0;
     }
@@ -186,8 +190,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     RS_STAMP(11);
     /* ---------------- P0: CQI refresh ---------------- */
     if (p.cqi_mode == RS_CQI_EPOCHS) {
-      if (p.direct || n_done % p.refresh == 0) {
-        long long e = p.direct ? 0 : n_done / p.refresh;
+      if (kDirect || n_done % p.refresh == 0) {
+        long long e = kDirect ? 0 : n_done / p.refresh;
         if (e >= p.n_epochs) { local_err = RS_CQI_EPOCHS; e = p.n_epochs - 1; }
         /* HBM grid is [U][R] (one row per UE, like the reference's per-UE CQI vectors); LDS keeps it
          * RBG-major [R][Upad] so that the metric scan reads 8 consecutive UEs of one RBG per load */
@@ -224,7 +228,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
     /* ---------------- P1: PF EWMA (ref: src/flows/radio-bearer.cpp:139-164) ---------------- */
     {
-      const bool do_ewma = !p.direct && !(t == last_update);
+      const bool do_ewma = !kDirect && !(t == last_update);
       const double dt = t - last_update;
       for (int u = tid, ku = 0; u < U; u += nt, ++ku) {
         double a = s_avg[u];
@@ -244,7 +248,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           s_avgk[u] = k;
           /* stage-1 ranking only, never part of a result; psi == 0 slices rank on the numerator */
           float r32 = ((psi_mask >> ku) & 1u) ? __builtin_amdgcn_rcpf((float)k) : 1.0f; /* v_rcp_f32, 1 ulp */
-          if (p.queue_mode) {
+          if (queue_mode_in) {
             /* customised slice (ref: :694-711): metric 0 while the prioritized bearer is empty, times the
              * head-of-line delay when beta (sched 7: always) -- folded into the stage-1 factor */
             const int sl = p.user_slice[u];
@@ -259,7 +263,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           s_rcp32[u] = __builtin_amdgcn_rcpf((float)a);
         }
       }
-      if (!p.direct) last_update = t;
+      if (!kDirect) last_update = t;
     }
     __syncthreads();
     RS_STAMP(0);
@@ -267,7 +271,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     /* ---------------- P2: quotas / slice choice (one wave, lanes = slices) ---------------- */
     if (wave == quota_wave) {
       int r0 = p.rand0, r1 = p.rand1;
-      if (!p.direct) {
+      if (!kDirect) {
         if (p.phy_draws)
           for (int i = 0; i < served_prev; i++) (void)rng.next();
         if (kTransport) {
@@ -310,7 +314,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       } else if (SCHED == 7 || SCHED == 11) {
         /* SelectSliceToServe, ref: downlink-nvs-scheduler.cpp:94-142 */
         int pick;
-        if (p.direct) {
+        if (kDirect) {
           pick = 0; /* the caller passes only the served slice's users */
         } else {
           const bool in = lane < S;
@@ -351,7 +355,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     int nvs_runs = 1; /* sched 7: runs of the served slice scanned in P3 */
     if (SCHED == 7 || SCHED == 11) {
       __syncthreads(); /* P3 scans the slice P2 picked */
-      seg_lo = p.direct ? 0 : m->nvs_slice;
+      seg_lo = kDirect ? 0 : m->nvs_slice;
     }
     RS_STAMP(1);
 
@@ -370,7 +374,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       uint16_t* nv_ha = (uint16_t*)(nv_draw + RS_NVS_DRAW_BYTES);
       uint8_t* nv_high = (uint8_t*)(nv_ha + RS_NVS_BATCH * R) + 128;
       int ub = m->seg_begin[seg_lo], ue = m->seg_begin[seg_lo + 1];
-      if (p.direct) { ub = 0; ue = U; }
+      if (kDirect) { ub = 0; ue = U; }
       const int n = ue - ub;
       for (int i = tid; i < n; i += nt) {
         const int u = ub + i;
@@ -390,7 +394,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       }
       if (tid < R) s_best_user[tid] = 0xFFFF;
       /* the generator wave draws batch b+1 into the other half of the draw buffer while the other waves scan batch b */
-      const bool overlap = !p.direct && nwaves > 1;
+      const bool overlap = !kDirect && nwaves > 1;
       const int half = RS_NVS_DRAW_BYTES / 2;
       int bs = (overlap ? half : RS_NVS_DRAW_BYTES) / (n > 0 ? n : 1);
       bs = bs > RS_NVS_BATCH ? RS_NVS_BATCH : bs;
@@ -420,7 +424,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         const int nb = RS_NVS_SAMPLES - b0 < bs ? RS_NVS_SAMPLES - b0 : bs;
         const int total = nb * n;
         const uint8_t* cur = overlap ? nv_draw + flip * half : nv_draw;
-        if (p.direct) {
+        if (kDirect) {
           /* drop-in: the caller passes the rand() values it drew, in draw order */
           for (int j = tid; j < total; j += nt) nv_draw[j] = (uint8_t)(p.draws[(size_t)b0 * n + j] & 3);
           __syncthreads();
@@ -494,8 +498,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       int nvs_lo = 0, nvs_hi = 0, nvs_first = 0;
       const bool nvs_split = SCHED == 7 && nvs_seg != 0;
       if (nvs_split) {
-        nvs_lo = p.direct ? 0 : m->seg_begin[seg_lo];
-        nvs_hi = p.direct ? U : m->seg_begin[seg_lo + 1];
+        nvs_lo = kDirect ? 0 : m->seg_begin[seg_lo];
+        nvs_hi = kDirect ? U : m->seg_begin[seg_lo + 1];
         nvs_first = nvs_lo & ~7;
         nvs_runs = idiv_small(nvs_hi - nvs_first + nvs_seg - 1, nvs_seg);
       }
@@ -504,7 +508,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         int sg = it / R, r = it - sg * R; /* r fastest: neighbouring lanes read neighbouring CQI bytes */
         int seg = SCHED == 7 ? seg_lo : sg;
         int ub = m->seg_begin[seg], ue = m->seg_begin[seg + 1];
-        if (SCHED == 7 && p.direct) { ub = 0; ue = U; }
+        if (SCHED == 7 && kDirect) { ub = 0; ue = U; }
         if (nvs_split) {
           ub = nvs_first + sg * nvs_seg;
           ue = ub + nvs_seg;
@@ -516,10 +520,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         int sl_eps = 1, sl_psi = 1;
         int sl_custom = 0; /* 1: alpha slice, 2: alpha slice with the HoL factor */
         if (SCHED != 1) {
-          int sl = SCHED == 7 ? (p.direct ? (int)p.user_slice[0] : seg) : seg;
+          int sl = SCHED == 7 ? (kDirect ? (int)p.user_slice[0] : seg) : seg;
           sl_eps = p.eps[sl];
           sl_psi = p.psi[sl];
-          if (p.queue_mode && p.alpha[sl]) sl_custom = (SCHED == 7 || p.beta[sl] != 0) ? 2 : 1;
+          if (queue_mode_in && p.alpha[sl]) sl_custom = (SCHED == 7 || p.beta[sl] != 0) ? 2 : 1;
         }
         const uint8_t* rowp = s_cqi + r * Upad;
         /* Exact two-stage argmax.  Stage 1 ranks the segment's users by the cheap
@@ -695,8 +699,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         for (int y = x; y < f + q; ++y) {
           if (ent_user[y] != u) continue;
           const int r2 = (int)((s_sorted[y] >> 8) & 63u);
-          if (p.prb_cqi) {
-            const uint8_t* pr = p.prb_cqi + ((size_t)u * R + r2) * G;
+          if (prb_cqi_in) {
+            const uint8_t* pr = prb_cqi_in + ((size_t)u * R + r2) * G;
             for (int g = 0; g < G; ++g) sum += s_e[pr[g]];
           } else {
             const double ev = s_e[s_cqi[r2 * Upad + u]];
@@ -966,9 +970,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         while (mm) {
           const int r2 = __ffsll((long long)mm) - 1;
           mm &= mm - 1;
-          if (p.prb_cqi) {
+          if (prb_cqi_in) {
             /* per-PRB reports (drop-in mode with the simulated channel): read the RBG's PRBs from HBM */
-            const uint8_t* pr = p.prb_cqi + ((size_t)owner * R + r2) * G;
+            const uint8_t* pr = prb_cqi_in + ((size_t)owner * R + r2) * G;
             for (int k = 0; k < G; ++k) sum += s_e[pr[k]];
           } else {
             const double ev = s_e[col[r2 * Upad]];
@@ -1026,7 +1030,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     RS_STAMP(8);
     served_prev = m->served;
     n_done += 1;
-    if (!p.direct) t += 0.001; /* ref: src/core/eventScheduler/simulator.cc:117-126 */
+    if (!kDirect) t += 0.001; /* ref: src/core/eventScheduler/simulator.cc:117-126 */
   }
 
   /* ---------------- store the cell ---------------- */
