@@ -683,18 +683,18 @@ const char* rs_batch_kernel_name(rs_batch* b) {
   if (!b) return "";
   if (b->jit) return "rs_cell_kernel_jit";
   switch (b->sched) {
-    case 1: return "rs_cell_kernel<1, 0>";
-    case 7: return "rs_cell_kernel<7, 0>";
-    case 8: return "rs_cell_kernel<8, 0>";
-    case RS_SCHED_VOGEL: return "rs_cell_kernel<103, 0>";
-    case RS_SCHED_NVS_NONGREEDY: return "rs_cell_kernel<11, 0>";
+    case 1: return "rs_cell_kernel<1, 0, false>";
+    case 7: return "rs_cell_kernel<7, 0, false>";
+    case 8: return "rs_cell_kernel<8, 0, false>";
+    case RS_SCHED_VOGEL: return "rs_cell_kernel<103, 0, false>";
+    case RS_SCHED_NVS_NONGREEDY: return "rs_cell_kernel<11, 0, false>";
     case RS_SCHED_UPPERBOUND: {
       const int ept = (b->R * b->S + b->threads - 1) / b->threads;
-      return ept <= 1 ? "rs_cell_kernel<10, 1>" : ept <= 2 ? "rs_cell_kernel<10, 2>" : ept <= 3 ? "rs_cell_kernel<10, 3>" : "rs_cell_kernel<10, 4>";
+      return ept <= 1 ? "rs_cell_kernel<10, 1, false>" : ept <= 2 ? "rs_cell_kernel<10, 2, false>" : ept <= 3 ? "rs_cell_kernel<10, 3, false>" : "rs_cell_kernel<10, 4, false>";
     }
     default: {
       const int ept = (b->R * b->S + b->threads - 1) / b->threads;
-      return ept <= 1 ? "rs_cell_kernel<9, 1>" : ept <= 2 ? "rs_cell_kernel<9, 2>" : ept <= 3 ? "rs_cell_kernel<9, 3>" : ept <= 4 ? "rs_cell_kernel<9, 4>" : "rs_cell_kernel<9, 0>";
+      return ept <= 1 ? "rs_cell_kernel<9, 1, false>" : ept <= 2 ? "rs_cell_kernel<9, 2, false>" : ept <= 3 ? "rs_cell_kernel<9, 3, false>" : ept <= 4 ? "rs_cell_kernel<9, 4, false>" : "rs_cell_kernel<9, 0, false>";
     }
   }
 }

@@ -72,13 +72,14 @@ namespace {
 #define RS_JIT_SCHED 8
 #endif
 
-template <int SCHED, int EPT, bool FIXED>
+template <int SCHED, int EPT, bool FIXED, bool DIRECT>
 __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* lds) {
   const int cell = blockIdx.x;
-  /* only the drop-in entry point uses these; the shape-specialised kernel serves batches, where they are constant */
-  const bool kDirect = FIXED ? false : (p.direct != 0);
-  const uint8_t* const prb_cqi_in = FIXED ? nullptr : p.prb_cqi;
-  const int queue_mode_in = FIXED ? 0 : p.queue_mode;
+  /* only the drop-in entry point (DIRECT: one TTI on caller-provided state) uses these; batches never do, and their
+   * kernels carry neither the code nor the registers */
+  constexpr bool kDirect = DIRECT;
+  const uint8_t* const prb_cqi_in = DIRECT ? p.prb_cqi : nullptr;
+  const int queue_mode_in = DIRECT ? p.queue_mode : 0;
   const int tid = threadIdx.x;
   const int nt = FIXED ? RS_JIT_NT : (int)blockDim.x;
   const int lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
@@ -1064,10 +1065,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 }  // namespace
 
 #ifndef RS_JIT_BUILD
-template <int SCHED, int EPT>
+template <int SCHED, int EPT, bool DIRECT>
 __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
   extern __shared__ __align__(16) unsigned char lds[];
-  rs_cell_body<SCHED, EPT, false>(p, lds);
+  rs_cell_body<SCHED, EPT, false, DIRECT>(p, lds);
 }
 #else
 /* shape-specialised entry point compiled at run time (rs_jit.cpp): static LDS of exactly the carve's size */
@@ -1075,7 +1076,7 @@ extern "C" __global__ void __launch_bounds__(RS_JIT_NT, 4) rs_cell_kernel_jit(Rs
   constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT);
   __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
   constexpr int kEpt = (RS_JIT_SCHED != 9 && RS_JIT_SCHED != 10) ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);
-  rs_cell_body<RS_JIT_SCHED, kEpt, true>(p, lds);
+  rs_cell_body<RS_JIT_SCHED, kEpt, true, false>(p, lds);
 }
 #endif
 
@@ -1149,25 +1150,31 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
   dim3 grid(p->n_cells), block(threads);
   const int N = p->R * p->S;
   const int ept = (N + threads - 1) / threads;
+  /* batches and the drop-in entry point (p->direct) run different instantiations */
+#define RS_LAUNCH_CELL(SCHED_, EPT_)                                                                             \
+  do {                                                                                                           \
+    if (p->direct) hipLaunchKernelGGL((rs_cell_kernel<SCHED_, EPT_, true>), grid, block, p->lds_bytes, stream, *p); \
+    else hipLaunchKernelGGL((rs_cell_kernel<SCHED_, EPT_, false>), grid, block, p->lds_bytes, stream, *p);         \
+  } while (0)
   switch (p->sched) {
-    case 1: hipLaunchKernelGGL((rs_cell_kernel<1, 0>), grid, block, p->lds_bytes, stream, *p); break;
-    case 7: hipLaunchKernelGGL((rs_cell_kernel<7, 0>), grid, block, p->lds_bytes, stream, *p); break;
-    case 8: hipLaunchKernelGGL((rs_cell_kernel<8, 0>), grid, block, p->lds_bytes, stream, *p); break;
-    case 103: hipLaunchKernelGGL((rs_cell_kernel<103, 0>), grid, block, p->lds_bytes, stream, *p); break;
-    case 11: hipLaunchKernelGGL((rs_cell_kernel<11, 0>), grid, block, p->lds_bytes, stream, *p); break;
+    case 1: RS_LAUNCH_CELL(1, 0); break;
+    case 7: RS_LAUNCH_CELL(7, 0); break;
+    case 8: RS_LAUNCH_CELL(8, 0); break;
+    case 103: RS_LAUNCH_CELL(103, 0); break;
+    case 11: RS_LAUNCH_CELL(11, 0); break;
     case 10:
-      if (ept <= 1) hipLaunchKernelGGL((rs_cell_kernel<10, 1>), grid, block, p->lds_bytes, stream, *p);
-      else if (ept <= 2) hipLaunchKernelGGL((rs_cell_kernel<10, 2>), grid, block, p->lds_bytes, stream, *p);
-      else if (ept <= 3) hipLaunchKernelGGL((rs_cell_kernel<10, 3>), grid, block, p->lds_bytes, stream, *p);
-      else if (ept <= 4) hipLaunchKernelGGL((rs_cell_kernel<10, 4>), grid, block, p->lds_bytes, stream, *p);
+      if (ept <= 1) RS_LAUNCH_CELL(10, 1);
+      else if (ept <= 2) RS_LAUNCH_CELL(10, 2);
+      else if (ept <= 3) RS_LAUNCH_CELL(10, 3);
+      else if (ept <= 4) RS_LAUNCH_CELL(10, 4);
       else return hipErrorInvalidValue;
       break;
     case 9:
-      if (ept <= 1) hipLaunchKernelGGL((rs_cell_kernel<9, 1>), grid, block, p->lds_bytes, stream, *p);
-      else if (ept <= 2) hipLaunchKernelGGL((rs_cell_kernel<9, 2>), grid, block, p->lds_bytes, stream, *p);
-      else if (ept <= 3) hipLaunchKernelGGL((rs_cell_kernel<9, 3>), grid, block, p->lds_bytes, stream, *p);
-      else if (ept <= 4) hipLaunchKernelGGL((rs_cell_kernel<9, 4>), grid, block, p->lds_bytes, stream, *p);
-      else hipLaunchKernelGGL((rs_cell_kernel<9, 0>), grid, block, p->lds_bytes, stream, *p);
+      if (ept <= 1) RS_LAUNCH_CELL(9, 1);
+      else if (ept <= 2) RS_LAUNCH_CELL(9, 2);
+      else if (ept <= 3) RS_LAUNCH_CELL(9, 3);
+      else if (ept <= 4) RS_LAUNCH_CELL(9, 4);
+      else RS_LAUNCH_CELL(9, 0);
       break;
     default: return hipErrorInvalidValue;
   }
@@ -1175,12 +1182,12 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
 }
 
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes) {
-  const void* fns[] = {(const void*)rs_cell_kernel<1, 0>, (const void*)rs_cell_kernel<7, 0>, (const void*)rs_cell_kernel<8, 0>, (const void*)rs_cell_kernel<103, 0>,
-                       (const void*)rs_cell_kernel<11, 0>,
-                       (const void*)rs_cell_kernel<10, 1>, (const void*)rs_cell_kernel<10, 2>, (const void*)rs_cell_kernel<10, 3>,
-                       (const void*)rs_cell_kernel<10, 4>,
-                       (const void*)rs_cell_kernel<9, 0>, (const void*)rs_cell_kernel<9, 1>, (const void*)rs_cell_kernel<9, 2>, (const void*)rs_cell_kernel<9, 3>,
-                       (const void*)rs_cell_kernel<9, 4>};
+#define RS_BOTH(SCHED_, EPT_) (const void*)rs_cell_kernel<SCHED_, EPT_, false>, (const void*)rs_cell_kernel<SCHED_, EPT_, true>
+  const void* fns[] = {RS_BOTH(1, 0),  RS_BOTH(7, 0),  RS_BOTH(8, 0),  RS_BOTH(103, 0), RS_BOTH(11, 0),
+                       RS_BOTH(10, 1), RS_BOTH(10, 2), RS_BOTH(10, 3), RS_BOTH(10, 4),
+                       RS_BOTH(9, 0),  RS_BOTH(9, 1),  RS_BOTH(9, 2),  RS_BOTH(9, 3),  RS_BOTH(9, 4)};
+#undef RS_BOTH
+
   for (const void* f : fns) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds_bytes);
     if (e != hipSuccess) return e;
