@@ -30,7 +30,7 @@ struct RsMisc {
   int32_t seg_begin[68];
   int32_t target[64];
   int32_t quota[64];
-  int32_t stack[96];             /* serial introsort emulation (debug path) */
+  int32_t stack[96];             /* serial introsort emulation (debug path, -DRS_SERIAL_SORT) */
   int32_t n_level[48];           /* level-synchronous introsort: live sub-ranges per recursion level */
   uint16_t hist[64 * 16];        /* counting sort: per 64-element chunk, per key */
   int32_t mcs_of_cqi[16];
@@ -40,6 +40,7 @@ struct RsMisc {
   int32_t pad[2];
   float ones16[16];              /* numerator table of an epsilon = 0 slice (pow(x, 0) = 1) */
   double eff16[16];              /* Vogel: flow_spectraleff of a key (key 0 = empty slice = 0.0) */
+  uint8_t eps_psi[64];           /* per slice: bit 0 = algo_epsilon, bit 1 = algo_psi (read by every work item of P3) */
 };
 
 /* LDS carve of one cell (byte offsets from the dynamic LDS base), a pure function of the cell shape so

@@ -141,6 +141,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     m->eff16[tid] = tab->eff[tid];
   }
   if (tid < S) {
+    m->eps_psi[tid] = (uint8_t)((p.eps[tid] ? 1 : 0) | (p.psi[tid] ? 2 : 0));
     s_w[tid] = p.weight[tid];
     s_sstate[tid] = p.slice_state[(size_t)cell * S + tid];
   }
@@ -522,8 +523,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         int sl_custom = 0; /* 1: alpha slice, 2: alpha slice with the HoL factor */
         if (SCHED != 1) {
           int sl = SCHED == 7 ? (kDirect ? (int)p.user_slice[0] : seg) : seg;
-          sl_eps = p.eps[sl];
-          sl_psi = p.psi[sl];
+          sl_eps = m->eps_psi[sl] & 1;
+          sl_psi = (m->eps_psi[sl] >> 1) & 1;
           if (queue_mode_in && p.alpha[sl]) sl_custom = (SCHED == 7 || p.beta[sl] != 0) ? 2 : 1;
         }
         const uint8_t* rowp = s_cqi + r * Upad;
