@@ -84,7 +84,7 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
   c.off_slice = off; off += 8 * 128;
   c.off_tx = off; off += rs_round_up(4 * U, 16);
   c.off_misc = off; off += rs_round_up((int)sizeof(RsMisc), 16);
-  c.off_tbs = off; off += rs_round_up(4 * 27 * (R + 1), 16);
+  c.off_tbs = off; off += rs_round_up(4 * 16 * (R + 1), 16); /* TBS bits of n RBGs at a final CQI */
   c.off_elems = off; off += rs_round_up(pf_like ? 8 * c.n_items : 4 * R * S, 16);
   c.off_sorted = off; off += (sched == 7 && nvs_seg != 0) ? 0 : rs_round_up(4 * R * S, 16);
   c.off_items = off; off += rs_round_up(2 * c.n_items, 16);
