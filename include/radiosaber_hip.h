@@ -50,7 +50,8 @@ enum {
   RS_SCHED_UPPERBOUND = 10, /* DownlinkTransportScheduler + UpperBound (ref: :223-246, apply step :603-616): every slice takes
                               its own best quota RBGs whatever the others take -- an upper bound, not an allocation: several
                               UEs may hold one RBG.  rbg_to_user then reports the UE of the lowest-numbered slice holding
-                              the RBG; user_nprb / user_tbs_bits / ... are complete.  Needs n_rbgs*n_slices <= 2048. */
+                              the RBG; user_nprb / user_tbs_bits / ... are complete and rs_tti_out.upper_rbg / upper_user list
+                              every slice's RBGs in push order.  Needs n_rbgs*n_slices <= 2048. */
   RS_SCHED_VOGEL = 103     /* DownlinkTransportScheduler + VogelApproximate (ref: :378-451; inter_sched_ = 3, which no CLI
                               scheduler number of the reference selects -- ENodeB::DLScheduler_VOGEL exists, ENodeB.cpp:375) */
 };
@@ -137,6 +138,10 @@ typedef struct rs_tti_out {
   int32_t* user_final_cqi;  /* [n] GetCQIFromSinr(GetEesmEffectiveSinr(..)), 0 = not scheduled */
   int32_t* user_mcs;        /* [n] mcs of the PDCCH records                               */
   int32_t* user_tbs_bits;   /* [n] UpdateAllocatedBits() argument                         */
+  /* RS_SCHED_UPPERBOUND only, both optional (NULL = not wanted): what the apply step :603-616 walks -- per slice the RBGs it
+   * took in push order and the user id each one went to (user_index[rbg][slice]); [S][n_rbgs], -1 padded */
+  int32_t* upper_rbg;
+  int32_t* upper_user;
 } rs_tti_out;
 
 /* replaces DownlinkTransportScheduler::RBsAllocation (ref: downlink-transport-scheduler.cpp:453-675),

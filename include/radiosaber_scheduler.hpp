@@ -46,7 +46,7 @@ struct BearerState {
  * (downlink-transport-scheduler.cpp:661-668) */
 struct Allocation {
   int user_id;
-  std::vector<int> prbs; /* GetListOfAllocatedRBs(), RBG-ascending (RS_SCHED_UPPERBOUND: only the RBGs rbg_to_user reports) */
+  std::vector<int> prbs; /* GetListOfAllocatedRBs(): RBG-ascending; RS_SCHED_UPPERBOUND: the slice's sorted (push) order */
   int final_cqi, mcs, tbs_bits;
   int n_prbs;            /* size of the reference's list (complete for every scheduler) */
 };
@@ -205,14 +205,31 @@ class GpuDownlinkScheduler {
     quota_.assign(num_slices_, 0);
     rbg_to_user_.assign(nb_rbgs_, -1);
     nprb_.assign(n, 0); fcqi_.assign(n, 0); mcs_.assign(n, 0); tbs_.assign(n, 0);
-    rs_tti_out out{target_.data(), quota_.data(), rbg_to_user_.data(), nprb_.data(), fcqi_.data(), mcs_.data(), tbs_.data()};
+    rs_tti_out out{target_.data(), quota_.data(), rbg_to_user_.data(), nprb_.data(), fcqi_.data(), mcs_.data(), tbs_.data(),
+                   nullptr, nullptr};
+    const bool upper = sched_ == RS_SCHED_UPPERBOUND;
+    if (upper) { /* several users may hold one RBG: the per-slice lists carry what the apply step :603-616 walks */
+      upper_rbg_.assign((size_t)num_slices_ * nb_rbgs_, -1);
+      upper_user_.assign((size_t)num_slices_ * nb_rbgs_, -1);
+      out.upper_rbg = upper_rbg_.data();
+      out.upper_user = upper_user_.data();
+    }
     if (rs_schedule_tti(ctx_, &in, &out) != RS_OK) throw std::runtime_error(std::string("rs_schedule_tti: ") + rs_last_error());
     for (int i = 0; i < n; ++i) {
       if (nprb_[i] == 0) continue;
       Allocation a{users_[i], {}, fcqi_[i], mcs_[i], tbs_[i], nprb_[i]};
-      for (int r = 0; r < nb_rbgs_; ++r)
-        if (rbg_to_user_[r] == users_[i])
-          for (int k = r * rbg_size_; k < (r + 1) * rbg_size_; ++k) a.prbs.push_back(k);
+      if (upper) { /* push order = the slice's sorted order */
+        const int sl = user_to_slice_[users_[i]];
+        for (int k = 0; k < nb_rbgs_; ++k)
+          if (upper_user_[(size_t)sl * nb_rbgs_ + k] == users_[i]) {
+            const int r = upper_rbg_[(size_t)sl * nb_rbgs_ + k];
+            for (int q = r * rbg_size_; q < (r + 1) * rbg_size_; ++q) a.prbs.push_back(q);
+          }
+      } else {
+        for (int r = 0; r < nb_rbgs_; ++r)
+          if (rbg_to_user_[r] == users_[i])
+            for (int k = r * rbg_size_; k < (r + 1) * rbg_size_; ++k) a.prbs.push_back(k);
+      }
       allocations_.push_back(a);
     }
     if (log_out_) WriteAllocationLog(*log_out_);
@@ -220,10 +237,11 @@ class GpuDownlinkScheduler {
 
   /* the reference's stdout of RBsAllocation: downlink-transport-scheduler.cpp:523-527 (slice line, transport schedulers
    * only), :631 / downlink-nvs-scheduler.cpp:330 (time stamp), :637-649 / nvs :334-348 (one line per served user).
-   * The PF scheduler prints no map.  UpperBound's per-user RBG lists are not recoverable from the ABI outputs. */
+   * The PF scheduler prints no map. */
   void WriteAllocationLog(std::ostream& os) const {
-    if (sched_ == RS_SCHED_PF || sched_ == RS_SCHED_UPPERBOUND) return;
-    const bool transport = sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL || sched_ == RS_SCHED_VOGEL;
+    if (sched_ == RS_SCHED_PF) return;
+    const bool transport = sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL || sched_ == RS_SCHED_VOGEL ||
+                           sched_ == RS_SCHED_UPPERBOUND;
     if (transport) {
       os << "slice_id, target_rbs, quota_rbgs: ";
       for (int i = 0; i < num_slices_; ++i) os << "(" << i << ", " << target_[i] << ", " << quota_[i] << ") ";
@@ -279,7 +297,7 @@ class GpuDownlinkScheduler {
   std::vector<uint8_t> cqi_, in_cqi_, cqi_prb_, in_prb_;
   std::vector<double> in_avg_, in_hol_;
   std::vector<uint8_t> in_prio_;
-  std::vector<int> in_draws_;
+  std::vector<int> in_draws_, upper_rbg_, upper_user_;
   std::vector<int> users_, target_, quota_, rbg_to_user_, nprb_, fcqi_, mcs_, tbs_;
   std::vector<Allocation> allocations_;
   unsigned long ts_ = 0;

@@ -36,7 +36,8 @@ class _TtiOut(C.Structure):
     _fields_ = [("target_rbs", C.POINTER(C.c_int)), ("quota_rbgs", C.POINTER(C.c_int)),
                 ("rbg_to_user", C.POINTER(C.c_int)), ("user_nprb", C.POINTER(C.c_int)),
                 ("user_final_cqi", C.POINTER(C.c_int)), ("user_mcs", C.POINTER(C.c_int)),
-                ("user_tbs_bits", C.POINTER(C.c_int)), ("served_slice", C.c_int)]
+                ("user_tbs_bits", C.POINTER(C.c_int)), ("served_slice", C.c_int),
+                ("upper_rbg", C.POINTER(C.c_int)), ("upper_user", C.POINTER(C.c_int))]
 
 
 class _TraceRun(C.Structure):
@@ -163,10 +164,12 @@ class TtiOut:
         self.user_final_cqi = np.zeros(U, np.int32)
         self.user_mcs = np.zeros(U, np.int32)
         self.user_tbs_bits = np.zeros(U, np.int32)
+        self.upper_rbg = np.full((S, R), -1, np.int32)   # sched 10 only
+        self.upper_user = np.full((S, R), -1, np.int32)
         self.c = _TtiOut(_p(self.target_rbs, C.c_int), _p(self.quota_rbgs, C.c_int),
                          _p(self.rbg_to_user, C.c_int), _p(self.user_nprb, C.c_int),
                          _p(self.user_final_cqi, C.c_int), _p(self.user_mcs, C.c_int),
-                         _p(self.user_tbs_bits, C.c_int), -1)
+                         _p(self.user_tbs_bits, C.c_int), -1, _p(self.upper_rbg, C.c_int), _p(self.upper_user, C.c_int))
 
     @property
     def served_slice(self):

@@ -449,6 +449,8 @@ int allocate_transport(rso_cell* c, const double* avg, int rand0, int rand1, rso
      * does not reach any result.  quota[j] > R would read past the vector in the reference; clamped here. */
     std::vector<std::vector<int>> lists(U);
     for (int i = 0; i < R; i++) out->rbg_to_user[i] = -1;
+    if (out->upper_rbg)
+      for (int i = 0; i < S * R; i++) { out->upper_rbg[i] = -1; out->upper_user[i] = -1; }
     for (int j = 0; j < S; j++) {
       if (quota[j] <= 0) continue;
       std::vector<std::pair<int, double>> v;
@@ -460,6 +462,7 @@ int allocate_transport(rso_cell* c, const double* avg, int rand0, int rand1, rso
         int u = user_index[(size_t)rbg * S + j];
         if (u < 0) return -5; /* reference: assert(uindex != -1) */
         lists[u].push_back(rbg);
+        if (out->upper_rbg) { out->upper_rbg[j * R + k] = rbg; out->upper_user[j * R + k] = u; }
         /* reporting convention of this restatement (the reference has no RBG -> UE map here): the user of the
          * lowest-numbered slice that took the RBG */
         if (out->rbg_to_user[rbg] < 0) out->rbg_to_user[rbg] = u;
@@ -705,7 +708,7 @@ int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_map, int* log_
   rso_srand(&g, run->seed);
   for (long i = 0; i < run->rand_skip; i++) (void)rso_rand(&g);
   std::vector<int> target(S), quota(S), map(R), nprb(U), fcqi(U), mcs(U), tbs(U);
-  rso_tti_out out = {target.data(), quota.data(), map.data(), nprb.data(), fcqi.data(), mcs.data(), tbs.data(), -1};
+  rso_tti_out out = {target.data(), quota.data(), map.data(), nprb.data(), fcqi.data(), mcs.data(), tbs.data(), -1, nullptr, nullptr};
   /* simulated time: every event is scheduled at Now()+0.001 in double
    * (simulator.cc:117-126, FrameManager.cpp:186-188): t_k = fl(t_{k-1} + 0.001) */
   double t = 0;
@@ -753,7 +756,7 @@ int rso_run_synth(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refr
   rso_rng g;
   rso_srand(&g, seed);
   std::vector<int> target(S), quota(S), map(R), nprb(U), fcqi(U), mcs(U), tbs(U);
-  rso_tti_out out = {target.data(), quota.data(), map.data(), nprb.data(), fcqi.data(), mcs.data(), tbs.data(), -1};
+  rso_tti_out out = {target.data(), quota.data(), map.data(), nprb.data(), fcqi.data(), mcs.data(), tbs.data(), -1, nullptr, nullptr};
   double t = 0;
   for (int k = 0; k < 100; k++) t += 0.001;
   rso_cell_set_last_update(c, 0.1);

@@ -98,6 +98,8 @@ typedef struct {
   int* user_mcs;       /* [U]  */
   int* user_tbs_bits;  /* [U]  */
   int served_slice;    /* sched 7: slice chosen by SelectSliceToServe, else -1 */
+  int* upper_rbg;      /* optional (may be NULL), sched 10: [S][R] RBGs every slice took, in push order, -1 padded */
+  int* upper_user;     /* optional, sched 10: [S][R] the user each of them went to                            */
 } rso_tti_out;
 
 rso_cell* rso_cell_create(const rso_config* cfg);

@@ -62,7 +62,8 @@ class _TtiOut(C.Structure):
     _fields_ = [("target_rbs", C.POINTER(C.c_int32)), ("quota_rbgs", C.POINTER(C.c_int32)),
                 ("rbg_to_user", C.POINTER(C.c_int32)), ("user_nprb", C.POINTER(C.c_int32)),
                 ("user_final_cqi", C.POINTER(C.c_int32)), ("user_mcs", C.POINTER(C.c_int32)),
-                ("user_tbs_bits", C.POINTER(C.c_int32))]
+                ("user_tbs_bits", C.POINTER(C.c_int32)),
+                ("upper_rbg", C.POINTER(C.c_int32)), ("upper_user", C.POINTER(C.c_int32))]
 
 
 # every symbol include/radiosaber_hip.h declares (tests check the library exports all of them)
@@ -281,6 +282,8 @@ class TtiResult:
     user_final_cqi: np.ndarray
     user_mcs: np.ndarray
     user_tbs_bits: np.ndarray
+    upper_rbg: Optional[np.ndarray] = None   # RS_SCHED_UPPERBOUND: [S][R] RBGs each slice took, push order, -1 padded
+    upper_user: Optional[np.ndarray] = None  # ... and the user each one went to
 
 
 class TtiScheduler:
@@ -331,10 +334,15 @@ class TtiScheduler:
                      _p(hol, C.c_double) if hol is not None else None,
                      _p(prio, C.c_uint8) if prio is not None else None,
                      _p(draws, C.c_int32) if draws is not None else None)
+        if self.sched == RS_SCHED_UPPERBOUND:
+            res.upper_rbg = np.full((S, self.R), -1, np.int32)
+            res.upper_user = np.full((S, self.R), -1, np.int32)
         tout = _TtiOut(_p(res.target_rbs, C.c_int32), _p(res.quota_rbgs, C.c_int32),
                        _p(res.rbg_to_user, C.c_int32), _p(res.user_nprb, C.c_int32),
                        _p(res.user_final_cqi, C.c_int32), _p(res.user_mcs, C.c_int32),
-                       _p(res.user_tbs_bits, C.c_int32))
+                       _p(res.user_tbs_bits, C.c_int32),
+                       _p(res.upper_rbg, C.c_int32) if res.upper_rbg is not None else None,
+                       _p(res.upper_user, C.c_int32) if res.upper_user is not None else None)
         _check(lib().rs_schedule_tti(self._h, C.byref(tin), C.byref(tout)))
         return res
 

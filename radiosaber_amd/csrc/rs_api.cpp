@@ -718,7 +718,7 @@ struct rs_ctx {
 
 namespace {
 struct CtxLayout {
-  size_t grid, slice, avg, hol, prio, draws, prb, in_total, tbs, uinfo, map, quota, target, out_total;
+  size_t grid, slice, avg, hol, prio, draws, prb, in_total, tbs, uinfo, map, quota, target, upper, out_total;
 };
 CtxLayout ctx_layout(int n, int R, int S, int G, bool with_draws) {
   CtxLayout l;
@@ -735,7 +735,8 @@ CtxLayout ctx_layout(int n, int R, int S, int G, bool with_draws) {
   l.map = 8 * (size_t)n;
   l.quota = l.map + round_up(2 * R, 8);
   l.target = l.quota + round_up(2 * S, 8);
-  l.out_total = l.target + round_up(2 * S, 8);
+  l.upper = l.target + round_up(2 * S, 8);
+  l.out_total = l.upper + 4 * (size_t)S * R; /* sched 10 only uses it */
   return l;
 }
 }  // namespace
@@ -869,6 +870,8 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   L.log_map = (int16_t*)(dev_out + l.map);
   L.log_quota = (int16_t*)(dev_out + l.quota);
   L.log_target = (int16_t*)(dev_out + l.target);
+  const bool want_upper = b->sched == RS_SCHED_UPPERBOUND && (out->upper_rbg || out->upper_user);
+  L.log_upper = want_upper ? (int32_t*)(dev_out + l.upper) : nullptr;
   /* direct mode: the kernel clears its per-user outputs itself and reads the single grid on every call */
   HIP_TRY(rs_launch_cells(&L, b->threads, st));
   if (!zc) HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, l.out_total, hipMemcpyDeviceToHost, st));
@@ -881,6 +884,17 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   for (int r = 0; r < R; r++) {
     int o = h_map[r];
     out->rbg_to_user[r] = o < 0 ? -1 : (in->user_id ? in->user_id[o] : o);
+  }
+  if (want_upper) {
+    const int32_t* h_upper = (const int32_t*)(c->h_out + l.upper);
+    for (int i = 0; i < S * R; i++) {
+      const int32_t v = h_upper[i];
+      if (out->upper_rbg) out->upper_rbg[i] = v < 0 ? -1 : (v & 63);
+      if (out->upper_user) out->upper_user[i] = v < 0 ? -1 : (in->user_id ? in->user_id[v >> 8] : (v >> 8));
+    }
+  } else {
+    if (out->upper_rbg) for (int i = 0; i < S * R; i++) out->upper_rbg[i] = -1;
+    if (out->upper_user) for (int i = 0; i < S * R; i++) out->upper_user[i] = -1;
   }
   for (int s = 0; s < S; s++) {
     if (out->target_rbs) out->target_rbs[s] = h_target[s];

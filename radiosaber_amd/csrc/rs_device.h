@@ -156,6 +156,7 @@ struct RsLaunch {
   const int32_t* beta;       /* [S] */
   const double* hol;         /* [U] head-of-line delay of the slice-priority bearer */
   const uint8_t* prio;       /* [U] prioritized bearer has data (NULL = all) */
+  int32_t* log_upper;        /* sched 10, drop-in mode: [S][R] (rbg | user << 8), -1 padded; NULL = off */
   const uint8_t* draws;      /* sched 11, drop-in mode: rand() % 4 of the RS_NVS_SAMPLES x U draws, in draw order */
   const int32_t* tbs_eff;    /* [R+1][27] TBS bits of n RBGs (n*G PRBs) at itbs, incl. the >110-PRB rule */
   /* state */

@@ -686,6 +686,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           if (u != 0xFFFF) atomicMin(&low_owner[rbg], (sl << 16) | u);
         }
         ent_user[x] = (uint16_t)u;
+        if (p.log_upper) p.log_upper[x] = u == 0xFFFF ? -1 : (int)((s_sorted[x] >> 8) & 63u) | (u << 8);
       }
       __syncthreads();
       for (int x = tid; x < N; x += nt) {

@@ -601,3 +601,31 @@ def test_drop_in_nvs_big_slice(rs, oracle):
         met = kb[cqi[ids]] / ((1 + avg[ids]) / 1000.0)[:, None]
         np.testing.assert_array_equal(res.rbg_to_user, ids[np.argmax(met, axis=0)])
     ts.close()
+
+
+def test_upper_bound_drop_in_lists(rs, oracle):
+    """RS_SCHED_UPPERBOUND through the drop-in entry point: besides the per-user results, the per-slice lists the
+    reference's apply step walks (RBGs in push order = the slice's std::sort order, and the user each one goes to)."""
+    ues, R, G = [5] * 20, 64, 8
+    sc = rs.SliceConfig(ues, weight=[0.05] * 20)
+    ts = rs.TtiScheduler(sc, R, G, sched=10)
+    cell = oracle.Cell(ues, R, G, 10, weights=[0.05] * 20)
+    rng = np.random.default_rng(41)
+    for it in range(8):
+        cqi = synth_cqi(800 + it, (sc.n_users, R), HIST)
+        avg = rng.uniform(1e3, 5e6, sc.n_users)
+        if it % 3 == 0:
+            avg[:] = 98000.0
+        r0, r1 = int(rng.integers(0, 2**31 - 1)), int(rng.integers(0, 2**31 - 1))
+        cell.set_cqi(cqi)
+        out = cell.new_out()
+        assert cell.allocate(avg, r0, r1, out) == 0
+        res = ts.schedule_tti(cqi, avg, r0, r1)
+        np.testing.assert_array_equal(res.upper_rbg, out.upper_rbg)
+        np.testing.assert_array_equal(res.upper_user, out.upper_user)
+        np.testing.assert_array_equal(res.user_nprb, out.user_nprb)
+        np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits)
+        np.testing.assert_array_equal(res.quota_rbgs, out.quota_rbgs)
+        # a slice's list is as long as its positive quota, and several slices may hold the same RBG
+        assert ((res.upper_rbg >= 0).sum(axis=1) == np.clip(res.quota_rbgs, 0, R)).all()
+    ts.close()
