@@ -16,13 +16,14 @@ int main(int argc, char** argv) {
   const int U = 100, R = 64, n_rows = atoi(argv[2]);
   const long skip = atol(argv[3]);
   const int n_ttis = atoi(argv[4]);
+  const int sched_id = argc > 5 ? atoi(argv[5]) : RS_SCHED_MAXCELL;
   std::vector<uint8_t> trace((size_t)U * n_rows * R);
   FILE* f = fopen(argv[1], "rb");
   if (!f || fread(trace.data(), 1, trace.size(), f) != trace.size()) return 3;
   fclose(f);
   std::vector<int> ues(20, 5), zeros(20, 0), ones(20, 1);
   std::vector<double> w(20, 0.05);
-  radiosaber::GpuDownlinkScheduler sched(ues, w, zeros, zeros, ones, ones, 512, 8, RS_SCHED_MAXCELL);
+  radiosaber::GpuDownlinkScheduler sched(ues, w, zeros, zeros, ones, ones, 512, 8, sched_id);
   std::ostringstream log_out, log_err;
   sched.SetTimeStamp(100);  // the reference's m_ts has counted the 100 idle TTIs before the first allocation
   sched.SetLogStreams(&log_out, &log_err);
@@ -58,6 +59,7 @@ int main(int argc, char** argv) {
   }
   for (int u : {1, 2, 5}) printf("cumu %d %lu %lu\n", u, sched.Bearer(u).cumulative_bytes, sched.Bearer(u).cumulative_rbs);
   printf("ts %lu\n", sched.GetTimeStamp());
+  for (int u = 0; u < U; u++) printf("ALL %d %lu %lu\n", u, sched.Bearer(u).cumulative_bytes, sched.Bearer(u).cumulative_rbs);
   // the reference-format logs, for the golden lines of SURVEY.md Appendix A
   {
     std::istringstream is(log_out.str());

@@ -54,3 +54,27 @@ def test_adapter_replays_the_reference_run(tmp_path, rs, traces):
     assert "ERR 100 app: 1 cumu_bytes: 749 cumu_rbs: 8 hol_delay: 0 user: 1 slice: 0" in lines
     assert "ERR 100 app: 7 cumu_bytes: 2196 cumu_rbs: 24 hol_delay: 0 user: 7 slice: 1" in lines
     assert "ERR 299 app: 5 cumu_bytes: 110838 cumu_rbs: 1336 hol_delay: 0 user: 5 slice: 1" in lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched", [7, 8, 1, 10, 11])
+def test_adapter_runs_every_cli_scheduler(tmp_path, rs, oracle, traces, sched):
+    """The same simulator-style loop (host-side slice pick and EWMA, libc rand() shared with the error model, the 300 x n
+    draws of scheduler 11 taken from libc by the adapter) for the other CLI schedulers: the adapter's cumulative counters
+    after 120 TTIs equal the oracle's run on the same traces."""
+    ka = json.loads((GOLDEN / "appendix_a.json").read_text())
+    exe = _build(tmp_path, rs)
+    per_user = traces["cqi"][traces["mapping"][0][np.arange(100) % 474]]
+    tf = tmp_path / "trace.bin"
+    tf.write_bytes(np.ascontiguousarray(per_user, np.uint8).tobytes())
+    skip = ka["config"]["rand_skip"]
+    out = subprocess.run([str(exe), str(tf), "40", str(skip), "120", str(sched)], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = np.array([[int(x) for x in l.split()[1:]] for l in out.stdout.split("\n") if l.startswith("ALL ")])
+    assert got.shape == (100, 3)
+    cell = oracle.Cell(ka["config"]["ues_per_slice"], 64, 8, sched, weights=[ka["config"]["weight"]] * 20)
+    cell.run_trace(traces["cqi"], traces["mapping"][0], ka["config"]["seed"], skip, 120)
+    st = cell.state()
+    np.testing.assert_array_equal(got[:, 1], st["cum_bytes"])
+    np.testing.assert_array_equal(got[:, 2], st["cum_rbs"])
