@@ -128,6 +128,8 @@ struct RsCellScalars {
   int64_t n_done;      /* scheduled TTIs so far                                        */
   int32_t rng_f, rng_b;
   uint32_t rng_r[32];  /* glibc TYPE_3 ring (31 words used)                            */
+  int32_t cqi_row;     /* trace row of the last CQI report (reloaded when a launch starts between reports) */
+  int32_t pad_;
 };
 
 enum { RS_CQI_NONE = 0, RS_CQI_EPOCHS = 1, RS_CQI_TRACE = 2 };

@@ -164,6 +164,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   double last_update = scal->last_update;
   long long last_sent = scal->last_sent;
   int reported = scal->reported;
+  int cqi_row = scal->cqi_row;
   int served_prev = scal->served_prev;
   long long n_done = scal->n_done;
   WaveRng rng;
@@ -192,7 +193,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     RS_STAMP(11);
     /* ---------------- P0: CQI refresh ---------------- */
     if (p.cqi_mode == RS_CQI_EPOCHS) {
-      if (kDirect || n_done % p.refresh == 0) {
+      /* a launch that starts inside an epoch loads that epoch's grid first: LDS does not survive between launches */
+      if (kDirect || tti == 0 || n_done % p.refresh == 0) {
         long long e = kDirect ? 0 : n_done / p.refresh;
         if (e >= p.n_epochs) { local_err = RS_CQI_EPOCHS; e = p.n_epochs - 1; }
         /* HBM grid is [U][R] (one row per UE, like the reference's per-UE CQI vectors); LDS keeps it
@@ -215,16 +217,20 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     } else if (p.cqi_mode == RS_CQI_TRACE) {
       /* ref: src/device/CqiManager/cqi-manager.cpp:105-123 (interval 40),
        *      src/protocolStack/mac/enb-mac-entity.cc:189-191 */
+      bool load = tti == 0 && reported; /* a launch that starts between two reports reloads the last reported row */
       if (!reported || ((int)(t * 1000) - last_sent) >= 40) {
         reported = 1;
         last_sent = (long long)(t * 1000);
         int stamp = (int)(t * 1000 / 40);
-        int row = stamp % p.row_mod;
-        if (row >= p.n_rows) { local_err = RS_CQI_TRACE; row = 0; }
+        cqi_row = stamp % p.row_mod;
+        if (cqi_row >= p.n_rows) { local_err = RS_CQI_TRACE; cqi_row = 0; }
+        load = true;
+      }
+      if (load) {
         for (int i = tid; i < U * R; i += nt) {
           int u = i / R, r = i - u * R;
           int tr = p.user_trace[(size_t)cell * U + u];
-          s_cqi[r * Upad + u] = p.trace[((size_t)tr * p.n_rows + row) * R + r];
+          s_cqi[r * Upad + u] = p.trace[((size_t)tr * p.n_rows + cqi_row) * R + r];
         }
       }
     }
@@ -1048,6 +1054,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     scal->last_update = last_update;
     scal->last_sent = last_sent;
     scal->reported = reported;
+    scal->cqi_row = cqi_row;
     scal->served_prev = served_prev;
     scal->n_done = n_done;
     if (local_err) atomicExch(p.err, local_err);

@@ -629,3 +629,55 @@ def test_upper_bound_drop_in_lists(rs, oracle):
         # a slice's list is as long as its positive quota, and several slices may hold the same RBG
         assert ((res.upper_rbg >= 0).sum(axis=1) == np.clip(res.quota_rbgs, 0, R)).all()
     ts.close()
+
+
+@pytest.mark.parametrize("sched", [9, 7, 11, 10, 1])
+def test_state_carries_across_launches(rs, oracle, sched):
+    """A run cut into launches of uneven length (not aligned with the 40-TTI CQI refresh) ends in the same state as the
+    oracle's single run: PF averages, pending transmitted bytes, the rand() ring (incl. the error-model draws owed for the
+    last TTI of a launch), clock, CQI epoch position, slice offsets / NVS EWMA."""
+    ues, R, G, n_cells = [6] * 7, 25, 4, 3
+    cuts = [17, 40, 1, 33, 12]
+    total = sum(cuts)
+    sc = rs.SliceConfig(ues)
+    grids = synth_cqi(77, (n_cells, (total + 39) // 40, sc.n_users, R), HIST)
+    seeds = np.arange(n_cells, dtype=np.uint32) + 1234
+    for jit in (False, True):
+        b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, phy_error_draws=True, jit=jit)
+        b.seed(seeds)
+        b.upload_cqi_epochs(grids)
+        for n in cuts:
+            b.run(n)
+        assert b.ttis_done == total
+        st = b.state()
+        for c in range(n_cells):
+            cell = oracle.Cell(ues, R, G, sched)
+            cell.run_synth(grids[c], int(seeds[c]), total, phy_error_draws=1, log=False)
+            ost = cell.state()
+            np.testing.assert_array_equal(st["cum_bytes"][c], ost["cum_bytes"])
+            np.testing.assert_array_equal(st["cum_rbs"][c], ost["cum_rbs"])
+            assert st["avg_rate"][c].tobytes() == ost["avg_rate"].tobytes()
+            assert st["slice_state"][c].tobytes() == ost["slice_state"].tobytes()
+        b.close()
+
+
+def test_trace_replay_across_launches(rs, oracle, traces):
+    """Trace mode, launches that start between two CQI reports: the last reported trace row is reloaded (LDS does not
+    survive a launch) and the report clock keeps running."""
+    ues = [5] * 20
+    sc = rs.SliceConfig(ues, weight=[0.05] * 20)
+    U = sc.n_users
+    b = rs.BatchScheduler(sc, 64, 8, 1, sched=9, phy_error_draws=True)
+    b.seed(np.array([805290992], np.uint32), np.array([4321], np.int64))
+    b.set_trace(traces["cqi"], traces["mapping"][2][np.arange(U) % 474][None, :])
+    for n in (13, 40, 27, 1, 59):
+        b.run(n)
+    st = b.state()
+    cell = oracle.Cell(ues, 64, 8, 9, weights=[0.05] * 20)
+    cell.run_trace(traces["cqi"], traces["mapping"][2], 805290992, 4321, 140)
+    ost = cell.state()
+    np.testing.assert_array_equal(st["cum_bytes"][0], ost["cum_bytes"])
+    np.testing.assert_array_equal(st["cum_rbs"][0], ost["cum_rbs"])
+    assert st["avg_rate"][0].tobytes() == ost["avg_rate"].tobytes()
+    assert st["slice_state"][0].tobytes() == ost["slice_state"].tobytes()
+    b.close()
