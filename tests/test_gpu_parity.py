@@ -681,3 +681,35 @@ def test_trace_replay_across_launches(rs, oracle, traces):
     assert st["avg_rate"][0].tobytes() == ost["avg_rate"].tobytes()
     assert st["slice_state"][0].tobytes() == ost["slice_state"].tobytes()
     b.close()
+
+
+def test_two_batches_interleaved_and_other_refresh_period(rs, oracle):
+    """Two live batches on one device (different schedulers, one shape-specialised, one with a 7-TTI CQI refresh) run
+    turn by turn; each ends where the oracle ends."""
+    ues, R, G = [4] * 9, 25, 4
+    sc = rs.SliceConfig(ues)
+    U = sc.n_users
+    total = 63
+    g1 = synth_cqi(91, (2, (total + 39) // 40, U, R), HIST)
+    g2 = synth_cqi(92, (2, (total + 6) // 7, U, R), HIST)
+    seeds = np.array([5, 6], np.uint32)
+    b1 = rs.BatchScheduler(sc, R, G, 2, sched=9, jit=True)
+    b2 = rs.BatchScheduler(sc, R, G, 2, sched=8, cqi_refresh=7, phy_error_draws=True)
+    for b, g in ((b1, g1), (b2, g2)):
+        b.seed(seeds)
+        b.upload_cqi_epochs(g)
+    for n in (10, 20, 5, 28):
+        b1.run_async(n)
+        b2.run_async(n)
+    b1.sync()
+    b2.sync()
+    for b, g, sched, refresh, phy in ((b1, g1, 9, 40, 0), (b2, g2, 8, 7, 1)):
+        st = b.state()
+        for c in range(2):
+            cell = oracle.Cell(ues, R, G, sched)
+            cell.run_synth(g[c], int(seeds[c]), total, refresh=refresh, phy_error_draws=phy, log=False)
+            ost = cell.state()
+            np.testing.assert_array_equal(st["cum_bytes"][c], ost["cum_bytes"])
+            assert st["avg_rate"][c].tobytes() == ost["avg_rate"].tobytes()
+            assert st["slice_state"][c].tobytes() == ost["slice_state"].tobytes()
+        b.close()
