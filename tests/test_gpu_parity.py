@@ -713,3 +713,13 @@ def test_two_batches_interleaved_and_other_refresh_period(rs, oracle):
             assert st["avg_rate"][c].tobytes() == ost["avg_rate"].tobytes()
             assert st["slice_state"][c].tobytes() == ost["slice_state"].tobytes()
         b.close()
+
+
+@pytest.mark.parametrize("sched", [9, 8, 7, 1, 10, 11, 103])
+def test_degenerate_shapes(rs, oracle, sched):
+    """One RBG, one UE, one slice, an empty slice between two others, one UE on 64 RBGs, 64 UEs on one RBG: no sort level,
+    no run, no batch is ever full -- every scheduler, both kernel flavours."""
+    for ues, R, G in (([1], 1, 1), ([1, 1], 1, 1), ([2], 2, 1), ([1, 2, 1], 3, 2), ([3], 1, 4), ([1] * 5, 2, 2),
+                      ([2, 0, 2], 4, 1), ([1], 64, 8), ([64], 1, 1)):
+        for jit in (False, True):
+            _check_batch(rs, oracle, sched, ues, R, G, n_cells=2, n_ttis=45, jit=jit, phy=1)
