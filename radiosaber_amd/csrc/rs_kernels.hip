@@ -12,8 +12,14 @@
  *                                          per load, IEEE FP64 division only for the survivors
  *   P4  inter-slice assignment             ref: :249-272 GreedyByRow / :351-376 MaximizeCell = exact
  *                                          std::sort emulation (level-synchronous introsort loop + stable
- *                                          counting sort) + greedy scan
+ *                                          counting sort, rs_sort_device.h) + greedy scan; also :223-246 UpperBound
+ *                                          (S segmented sorts), :378-451 VogelApproximate, and the NVS non-greedy
+ *                                          sampler (downlink-nvs-scheduler.cpp:405-528) in place of P3/P4
  *   P5  apply + EESM link adaptation + DoStopSchedule counters     ref: :589-674, :170-221
+ *
+ * Template parameters of the cell body: SCHED = the reference's CLI scheduler number (1, 7, 8, 9, 10, 11; 103 = Vogel),
+ * EPT = sort positions per thread (0: state in LDS, any size), FIXED = shape-specialised build, DIRECT = the drop-in
+ * entry point's one-TTI form on caller-provided state.  Wave-level building blocks live in rs_wave.h.
  *
  * The same source is compiled twice: into the library with the cell shape as launch arguments, and at
  * run time (hiprtc, rs_jit.cpp) with the shape as compile-time constants (RS_JIT_*).
