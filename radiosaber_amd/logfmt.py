@@ -22,8 +22,11 @@ import numpy as np
 
 
 def stderr_lines(tbs_bits, rbg_to_user, user_to_slice: Sequence[int], rbg_size: int, first_ts: int = 100,
-                 cum_bytes0=None, cum_rbs0=None) -> List[str]:
-    """tbs_bits [n_ttis][U], rbg_to_user [n_ttis][R] of ONE cell -> the reference's stderr lines."""
+                 cum_bytes0=None, cum_rbs0=None, nprb=None, pf_format: bool = False) -> List[str]:
+    """tbs_bits [n_ttis][U], rbg_to_user [n_ttis][R] of ONE cell -> the reference's stderr lines.
+    nprb [n_ttis][U] (run_logged's "nprb"): the per-user PRB counts, needed for UpperBound where several users hold one
+    RBG; derived from rbg_to_user otherwise.  pf_format: the "flow:" line of the PF scheduler
+    (downlink-packet-scheduler.cpp:140-145) instead of the "app: .. user: .. slice: .." line."""
     tbs_bits = np.asarray(tbs_bits)
     rbg_to_user = np.asarray(rbg_to_user)
     n_ttis, U = tbs_bits.shape
@@ -31,12 +34,16 @@ def stderr_lines(tbs_bits, rbg_to_user, user_to_slice: Sequence[int], rbg_size: 
     cr = np.zeros(U, np.int64) if cum_rbs0 is None else np.array(cum_rbs0, np.int64)
     out = []
     for n in range(n_ttis):
-        nprb = np.bincount(rbg_to_user[n][rbg_to_user[n] >= 0], minlength=U) * rbg_size
+        prbs = np.asarray(nprb[n]) if nprb is not None else \
+            np.bincount(rbg_to_user[n][rbg_to_user[n] >= 0], minlength=U) * rbg_size
         for u in np.flatnonzero(tbs_bits[n] // 8 > 0):
             cb[u] += min(int(tbs_bits[n, u]) // 8, 100000000)
-            cr[u] += int(nprb[u])
-            out.append(f"{first_ts + n} app: {u} cumu_bytes: {cb[u]} cumu_rbs: {cr[u]} hol_delay: 0 "
-                       f"user: {u} slice: {user_to_slice[u]}")
+            cr[u] += int(prbs[u])
+            if pf_format:
+                out.append(f"{first_ts + n} flow: {u} cumu_bytes: {cb[u]} cumu_rbs: {cr[u]} hol_delay: 0")
+            else:
+                out.append(f"{first_ts + n} app: {u} cumu_bytes: {cb[u]} cumu_rbs: {cr[u]} hol_delay: 0 "
+                           f"user: {u} slice: {user_to_slice[u]}")
     return out
 
 

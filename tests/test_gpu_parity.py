@@ -723,3 +723,46 @@ def test_degenerate_shapes(rs, oracle, sched):
                       ([2, 0, 2], 4, 1), ([1], 64, 8), ([64], 1, 1)):
         for jit in (False, True):
             _check_batch(rs, oracle, sched, ues, R, G, n_cells=2, n_ttis=45, jit=jit, phy=1)
+
+
+def test_experiment_runner_tool(rs, oracle, tmp_path):
+    """tools/run_experiment.py = one line of the reference's run scripts: reads ue<id>.log / mapping.config / the slice
+    JSON, runs the cell on the GPU, writes the reference's stderr lines.  Checked on files written here: the last
+    cumu_bytes / cumu_rbs of every flow equal the oracle's trace run, and the reducer of plot_throughput.py parses it."""
+    import subprocess
+    import sys as _sys
+    from pathlib import Path
+    from radiosaber_amd import logfmt
+    root = Path(__file__).resolve().parents[1]
+    rng = np.random.default_rng(55)
+    n_traces, rows = 6, 475
+    grid = rng.integers(1, 16, (n_traces, rows, 64)).astype(np.uint8)
+    for t in range(n_traces):
+        (tmp_path / f"ue{t}.log").write_text("".join(" ".join(str(v) for v in np.repeat(r, 8)) + " \n" for r in grid[t]))
+    mapping = np.array([3, 0, 5, 1, 2, 4, 1, 0], np.int32)
+    (tmp_path / "mapping.config").write_text("".join(f"{i} {m}\n" for i, m in enumerate(mapping)))
+    cfg = {"ues_per_slice": [3, 2, 4], "slices": [{"n_slices": 3, "weight": 1 / 3, "algo_alpha": 0, "algo_beta": 0,
+                                                    "algo_epsilon": 1, "algo_psi": 1}]}
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    log = tmp_path / "run.log"
+    for sched in (9, 1):
+        r = subprocess.run([_sys.executable, str(root / "tools" / "run_experiment.py"), "--sched", str(sched), "--seed", "1",
+                            "--duration", "0.15", "--config", str(tmp_path / "config.json"), "--traces", str(tmp_path),
+                            "--rand-skip", "77", "--log", str(log)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = log.read_text().strip().split("\n")
+        cell = oracle.Cell([3, 2, 4], 64, 8, sched)
+        cell.run_trace(grid, mapping, 749913912, 77, 150)
+        st = cell.state()
+        last = {}
+        for ln in lines:
+            w = ln.split(" ")
+            last[int(w[2])] = (int(w[4]), int(w[6]))
+        for u in range(9):
+            assert last[u] == (int(st["cum_bytes"][u]), int(st["cum_rbs"][u])), (sched, u)
+        if sched == 9:
+            assert lines[0].startswith("100 app: ") and " user: " in lines[0] and " slice: " in lines[0]
+            mbps, _ = logfmt.slice_throughput_from_log(lines, 9, 3, begin_ts=0, end_ts=250)
+            assert len(mbps) == 3 and all(x > 0 for x in mbps)
+        else:
+            assert lines[0].startswith("100 flow: ") and "user:" not in lines[0]
