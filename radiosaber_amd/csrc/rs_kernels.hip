@@ -590,10 +590,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               best_a = fmaxf(best_a, a);
             }
           }
-          const float thr = best_a * kTol;
+          /* survivors: a~ >= (1 - 2^-19) max a~ and a~ > 0.  With a positive maximum the threshold is positive and the
+           * second test is implied; with an all-zero block an infinite threshold leaves no survivor */
+          const float thr = best_a > 0.0f ? best_a * kTol : __builtin_inff();
           uint32_t cand = 0;
 #pragma unroll
-          for (int k = 0; k < kP3Block; ++k) cand |= (av[k] >= thr && av[k] > 0.0f) ? (1u << k) : 0u;
+          for (int k = 0; k < kP3Block; ++k) cand |= av[k] >= thr ? (1u << k) : 0u;
           /* customised slices can rank every user at 0 (no prioritized data): the reference's scan then
            * keeps the first user (0 > -1), so that user goes to stage 2 */
           if (sl_custom && !cand) cand = 1u << ((ub > blk ? ub : blk) - blk);
@@ -608,7 +610,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               metric = s_num[c] / s_avg[u];
             } else {
               /* ref: :688-693  pow(se_kbps, eps) / pow(avg_kbps, psi), eps, psi in {0,1} */
-              const double num = sl_eps ? s_num[c] : 1.0, den = sl_psi ? s_avgk[u] : 1.0;
+              /* both table reads are issued whatever the slice's exponents are (no branch around an LDS read) */
+              const double num_c = s_num[c], den_u = s_avgk[u];
+              const double num = sl_eps ? num_c : 1.0, den = sl_psi ? den_u : 1.0;
               if (sl_custom && p.prio && p.prio[u] == 0) metric = 0.0;
               else if (sl_custom == 2) metric = p.hol[u] * num / den; /* HoL * pow(se) / pow(avg), left to right */
               else metric = num / den;
