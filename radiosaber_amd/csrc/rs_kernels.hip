@@ -585,7 +585,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(nm[k])); /* eight table reads in flight, none behind a branch */
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              const float a = (d0 + (unsigned)k < seg_len) ? nm[k] * rc[k] : 0.0f;
+              /* sched 1 scans 32-aligned runs of ALL users: the only slots outside a run are beyond the last user, where
+               * the reciprocal array holds the zeros it was initialised with -- the product is 0 without a range test */
+              const float a = (SCHED == 1 || d0 + (unsigned)k < seg_len) ? nm[k] * rc[k] : 0.0f;
               av[8 * g + k] = a;
               best_a = fmaxf(best_a, a);
             }
