@@ -41,6 +41,7 @@ struct RsMisc {
   float ones16[16];              /* numerator table of an epsilon = 0 slice (pow(x, 0) = 1) */
   double eff16[16];              /* Vogel: flow_spectraleff of a key (key 0 = empty slice = 0.0) */
   uint8_t eps_psi[64];           /* per slice: bit 0 = algo_epsilon, bit 1 = algo_psi (read by every work item of P3) */
+  int32_t rcp_off[64];           /* per slice: window start in the reciprocal array minus the slice's 8-aligned first user */
 };
 
 /* LDS carve of one cell (byte offsets from the dynamic LDS base), a pure function of the cell shape so
@@ -79,7 +80,9 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
   const bool pf_like = sched == 1 || (sched == 7 && nvs_seg != 0); /* winner tables instead of sort records */
   int off = 8 * U; /* avg */
   c.off_avgk = off; off += 8 * U;
-  c.off_rcp = off; off += rs_round_up(4 * c.Upad, 16);
+  /* stage-1 reciprocals, one 8-aligned window per slice with zeros around it (f32[Upad + 16 S]), then each user's
+   * window offset (i16[U]) */
+  c.off_rcp = off; off += rs_round_up(4 * (c.Upad + 16 * S) + 2 * U, 16);
   c.off_tab = off; off += 8 * 48 + 64;
   c.off_slice = off; off += 8 * 128;
   c.off_tx = off; off += rs_round_up(4 * U, 16);

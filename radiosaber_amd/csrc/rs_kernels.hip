@@ -135,7 +135,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   /* TBS bits of n RBGs at a final CQI: the I_TBS step of CQI -> MCS -> I_TBS -> TBS folded in ([R+1][16]) */
   for (int i = tid; i < (R + 1) * 16; i += nt) s_tbs[i] = p.tbs_eff[(i >> 4) * 27 + tab->itbs_of_cqi[i & 15]];
   for (int i = tid; i < (R * Upad) >> 2; i += nt) ((uint32_t*)s_cqi)[i] = 0;
-  for (int i = tid; i < Upad; i += nt) s_rcp32[i] = 0.0f;
+  for (int i = tid; i < Upad + 16 * S; i += nt) s_rcp32[i] = 0.0f;
   if (tid < 16) {
     s_num[tid] = (SCHED == 1 || SCHED == 11) ? tab->pfnum[tid] : tab->kbps[tid];
     s_e[tid] = tab->eesm_e[tid];
@@ -165,6 +165,21 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       int sp = u == 0 ? -1 : (int)p.user_slice[u - 1];
       for (int q = sp + 1; q <= s; q++) m->seg_begin[q] = u;
     }
+  }
+  /* The stage-1 reciprocals of a slice live in their own 8-aligned window of s_rcp32, zero before the slice's first user
+   * and after its last: the metric scan reads whole groups of 8 and a slot outside the slice multiplies to 0 without a
+   * range test.  (Sched 1 has no slices: natural order, zeros behind the last user.) */
+  int16_t* s_uoff = (int16_t*)(s_rcp32 + Upad + 16 * S); /* per user: window position minus user index */
+  if (SCHED != 1) {
+    __syncthreads();
+    if (wave == 0) {
+      const int ub = lane < S ? m->seg_begin[lane] : 0, ue = lane < S ? m->seg_begin[lane + 1] : 0;
+      const int wl = ue > ub ? ((ue + 7) & ~7) - (ub & ~7) : 0;
+      const int wb = wave_scan_incl(wl) - wl;
+      if (lane < S) m->rcp_off[lane] = wb - (ub & ~7);
+    }
+    __syncthreads();
+    for (int u = tid; u < U; u += nt) s_uoff[u] = (int16_t)m->rcp_off[p.user_slice[u]];
   }
   double t = scal->t;
   double last_update = scal->last_update;
@@ -272,7 +287,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               r32 = !has ? 0.0f : (use_hol ? r32 * (float)p.hol[u] : r32);
             }
           }
-          s_rcp32[u] = r32;
+          s_rcp32[u + s_uoff[u]] = r32;
         } else {
           s_rcp32[u] = __builtin_amdgcn_rcpf((float)a);
         }
@@ -552,12 +567,14 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         constexpr int kP3Block = (SCHED == 7 && FIXED && kCv.nvs_seg != 0) ? kCv.nvs_seg : RS_P3_BLOCK;
         const bool one_num = SCHED != 1 && !sl_eps;
         const float* numtab = one_num ? m->ones16 : s_num32; /* a table either way: no branch per user */
-        const unsigned seg_len = (unsigned)(ue - ub);
+        /* this slice's window, indexed by user (drop-in NVS passes the served slice's users only: their own slice id) */
+        const float* rcw = s_rcp32 + (SCHED == 1 ? 0 : m->rcp_off[(SCHED == 7 && kDirect) ? (int)p.user_slice[0] : seg]);
 #ifdef RS_EXP_P3_SKIP
         bu = ub; bkey = rowp[ub]; best = 1.0; /* timing experiment only: wrong results */
         for (int blk = ue; blk < ue; blk += kP3Block) {
 #else
-        for (int blk = ub & ~7; blk < ue; blk += kP3Block) {
+        /* (an empty segment must not enter: its 8-aligned start lies before its end, inside a neighbour's window) */
+        for (int blk = ue > ub ? (ub & ~7) : ue; blk < ue; blk += kP3Block) {
 #endif
           /* a~ of the 32 users blk..blk+31 (0 for users outside [ub, ue) and for the padding) */
           float av[kP3Block];
@@ -569,11 +586,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
             if (u0 < ue) {
               cw = *(const uint2*)(rowp + u0);
-              ra = *(const float4*)(s_rcp32 + u0);
-              rb = *(const float4*)(s_rcp32 + u0 + 4);
+              ra = *(const float4*)(rcw + u0);
+              rb = *(const float4*)(rcw + u0 + 4);
             }
             const float rc[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-            const unsigned d0 = (unsigned)(u0 - ub); /* wraps to a huge value left of the segment */
             float nm[8];
             /* CQI bytes are <= 15, so four of them scale to table byte offsets with one shift and each address is
              * one byte-select add */
@@ -585,9 +601,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(nm[k])); /* eight table reads in flight, none behind a branch */
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              /* sched 1 scans 32-aligned runs of ALL users: the only slots outside a run are beyond the last user, where
-               * the reciprocal array holds the zeros it was initialised with -- the product is 0 without a range test */
-              const float a = (SCHED == 1 || d0 + (unsigned)k < seg_len) ? nm[k] * rc[k] : 0.0f;
+              /* no range test: a slot outside the slice (or, sched 1, beyond the last user) reads a zero reciprocal */
+              const float a = nm[k] * rc[k];
               av[8 * g + k] = a;
               best_a = fmaxf(best_a, a);
             }
