@@ -214,6 +214,10 @@ int rs_batch_set_trace(rs_batch* b, const uint8_t* h_trace, int32_t n_traces, in
  *   A line with fewer than nb_rbs values repeats the last value read, like the reference's extraction loop.
  * rs_trace_load_dir reads ue0.log .. ue<n_traces-1>.log of one directory into out_rbg =
  *   [n_traces][n_rows][nb_rbs/rbg_size] (the h_trace argument of rs_batch_set_trace); same return value. */
+/* LDS bytes one cell occupies (the kernel's carve for this shape; no GPU needed).  160 KB per CU: <= 40 960 B keeps four
+ * cells on a CU, <= 81 920 B two. */
+int rs_lds_bytes_per_cell(int n_slices, int n_users, int n_rbgs, int sched, int threads);
+
 /* measurement helper: streaming copy of `bytes` (16 B per lane), `iters` launches timed with HIP events;
  * *copy_gbs = (bytes read + bytes written) / time.  Quoted by bench.py next to the 8 TB/s HBM3E spec. */
 int rs_hbm_copy_probe(int device, uint64_t bytes, int iters, double* copy_gbs);

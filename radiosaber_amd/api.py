@@ -75,7 +75,7 @@ ABI_SYMBOLS = [
     "rs_batch_run", "rs_batch_run_async", "rs_batch_sync", "rs_batch_run_logged",
     "rs_batch_run_timed", "rs_batch_read_state", "rs_batch_slice_bytes_device",
     "rs_batch_slice_bytes", "rs_jit_selfcheck", "rs_batch_debug_stamps", "rs_batch_ttis_done", "rs_batch_stream", "rs_batch_kernel_name",
-    "rs_trace_read_mapping", "rs_trace_read_ue_log", "rs_trace_load_dir", "rs_hbm_copy_probe",
+    "rs_trace_read_mapping", "rs_trace_read_ue_log", "rs_trace_load_dir", "rs_hbm_copy_probe", "rs_lds_bytes_per_cell",
 ]
 
 _lib = None
@@ -125,6 +125,7 @@ def lib():
     L.rs_batch_stream.argtypes = [C.c_void_p]
     L.rs_batch_kernel_name.restype = C.c_char_p
     L.rs_batch_kernel_name.argtypes = [C.c_void_p]
+    L.rs_lds_bytes_per_cell.argtypes = [C.c_int] * 5
     L.rs_hbm_copy_probe.argtypes = [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.rs_trace_read_mapping.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_int32]
     L.rs_trace_read_ue_log.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8),
@@ -161,6 +162,11 @@ def jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCH
 
 def device_count():
     return lib().rs_device_count()
+
+
+def lds_bytes_per_cell(n_slices, n_users, n_rbgs, sched=RS_SCHED_MAXCELL, threads=512):
+    """LDS bytes of one cell of this shape (<= 40 960: four cells per CU, <= 81 920: two)."""
+    return _count(lib().rs_lds_bytes_per_cell(n_slices, n_users, n_rbgs, sched, threads))
 
 
 def hbm_copy_probe(device=0, nbytes=1 << 30, iters=10):

@@ -1004,6 +1004,13 @@ int rs_trace_load_dir(const char* dir, int32_t n_traces, int32_t n_rows, int32_t
   return mixed > 0x7fffffff ? 0x7fffffff : (int)mixed;
 }
 
+int rs_lds_bytes_per_cell(int n_slices, int n_users, int n_rbgs, int sched, int threads) {
+  if (n_slices < 1 || n_slices > RS_MAX_SLICES || n_users < 1 || n_users > RS_MAX_USERS || n_rbgs < 1 || n_rbgs > RS_MAX_RBGS ||
+      threads < 64 || threads > 512 || threads % 64)
+    return fail(RS_ERR_INVALID, "bad shape");
+  return rs_carve(n_slices, n_users, n_rbgs, sched, threads).lds_bytes;
+}
+
 /* ---- measurement helper ---- */
 int rs_hbm_copy_probe(int device, uint64_t bytes, int iters, double* copy_gbs) {
   if (!copy_gbs || iters < 1 || bytes < (1u << 20) || (bytes & 15)) return fail(RS_ERR_INVALID, "bad probe arguments");

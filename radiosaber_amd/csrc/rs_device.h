@@ -30,7 +30,9 @@ struct RsMisc {
   int32_t seg_begin[68];
   int32_t target[64];
   int32_t quota[64];
-  int32_t stack[96];             /* serial introsort emulation (debug path, -DRS_SERIAL_SORT) */
+#ifdef RS_SERIAL_SORT
+  int32_t stack[96];             /* serial introsort emulation (debug build only) */
+#endif
   int32_t n_level[48];           /* level-synchronous introsort: live sub-ranges per recursion level */
   uint16_t hist[64 * 16];        /* counting sort: per 64-element chunk, per key */
   int32_t mcs_of_cqi[16];
@@ -92,7 +94,8 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
   c.off_sorted = off; off += (sched == 7 && nvs_seg != 0) ? 0 : rs_round_up(4 * R * S, 16);
   c.off_items = off; off += rs_round_up(2 * c.n_items, 16);
   /* level-synchronous introsort scratch: cut per sub-range (+ bounds/pivots when the state lives in LDS) */
-  c.off_sortx = off; off += (sched == 9 || sched == 10) ? rs_round_up((c.ept <= 4 ? 2 : 8) * R * S, 16)
+  /* register form (ept <= 4): one cut slot per 16 positions; LDS form: bounds, pivots and cuts per position */
+  c.off_sortx = off; off += (sched == 9 || sched == 10) ? rs_round_up(c.ept <= 4 ? 4 * (R * S / 16 + 2) : 8 * R * S, 16)
                                                            : (sched == 11 ? rs_round_up(rs_nvs_scratch_bytes(U, R), 16) : 0);
   c.off_cqi = off; off += rs_round_up(c.Upad * R, 16);
   c.lds_bytes = off;

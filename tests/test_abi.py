@@ -113,3 +113,16 @@ def test_product_never_touches_the_oracle():
 def test_shape_specialised_source_compiles_for_gfx950(rs, shape):
     """hiprtc build of the embedded kernel source with the cell shape as compile-time constants (no GPU needed)."""
     assert rs.jit_selfcheck(*shape) > 10000
+
+
+def test_headline_shapes_keep_four_cells_per_cu(rs):
+    """160 KB of LDS per CU: a cell of the headline shape (20 slices x 500 UEs x 25 RBGs) must stay at or under 40 960 B so
+    that large batches place four cells on a CU (measured: 38 M instead of 23-29 M TTIs/s at 1 024+ cells), and the
+    as-shipped 64-RBG grid under 81 920 B (two per CU)."""
+    for sched in (1, 7, 8, 9):
+        for threads in (256, 512):
+            assert rs.lds_bytes_per_cell(20, 500, 25, sched, threads) <= 40960, (sched, threads)
+            assert rs.lds_bytes_per_cell(20, 500, 64, sched, threads) <= 81920, (sched, threads)
+    assert rs.lds_bytes_per_cell(20, 500, 25, 10, 512) <= 40960
+    with pytest.raises(rs.RadioSaberError):
+        rs.lds_bytes_per_cell(65, 500, 25)
