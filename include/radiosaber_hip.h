@@ -52,6 +52,9 @@ enum {
                               UEs may hold one RBG.  rbg_to_user then reports the UE of the lowest-numbered slice holding
                               the RBG; user_nprb / user_tbs_bits / ... are complete and rs_tti_out.upper_rbg / upper_user list
                               every slice's RBGs in push order.  Needs n_rbgs*n_slices <= 2048. */
+  RS_SCHED_SUBOPT = 101,   /* DownlinkTransportScheduler + SubOpt (ref: :274-349; inter_sched_ = 1, which no CLI number selects):
+                            * best slice per RBG, then least-loss moves from slices above to slices below their quota, ties
+                            * in the order libstdc++'s unordered_map yields the slices */
   RS_SCHED_VOGEL = 103     /* DownlinkTransportScheduler + VogelApproximate (ref: :378-451; inter_sched_ = 3, which no CLI
                               scheduler number of the reference selects -- ENodeB::DLScheduler_VOGEL exists, ENodeB.cpp:375) */
 };

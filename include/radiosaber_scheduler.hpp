@@ -191,7 +191,7 @@ class GpuDownlinkScheduler {
     }
     in.hol_delay = in_hol_.data();
     in.prio_has_data = in_prio_.data();
-    if (sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL || sched_ == RS_SCHED_VOGEL || sched_ == RS_SCHED_UPPERBOUND) {
+    if (sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL || sched_ == RS_SCHED_VOGEL || sched_ == RS_SCHED_SUBOPT || sched_ == RS_SCHED_UPPERBOUND) {
       in.rand0 = rand();
       in.rand1 = rand();
     }
@@ -240,7 +240,7 @@ class GpuDownlinkScheduler {
    * The PF scheduler prints no map. */
   void WriteAllocationLog(std::ostream& os) const {
     if (sched_ == RS_SCHED_PF) return;
-    const bool transport = sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL || sched_ == RS_SCHED_VOGEL ||
+    const bool transport = sched_ == RS_SCHED_SEQUENTIAL || sched_ == RS_SCHED_MAXCELL || sched_ == RS_SCHED_VOGEL || sched_ == RS_SCHED_SUBOPT ||
                            sched_ == RS_SCHED_UPPERBOUND;
     if (transport) {
       os << "slice_id, target_rbs, quota_rbgs: ";

@@ -15,6 +15,7 @@ LIB = HERE / "librs_oracle.so"
 REF_DIR = HERE / "_ref"
 
 SCHED_PF, SCHED_NVS, SCHED_SEQUENTIAL, SCHED_MAXCELL, SCHED_VOGEL, SCHED_UPPERBOUND, SCHED_NVS_NONGREEDY = 1, 7, 8, 9, 103, 10, 11
+SCHED_SUBOPT = 101
 
 
 def build(quiet=True):
@@ -90,7 +91,7 @@ def lib():
                                     C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.rso_srand.argtypes = [C.POINTER(_Rng), C.c_uint]
         L.rso_rand.argtypes = [C.POINTER(_Rng)]
-        for fn in ("rso_greedy_by_row", "rso_maximize_cell", "rso_vogel"):
+        for fn in ("rso_greedy_by_row", "rso_maximize_cell", "rso_vogel", "rso_subopt"):
             getattr(L, fn).argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.c_int,
                                        C.POINTER(C.c_int)]
         L.rso_maximize_cell_order.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_int)]
@@ -138,7 +139,7 @@ class Rng:
 
 
 def interslice(fn, eff, quota):
-    """fn in {'greedy_by_row','maximize_cell','vogel'}; eff [R][S] float64 -> rbg_to_slice [R]."""
+    """fn in {'greedy_by_row','maximize_cell','vogel','subopt'}; eff [R][S] float64 -> rbg_to_slice [R]."""
     eff = np.ascontiguousarray(eff, np.float64)
     R, S = eff.shape
     q = np.ascontiguousarray(quota, np.int32)

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -216,7 +217,49 @@ void rso_vogel(const double* eff, const int* quota, int R, int S, int* rbg_to_sl
   }
 }
 
-void rso_subopt(const double*, int*, int, int, int*) { /* iterates an unordered_map: not restated */ }
+/* ref: downlink-transport-scheduler.cpp:274-349.  Every RBG first goes to its best slice (first maximum), then single RBGs
+ * move from slices above their quota to slices below it, each time the move that loses the least efficiency; ties go to
+ * the first candidate in RBG order and, within an RBG, in the order the `slice_fewer` hashtable yields its keys -- the
+ * real std::unordered_map is used here so that the order is libstdc++'s, as in the reference.  Negative quotas count as 0
+ * (the reference clamps them in place). */
+void rso_subopt(const double* eff, const int* quota_in, int R, int S, int* rbg_to_slice) {
+  std::vector<int> quota(quota_in, quota_in + S), got(S, 0);
+  for (int j = 0; j < S; j++)
+    if (quota[j] < 0) quota[j] = 0;
+  for (int i = 0; i < R; i++) {
+    double best = -1;
+    int pick = -1;
+    for (int j = 0; j < S; j++)
+      if (eff[i * S + j] > best) { best = eff[i * S + j]; pick = j; }
+    rbg_to_slice[i] = pick;
+    got[pick] += 1;
+  }
+  std::unordered_map<int, int> more, fewer;
+  for (int j = 0; j < S; j++) {
+    if (got[j] > quota[j]) more[j] = got[j] - quota[j];
+    else if (got[j] < quota[j]) fewer[j] = quota[j] - got[j];
+  }
+  while (!more.empty() && !fewer.empty()) {
+    int from = -1, to = -1, rbg = -1;
+    double least = std::numeric_limits<double>::max();
+    for (int i = 0; i < R; i++) {
+      const int own = rbg_to_slice[i];
+      if (more.find(own) == more.end()) continue;
+      for (auto it = fewer.begin(); it != fewer.end(); ++it) {
+        const double loss = eff[i * S + own] - eff[i * S + it->first];
+        if (loss < least) { least = loss; from = own; to = it->first; rbg = i; }
+      }
+    }
+    if (from < 0) break; /* reference asserts */
+    got[from] -= 1;
+    got[to] += 1;
+    rbg_to_slice[rbg] = to;
+    more.at(from) -= 1;
+    fewer.at(to) -= 1;
+    if (more.at(from) <= 0 || got[from] <= 0) more.erase(from);
+    if (fewer.at(to) <= 0) fewer.erase(to);
+  }
+}
 
 }  // extern "C"
 
@@ -481,6 +524,7 @@ int allocate_transport(rso_cell* c, const double* avg, int rand0, int rand1, rso
     case RSO_SCHED_SEQUENTIAL: rso_greedy_by_row(slice_eff.data(), quota.data(), R, S, rbg_to_slice.data()); break;
     case RSO_SCHED_MAXCELL: rso_maximize_cell(slice_eff.data(), quota.data(), R, S, rbg_to_slice.data()); break;
     case RSO_SCHED_VOGEL: rso_vogel(slice_eff.data(), quota.data(), R, S, rbg_to_slice.data()); break;
+    case RSO_SCHED_SUBOPT: rso_subopt(slice_eff.data(), quota.data(), R, S, rbg_to_slice.data()); break;
     default: return -2;
   }
   /* :589-601 apply; an RBG MaximizeCell could not place stays unassigned (reference would
@@ -698,7 +742,8 @@ int rso_cell_step(rso_cell* c, double now, int rand0, int rand1, rso_tti_out* ou
 }
 
 static bool uses_rand(int sched) {
-  return sched == RSO_SCHED_SEQUENTIAL || sched == RSO_SCHED_MAXCELL || sched == RSO_SCHED_VOGEL || sched == RSO_SCHED_UPPERBOUND;
+  return sched == RSO_SCHED_SEQUENTIAL || sched == RSO_SCHED_MAXCELL || sched == RSO_SCHED_VOGEL || sched == RSO_SCHED_UPPERBOUND ||
+         sched == RSO_SCHED_SUBOPT;
 }
 
 int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_map, int* log_fcqi, int* log_quota,

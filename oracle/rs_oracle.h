@@ -16,6 +16,8 @@
  *                             unittest/test_tp_algos.cpp (oracle/_ref/libref_tp_algos.so).
  *   - whole sched-9 TTI loop  SURVEY.md Appendix A known-answer values (first scheduled TTI map,
  *                             cumu_bytes/cumu_rbs after 200 TTIs), tests/golden/appendix_a.json.
+ *   - SubOpt ................ restated from the cited lines with the real std::unordered_map; PARITY UNPINNED
+ *                             (no CLI number selects it, not in the unit program).
  *   - sched 1/7/8 loops ..... restated from the cited lines; PARITY UNPINNED beyond the shared
  *                             components above (the full simulator cannot be built in this image:
  *                             it needs jsoncpp and a generated header).
@@ -67,7 +69,7 @@ int rso_rand(rso_rng* g);
 void rso_greedy_by_row(const double* eff, const int* quota, int R, int S, int* rbg_to_slice);
 void rso_maximize_cell(const double* eff, const int* quota, int R, int S, int* rbg_to_slice);
 void rso_vogel(const double* eff, const int* quota, int R, int S, int* rbg_to_slice);
-void rso_subopt(const double* eff, int* quota_inout, int R, int S, int* rbg_to_slice);
+void rso_subopt(const double* eff, const int* quota, int R, int S, int* rbg_to_slice); /* :274-349 */
 /* the post-std::sort order MaximizeCell scans (index = rbg*S+slice), for kernel unit tests */
 void rso_maximize_cell_order(const double* eff, int R, int S, int* order);
 

@@ -5,14 +5,14 @@ HIP for gfx950).  There is no CPU fallback: creating a scheduler without a HIP d
 built library, raises.
 """
 from .api import (  # noqa: F401
-    RS_SCHED_MAXCELL, RS_SCHED_NVS, RS_SCHED_PF, RS_SCHED_NVS_NONGREEDY, RS_SCHED_SEQUENTIAL, RS_SCHED_UPPERBOUND, RS_SCHED_VOGEL,
+    RS_SCHED_MAXCELL, RS_SCHED_NVS, RS_SCHED_PF, RS_SCHED_NVS_NONGREEDY, RS_SCHED_SEQUENTIAL, RS_SCHED_UPPERBOUND, RS_SCHED_VOGEL, RS_SCHED_SUBOPT,
     TRACE_CQI_HISTOGRAM,
     BatchScheduler, RadioSaberError, SliceConfig, TtiResult, TtiScheduler, device_count, hbm_copy_probe, jit_selfcheck, lds_bytes_per_cell,
     lib,
     link_tables, load_trace_dir, read_trace_mapping, read_ue_trace,
 )
 
-__all__ = ["RS_SCHED_PF", "RS_SCHED_NVS", "RS_SCHED_SEQUENTIAL", "RS_SCHED_MAXCELL", "RS_SCHED_VOGEL", "RS_SCHED_UPPERBOUND", "RS_SCHED_NVS_NONGREEDY", "SliceConfig",
+__all__ = ["RS_SCHED_PF", "RS_SCHED_NVS", "RS_SCHED_SEQUENTIAL", "RS_SCHED_MAXCELL", "RS_SCHED_VOGEL", "RS_SCHED_SUBOPT", "RS_SCHED_UPPERBOUND", "RS_SCHED_NVS_NONGREEDY", "SliceConfig",
            "TtiScheduler", "TtiResult", "BatchScheduler", "RadioSaberError", "device_count", "lib",
            "link_tables", "jit_selfcheck", "TRACE_CQI_HISTOGRAM", "read_trace_mapping", "read_ue_trace",
            "load_trace_dir", "hbm_copy_probe", "lds_bytes_per_cell"]

@@ -17,6 +17,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
+RS_SCHED_SUBOPT = 101
 RS_SCHED_PF, RS_SCHED_NVS, RS_SCHED_SEQUENTIAL, RS_SCHED_MAXCELL, RS_SCHED_UPPERBOUND, RS_SCHED_NVS_NONGREEDY, RS_SCHED_VOGEL = \
     1, 7, 8, 9, 10, 11, 103
 

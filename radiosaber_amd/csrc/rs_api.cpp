@@ -230,7 +230,7 @@ int validate(const rs_config* c, bool direct) {
   if (c->rbg_size < 1 || c->rbg_size > 8) return fail(RS_ERR_INVALID, "rbg_size %d outside 1..8", c->rbg_size);
   if (c->n_rbgs * c->rbg_size > 512) return fail(RS_ERR_INVALID, "more than 512 PRBs (reference get_rbg_size throws)");
   if (c->sched != RS_SCHED_PF && c->sched != RS_SCHED_NVS && c->sched != RS_SCHED_SEQUENTIAL && c->sched != RS_SCHED_MAXCELL &&
-      c->sched != RS_SCHED_VOGEL && c->sched != RS_SCHED_UPPERBOUND && c->sched != RS_SCHED_NVS_NONGREEDY)
+      c->sched != RS_SCHED_VOGEL && c->sched != RS_SCHED_SUBOPT && c->sched != RS_SCHED_UPPERBOUND && c->sched != RS_SCHED_NVS_NONGREEDY)
     return fail(RS_ERR_INVALID, "sched %d not supported (1, 7, 8, 9)", c->sched);
   if (!c->slice_weight || !c->algo_alpha || !c->algo_epsilon || !c->algo_psi || !c->user_to_slice)
     return fail(RS_ERR_INVALID, "null slice/user array");
@@ -686,6 +686,7 @@ const char* rs_batch_kernel_name(rs_batch* b) {
     case 1: return "rs_cell_kernel<1, 0, false>";
     case 7: return "rs_cell_kernel<7, 0, false>";
     case 8: return "rs_cell_kernel<8, 0, false>";
+    case RS_SCHED_SUBOPT: return "rs_cell_kernel<101, 0, false>";
     case RS_SCHED_VOGEL: return "rs_cell_kernel<103, 0, false>";
     case RS_SCHED_NVS_NONGREEDY: return "rs_cell_kernel<11, 0, false>";
     case RS_SCHED_UPPERBOUND: {

@@ -61,6 +61,9 @@ constexpr int rs_upad_of(int U) {
 }
 /* sched 11 (NVS non-greedy sampler) scratch, at off_sortx: val f64[U][4] | hm f64[32][R] | draws u8[8192] |
  * ha u16[32][R] | pad | high u8[U] */
+#ifndef RS_UMAP_SCRATCH_BYTES
+#define RS_UMAP_SCRATCH_BYTES 272 /* sched 101 (SubOpt), at off_sortx: rs_umap_order's nxt u8[68] | bkt u8[128] | ord u8[64] */
+#endif
 #define RS_NVS_SAMPLES 300      /* num_sample, downlink-nvs-scheduler.cpp:430 */
 #define RS_NVS_DRAW_BYTES 8192  /* draws of one batch of samples */
 #define RS_NVS_BATCH 32         /* samples per batch at most */
@@ -96,7 +99,7 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
   /* level-synchronous introsort scratch: cut per sub-range (+ bounds/pivots when the state lives in LDS) */
   /* register form (ept <= 4): one cut slot per 16 positions; LDS form: bounds, pivots and cuts per position */
   c.off_sortx = off; off += (sched == 9 || sched == 10) ? rs_round_up(c.ept <= 4 ? 4 * (R * S / 16 + 2) : 8 * R * S, 16)
-                                                           : (sched == 11 ? rs_round_up(rs_nvs_scratch_bytes(U, R), 16) : 0);
+                                                           : (sched == 11 ? rs_round_up(rs_nvs_scratch_bytes(U, R), 16) : (sched == 101 ? RS_UMAP_SCRATCH_BYTES : 0));
   c.off_cqi = off; off += rs_round_up(c.Upad * R, 16);
   c.lds_bytes = off;
   return c;

@@ -17,7 +17,7 @@
  *                                          sampler (downlink-nvs-scheduler.cpp:405-528) in place of P3/P4
  *   P5  apply + EESM link adaptation + DoStopSchedule counters     ref: :589-674, :170-221
  *
- * Template parameters of the cell body: SCHED = the reference's CLI scheduler number (1, 7, 8, 9, 10, 11; 103 = Vogel),
+ * Template parameters of the cell body: SCHED = the reference's CLI scheduler number (1, 7, 8, 9, 10, 11; 101 = SubOpt, 103 = Vogel),
  * EPT = sort positions per thread (0: state in LDS, any size), FIXED = shape-specialised build, DIRECT = the drop-in
  * entry point's one-TTI form on caller-provided state.  Wave-level building blocks live in rs_wave.h.
  *
@@ -98,7 +98,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
                               kCv.n_seg, kCv.n_items}
                        : Offs{p.off_avgk, p.off_rcp, p.off_tab, p.off_slice, p.off_tx, p.off_misc, p.off_tbs, p.off_elems,
                               p.off_sorted, p.off_items, p.off_sortx, p.off_cqi, p.Upad, p.n_seg, p.n_items};
-  constexpr bool kTransport = (SCHED == 8 || SCHED == 9 || SCHED == 103 || SCHED == 10);
+  constexpr bool kTransport = (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103 || SCHED == 10);
   const int quota_wave = nwaves - 1; /* P2 runs on the last wave, beside the other waves' P3 */
 
   double* s_avg = (double*)lds;
@@ -953,6 +953,70 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           int u = s_best_user[my_slice * R + lane];
           owner = u == 0xFFFF ? -1 : u;
         }
+      } else if (SCHED == 101) {
+        /* SubOpt, ref: downlink-transport-scheduler.cpp:274-349.  Every RBG (lanes = RBGs) starts at its best slice (first
+         * maximum); then one RBG per round moves from a slice above its quota to a slice below it -- the move with the
+         * smallest efficiency loss, first in (RBG ascending, `slice_fewer` iteration order) among equal losses.  That order
+         * is libstdc++'s unordered_map order after the ascending insertions (erasures keep it): lane 0 computes it once per
+         * TTI (rs_umap_order), lane p then holds the p-th key.  Counters live in lanes = slices; negative quotas count as 0. */
+        int my_slice = -1;
+        const uint32_t* row = s_elems + (lane < R ? lane : 0) * S;
+        {
+          int bestk = -1;
+          for (int k = 0; k < S; ++k) {
+            const int key = (int)(row[k] >> 16);
+            if (key > bestk) { bestk = key; my_slice = k; }
+          }
+          if (lane >= R) my_slice = -1;
+        }
+        for (int sl = 0; sl < S; ++sl) {
+          const int cnt = __popcll(__ballot(my_slice == sl));
+          if (lane == sl) got = cnt;
+        }
+        int quota = lane < S ? m->quota[lane] : 0;
+        quota = quota < 0 ? 0 : quota;
+        int more = (lane < S && got > quota) ? got - quota : 0;
+        int fewer = (lane < S && got < quota) ? quota - got : 0;
+        unsigned long long more_mask = __ballot(more > 0), fewer_mask = __ballot(fewer > 0);
+        uint8_t* um = (uint8_t*)(lds + o.sortx);
+        int n_ord = 0;
+        if (lane == 0 && more_mask && fewer_mask) n_ord = rs_umap_order(fewer_mask, um, um + 68, um + 196);
+        n_ord = __builtin_amdgcn_readfirstlane(n_ord);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int ordv = lane < n_ord ? um[196 + lane] : 0;
+        while (more_mask && fewer_mask) {
+          const bool cand = my_slice >= 0 && ((more_mask >> my_slice) & 1ull);
+          const double own_eff = m->eff16[row[my_slice >= 0 ? my_slice : 0] >> 16];
+          double least = 1.7976931348623157e308;
+          int to_sl = -1;
+          for (int q = 0; q < n_ord; ++q) {
+            const int key = __builtin_amdgcn_readlane(ordv, q);
+            if (!((fewer_mask >> key) & 1ull)) continue;
+            const double loss = own_eff - m->eff16[row[key] >> 16];
+            if (loss < least) { least = loss; to_sl = key; }
+          }
+          /* smallest loss over the candidate RBGs, lowest RBG among equals: losses are >= 0, their bit patterns order
+           * like the values */
+          const long long lb = __double_as_longlong(least);
+          const int hi = cand ? (int)(lb >> 32) : 0x7fffffff;
+          const int hmin = wave_min(hi);
+          const int lo = (cand && hi == hmin) ? (int)((uint32_t)lb ^ 0x80000000u) : 0x7fffffff;
+          const int lmin = wave_min(lo);
+          const unsigned long long hit = __ballot(cand && hi == hmin && lo == lmin);
+          if (!hit) break; /* reference asserts */
+          const int rbg = __ffsll((long long)hit) - 1;
+          const int from = __builtin_amdgcn_readlane(my_slice, rbg), to = __builtin_amdgcn_readlane(to_sl, rbg);
+          if (lane == rbg) my_slice = to;
+          if (lane == from) { got--; more--; }
+          if (lane == to) { got++; fewer--; }
+          more_mask = __ballot(more > 0 && got > 0);
+          fewer_mask = __ballot(fewer > 0);
+        }
+        if (lane < R && my_slice >= 0) {
+          int u = s_best_user[my_slice * R + lane];
+          owner = u == 0xFFFF ? -1 : u;
+        }
       } else if (SCHED == 1) {
         /* ref: downlink-packet-scheduler.cpp:221-237 -- per RBG the first maximum over all flows,
          * here over the segment winners in ascending segment order */
@@ -1205,6 +1269,7 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
     case 1: RS_LAUNCH_CELL(1, 0); break;
     case 7: RS_LAUNCH_CELL(7, 0); break;
     case 8: RS_LAUNCH_CELL(8, 0); break;
+    case 101: RS_LAUNCH_CELL(101, 0); break;
     case 103: RS_LAUNCH_CELL(103, 0); break;
     case 11: RS_LAUNCH_CELL(11, 0); break;
     case 10:
@@ -1228,7 +1293,7 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
 
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes) {
 #define RS_BOTH(SCHED_, EPT_) (const void*)rs_cell_kernel<SCHED_, EPT_, false>, (const void*)rs_cell_kernel<SCHED_, EPT_, true>
-  const void* fns[] = {RS_BOTH(1, 0),  RS_BOTH(7, 0),  RS_BOTH(8, 0),  RS_BOTH(103, 0), RS_BOTH(11, 0),
+  const void* fns[] = {RS_BOTH(1, 0),  RS_BOTH(7, 0),  RS_BOTH(8, 0),  RS_BOTH(101, 0), RS_BOTH(103, 0), RS_BOTH(11, 0),
                        RS_BOTH(10, 1), RS_BOTH(10, 2), RS_BOTH(10, 3), RS_BOTH(10, 4),
                        RS_BOTH(9, 0),  RS_BOTH(9, 1),  RS_BOTH(9, 2),  RS_BOTH(9, 3),  RS_BOTH(9, 4)};
 #undef RS_BOTH

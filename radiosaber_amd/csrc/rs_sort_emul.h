@@ -166,4 +166,72 @@ RS_HD void introsort_loop(A& v, int n, S& stk, int depth_limit = -1) {
 
 }  // namespace rs_sort
 
+/* ---- Iteration order of libstdc++'s std::unordered_map<int, int> (GCC 11, <bits/hashtable.h> + _Prime_rehash_policy), restated
+ * for host and device code.
+ *
+ * The reference's SubOpt (downlink-transport-scheduler.cpp:296-306, 315) fills `slice_fewer` with the slices below their
+ * quota in ascending slice order and afterwards iterates it with strict `<` comparisons, so ties between equal
+ * efficiency losses go to the slice the hashtable happens to yield first.  Later `erase` calls unlink nodes without moving
+ * the others, hence the order of the survivors is the order right after the insertions, which this file computes:
+ *
+ *  - one singly linked list of all nodes; the nodes of a bucket are contiguous; a bucket remembers the node BEFORE its first;
+ *  - insert into a non-empty bucket: right behind that "before" node (front of the bucket's group); into an empty bucket:
+ *    at the front of the whole list (and the bucket of the former first node now has the new node as its "before");
+ *  - identity hash, bucket = key % bucket_count; bucket counts 13, 29, 59, 127, grown when the element count would exceed
+ *    the bucket count (max_load_factor 1; the first insertion allocates 13 buckets);
+ *  - a rehash walks the old list front to back and re-inserts each node by the same two rules.
+ *
+ * tests/test_sort_emul.py::test_unordered_map_order_matches_libstdcxx checks this against the real container on every
+ * subset it draws; the oracle calls the real container.
+ */
+#define RS_UMAP_NIL 0xFF
+#define RS_UMAP_HEAD 64 /* index of the list's before-begin node in nxt[] */
+#ifndef RS_UMAP_SCRATCH_BYTES
+#define RS_UMAP_SCRATCH_BYTES 272 /* nxt u8[68] | bkt u8[128] | ord u8[64] (+ padding) */
+#endif
+
+/* keys: bit k set = key k inserted (ascending); nxt[65], bkt[127]: scratch; ord[64]: the keys in iteration order.
+ * Returns the number of keys. */
+RS_HD int rs_umap_order(uint64_t keys, uint8_t* nxt, uint8_t* bkt, uint8_t* ord) {
+  int n_bkt = 0, count = 0;
+  nxt[RS_UMAP_HEAD] = RS_UMAP_NIL;
+  for (int key = 0; key < 64; ++key) {
+    if (!((keys >> key) & 1ull)) continue;
+    if (count + 1 > n_bkt) { /* _M_need_rehash: 0 -> 13 -> 29 -> 59 -> 127 */
+      n_bkt = n_bkt == 0 ? 13 : (n_bkt == 13 ? 29 : (n_bkt == 29 ? 59 : 127));
+      for (int b = 0; b < n_bkt; ++b) bkt[b] = RS_UMAP_NIL;
+      int p = nxt[RS_UMAP_HEAD], front_bkt = 0;
+      nxt[RS_UMAP_HEAD] = RS_UMAP_NIL;
+      while (p != RS_UMAP_NIL) { /* _M_rehash_aux(unique keys) */
+        const int next = nxt[p], b = p % n_bkt;
+        if (bkt[b] == RS_UMAP_NIL) {
+          nxt[p] = nxt[RS_UMAP_HEAD];
+          nxt[RS_UMAP_HEAD] = (uint8_t)p;
+          bkt[b] = RS_UMAP_HEAD;
+          if (nxt[p] != RS_UMAP_NIL) bkt[front_bkt] = (uint8_t)p;
+          front_bkt = b;
+        } else {
+          nxt[p] = nxt[bkt[b]];
+          nxt[bkt[b]] = (uint8_t)p;
+        }
+        p = next;
+      }
+    }
+    const int b = key % n_bkt; /* _M_insert_bucket_begin */
+    if (bkt[b] != RS_UMAP_NIL) {
+      nxt[key] = nxt[bkt[b]];
+      nxt[bkt[b]] = (uint8_t)key;
+    } else {
+      nxt[key] = nxt[RS_UMAP_HEAD];
+      nxt[RS_UMAP_HEAD] = (uint8_t)key;
+      if (nxt[key] != RS_UMAP_NIL) bkt[nxt[key] % n_bkt] = (uint8_t)key;
+      bkt[b] = RS_UMAP_HEAD;
+    }
+    ++count;
+  }
+  int m = 0;
+  for (int p = nxt[RS_UMAP_HEAD]; p != RS_UMAP_NIL; p = nxt[p]) ord[m++] = (uint8_t)p;
+  return m;
+}
+
 #endif /* RS_SORT_EMUL_H_ */

@@ -246,7 +246,7 @@ def test_device_synth_grids_in_range_and_runs(rs, oracle):
     b.close()
 
 
-@pytest.mark.parametrize("sched", [9, 8, 1, 7, 103, 10])
+@pytest.mark.parametrize("sched", [9, 8, 1, 7, 103, 10, 101])
 def test_drop_in_single_tti(rs, oracle, sched):
     """rs_schedule_tti == RBsAllocation() of the oracle, carrying slice_rbs_offset_ across calls."""
     ues, R, G = [5] * 20, 64, 8
@@ -455,7 +455,7 @@ def test_random_shapes_all_schedulers(rs, oracle, seed):
         R, G = [(25, 4), (64, 8), (12, 2), (50, 2), (17, 3), (33, 3)][int(rng.integers(0, 6))]
         w = rng.uniform(0.2, 1.0, S)
         w = [float(x) for x in w / w.sum()]
-        sched = [9, 9, 9, 8, 7, 1, 103, 10, 11][int(rng.integers(0, 9))]
+        sched = [9, 9, 9, 8, 7, 1, 103, 10, 11, 101][int(rng.integers(0, 10))]
         threads = [0, 64, 128, 256, 512][int(rng.integers(0, 5))]
         if sched == 10 and threads and R * S > 4 * threads:
             threads = 0  # UpperBound needs R*S <= 4 * threads; 0 lets the library choose
@@ -474,6 +474,21 @@ def test_maximum_sizes(rs, oracle):
     _check_batch(rs, oracle, 8, [512, 512], 64, 8, n_cells=1, n_ttis=45)          # U = 1024 x 64 RBGs
     _check_batch(rs, oracle, 1, [512, 512], 64, 8, n_cells=1, n_ttis=45)
     _check_batch(rs, oracle, 7, [1024], 64, 8, n_cells=1, n_ttis=45)
+
+
+def test_subopt_policy_on_the_device(rs, oracle):
+    """N4: SubOpt (ref: downlink-transport-scheduler.cpp:274-349).  Ties between equal efficiency losses follow the order
+    libstdc++'s unordered_map yields the under-quota slices: the oracle uses the real container, the device its own
+    restatement of the hashtable (rs_umap_order, checked against the container on the CPU).  More than 13 / 29 / 59
+    under-quota slices exercise the rehashes; skewed weights make slices over and under quota every TTI."""
+    _check_batch(rs, oracle, 101, [5] * 20, 25, 4, n_cells=3, n_ttis=90)
+    _check_batch(rs, oracle, 101, [5] * 20, 64, 8, n_cells=2, n_ttis=50)
+    _check_batch(rs, oracle, 101, [3, 7, 0, 1, 12], 25, 4, n_cells=2, n_ttis=50)                 # ragged, one empty slice
+    _check_batch(rs, oracle, 101, [10] * 5, 25, 4, n_cells=2, n_ttis=90, weights=[0.62, 0.3, 0.05, 0.02, 0.01])
+    _check_batch(rs, oracle, 101, [2] * 64, 64, 2, n_cells=2, n_ttis=60)                          # 64 slices: 13 -> 29 -> 59 -> 127 buckets
+    _check_batch(rs, oracle, 101, [3] * 40, 50, 2, n_cells=2, n_ttis=60)
+    _check_batch(rs, oracle, 101, [2] * 64, 33, 3, n_cells=1, n_ttis=45, jit=True)
+    _check_batch(rs, oracle, 101, [25] * 20, 25, 4, n_cells=1, n_ttis=45, jit=True)
 
 
 def test_vogel_policy_on_the_device(rs, oracle):
@@ -715,7 +730,7 @@ def test_two_batches_interleaved_and_other_refresh_period(rs, oracle):
         b.close()
 
 
-@pytest.mark.parametrize("sched", [9, 8, 7, 1, 10, 11, 103])
+@pytest.mark.parametrize("sched", [9, 8, 7, 1, 10, 11, 103, 101])
 def test_degenerate_shapes(rs, oracle, sched):
     """One RBG, one UE, one slice, an empty slice between two others, one UE on 64 RBGs, 64 UEs on one RBG: no sort level,
     no run, no batch is ever full -- every scheduler, both kernel flavours."""

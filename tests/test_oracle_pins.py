@@ -184,6 +184,51 @@ def test_vogel_matches_reference_unit_code(oracle):
         assert (got == out).all(), trial
 
 
+def test_subopt_properties(oracle):
+    """SubOpt (ref: downlink-transport-scheduler.cpp:274-349) has no reference output to pin against (no CLI number, not in
+    the unit program): parity unpinned.  Checked here: quotas are met exactly when they sum to R; on grids without equal
+    losses (continuous values, where the hashtable order cannot matter) it equals a plain Python restatement; and every
+    move goes from an over-quota to an under-quota slice."""
+    rng = np.random.default_rng(8)
+    eff = np.array([0.0] + KA["eff_of_cqi"])
+    for trial in range(150):
+        R, S = int(rng.integers(2, 40)), int(rng.integers(1, 30))
+        ties = trial % 2 == 0
+        grid = eff[rng.integers(0, 16, (R, S))] if ties else rng.uniform(0.0, 5.0, (R, S))
+        quota = np.zeros(S, np.int32)
+        for _ in range(R):
+            quota[rng.integers(0, S)] += 1
+        if trial % 7 == 0 and S > 1:  # negative quotas count as 0
+            quota[0] = -2
+        out = oracle.interslice("subopt", grid, quota)
+        q = np.maximum(quota, 0)
+        got = np.bincount(out, minlength=S)
+        if q.sum() == R:
+            assert (got == q).all(), trial
+        first = grid.argmax(1)
+        moved = out != first
+        have = np.bincount(first, minlength=S)
+        assert (have[first[moved]] > q[first[moved]]).all() and (have[out[moved]] < q[out[moved]]).all()
+        if not ties:
+            own = first.copy()
+            cnt = have.copy()
+            more = {j: cnt[j] - q[j] for j in range(S) if cnt[j] > q[j]}
+            fewer = {j: q[j] - cnt[j] for j in range(S) if cnt[j] < q[j]}
+            while more and fewer:
+                loss, i, j = min((grid[i, own[i]] - grid[i, j], i, j) for i in range(R) if own[i] in more for j in fewer)
+                f = own[i]
+                own[i] = j
+                cnt[f] -= 1
+                cnt[j] += 1
+                more[f] -= 1
+                fewer[j] -= 1
+                if more[f] <= 0 or cnt[f] <= 0:
+                    del more[f]
+                if fewer[j] <= 0:
+                    del fewer[j]
+            assert (own == out).all(), trial
+
+
 def test_greedy_by_row_properties(oracle):
     rng = np.random.default_rng(4)
     eff = np.array([0.0] + KA["eff_of_cqi"])
