@@ -115,7 +115,10 @@ typedef struct rs_tti_in {
   const uint8_t* cqi;       /* [n][R] CQI (1..15) of PRB rbg*rbg_size = GetCqiFeedbacks().at(rbg*rbg_size);
                                the whole RBG carries that CQI (true for every shipped trace);
                                see cqi_prb for the general case                                     */
-  const double* avg_rate;   /* [n] sum over the user's bearers of GetAverageTransmissionRate()      */
+  const double* avg_rate;   /* [n] GetAverageTransmissionRate() of the user's bearer; the kernel forms the reference's
+                             *     `averageRate = 1 + avg` (:681-686).  A user holding two bearers (MAX_BEARERS = 2): pass
+                             *     ((1 + a0) + a1) - 1, which is exact for averages >= 1 and reproduces the reference's
+                             *     summation order bit for bit (the C++ adapter does this) */
   int32_t rand0, rand1;     /* the two rand() values RBsAllocation draws (ref: :490, :511);
                                ignored by RS_SCHED_PF / RS_SCHED_NVS                                */
   const uint8_t* cqi_prb;   /* optional [n][R*rbg_size]: the full per-PRB GetCqiFeedbacks() vectors.  When

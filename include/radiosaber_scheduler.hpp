@@ -29,6 +29,8 @@
 
 namespace radiosaber {
 
+constexpr int kMaxBearers = 2; /* MAX_BEARERS, packet-scheduler.h:31: a user's bearers are indexed by their priority */
+
 /* RadioBearer fields the path reads and writes (src/flows/radio-bearer.h:81-85) */
 struct BearerState {
   double average_transmission_rate = 100000; /* radio-bearer.cpp:54 */
@@ -36,10 +38,15 @@ struct BearerState {
   double last_update = 0;
   unsigned long cumulative_bytes = 0;
   unsigned long cumulative_rbs = 0;
-  bool has_packets = true; /* InfiniteBuffer: always backlogged */
-  /* customised slices (algo_alpha = 1): state of the slice-priority bearer */
-  double hol_delay = 0;          /* GetHeadOfLinePacketDelay() */
-  bool prio_has_data = true;     /* m_dataToTransmit[slice_priority_[slice]] != 0 */
+  bool has_packets = true; /* HasPackets(); InfiniteBuffer: always backlogged */
+  double hol_delay = 0;    /* GetHeadOfLinePacketDelay(), refreshed by the simulator before DoSchedule() */
+  /* one bearer per user (no AddBearer call): what the metric of a customised slice (algo_alpha = 1) sees,
+   * m_dataToTransmit[slice_priority_[slice]] != 0.  With AddBearer it is derived from the bearers themselves. */
+  bool prio_has_data = true;
+  /* bearers of a user (priority 0 exists from the start, application id = user id; AddBearer creates the others) */
+  bool exists = false;
+  int application_id = -1; /* GetApplication()->GetApplicationID(), the "app:" of the stderr line */
+  int queue_size = -1;     /* GetQueueSize() in bytes, refreshed by the simulator; < 0: InfiniteBuffer (100000000) */
 };
 
 /* One PDCCH record group: what RBsAllocation() hands to the PHY per scheduled user
@@ -65,7 +72,12 @@ class GpuDownlinkScheduler {
       for (int j = 0; j < ues_per_slice[s]; ++j) user_to_slice_.push_back(s);
     nb_rbs_ = nb_rbs - (nb_rbs % rbg_size); /* :460 */
     nb_rbgs_ = nb_rbs_ / rbg_size;
-    bearers_.resize(user_to_slice_.size());
+    bearers_.resize(user_to_slice_.size() * (size_t)kMaxBearers);
+    for (size_t u = 0; u < user_to_slice_.size(); ++u) {
+      bearers_[u * kMaxBearers].exists = true;
+      bearers_[u * kMaxBearers].application_id = (int)u;
+    }
+    slice_priority_.assign(num_slices_, 0);
     cqi_.assign(user_to_slice_.size() * (size_t)nb_rbgs_, 10); /* ENodeB.cpp:212-217 */
     slice_ewma_time_.assign(num_slices_, 0.0);
     rs_config c{};
@@ -98,7 +110,18 @@ class GpuDownlinkScheduler {
     for (int k = 0; k < nb_rbs_; ++k) cqi_prb_[(size_t)user_id * nb_rbs_ + k] = (uint8_t)cqi_per_prb[k];
     for (int r = 0; r < nb_rbgs_; ++r) cqi_[(size_t)user_id * nb_rbgs_ + r] = (uint8_t)cqi_per_prb[r * rbg_size_];
   }
-  BearerState& Bearer(int user_id) { return bearers_[user_id]; }
+  BearerState& Bearer(int user_id, int priority = 0) { return bearers_[(size_t)user_id * kMaxBearers + priority]; }
+  /* a further RadioBearer of the user (single-cell-with-interference.h:413-440 gives every UE one InternetFlow per
+   * configured priority next to its best-effort flow); priority = RadioBearer::GetPriority() in 0..kMaxBearers-1 */
+  BearerState& AddBearer(int user_id, int priority, int application_id) {
+    if (priority < 0 || priority >= kMaxBearers) throw std::runtime_error("bearer priority outside 0..MAX_BEARERS-1");
+    BearerState& b = Bearer(user_id, priority);
+    b.exists = true;
+    b.application_id = application_id;
+    multi_bearer_ = true;
+    return b;
+  }
+  const std::vector<int>& SlicePriority() const { return slice_priority_; }
   unsigned long GetTimeStamp() const { return ts_; }
   const std::vector<Allocation>& LastAllocations() const { return allocations_; }
   const std::vector<int>& SliceTargetRbs() const { return target_; }
@@ -119,7 +142,7 @@ class GpuDownlinkScheduler {
   /* radio-bearer.cpp:139-164 for every bearer (downlink-transport-scheduler.cpp:715-727) */
   void UpdateAverageTransmissionRate(double now) {
     for (BearerState& b : bearers_) {
-      if (now == b.last_update) continue;
+      if (!b.exists || now == b.last_update) continue;
       double rate = (b.transmitted_bytes * 8) / (now - b.last_update);
       double beta = 0.02;
       b.average_transmission_rate = ((1 - beta) * b.average_transmission_rate) + (beta * rate);
@@ -132,8 +155,8 @@ class GpuDownlinkScheduler {
   /* downlink-nvs-scheduler.cpp:94-142 */
   int SelectSliceToServe() {
     std::vector<bool> with_queue(num_slices_, false);
-    for (size_t u = 0; u < bearers_.size(); ++u)
-      if (bearers_[u].has_packets) with_queue[user_to_slice_[u]] = true;
+    for (size_t k = 0; k < bearers_.size(); ++k)
+      if (bearers_[k].exists && bearers_[k].has_packets) with_queue[user_to_slice_[k / kMaxBearers]] = true;
     int slice_id = 0;
     double max_score = 0;
     for (int i = 0; i < num_slices_; ++i) {
@@ -151,13 +174,28 @@ class GpuDownlinkScheduler {
     return slice_id;
   }
 
-  /* downlink-transport-scheduler.cpp:105-150: users with queued data, first-seen (= id) order */
+  /* downlink-transport-scheduler.cpp:105-150 (downlink-nvs-scheduler.cpp:144-194 with the slice filter) +
+   * PacketScheduler::InsertFlowToUser (packet-scheduler.cpp:305-335): bearers in container order (user, then priority);
+   * a bearer with packets enters its user's record at index = priority with dataToTransmit = queue size (100000000 for
+   * an InfiniteBuffer) and raises its slice's priority; users in first-seen (= id) order */
   void SelectFlowsToSchedule(int slice_serve = -1) {
     users_.clear();
-    for (size_t u = 0; u < bearers_.size(); ++u) {
-      if (!bearers_[u].has_packets) continue;
+    data_.clear();
+    slice_priority_.assign(num_slices_, 0);
+    for (size_t u = 0; u < user_to_slice_.size(); ++u) {
       if (slice_serve >= 0 && user_to_slice_[u] != slice_serve) continue;
-      users_.push_back((int)u);
+      bool seen = false;
+      for (int pr = 0; pr < kMaxBearers; ++pr) {
+        const BearerState& b = bearers_[u * kMaxBearers + pr];
+        if (!b.exists || !b.has_packets) continue;
+        if (pr > slice_priority_[user_to_slice_[u]]) slice_priority_[user_to_slice_[u]] = pr;
+        if (!seen) {
+          users_.push_back((int)u);
+          data_.insert(data_.end(), kMaxBearers, -1); /* -1: m_bearers[pr] == NULL */
+          seen = true;
+        }
+        data_[data_.size() - kMaxBearers + pr] = b.queue_size < 0 ? 100000000 : b.queue_size;
+      }
     }
   }
 
@@ -170,7 +208,18 @@ class GpuDownlinkScheduler {
     for (int i = 0; i < n; ++i) {
       const int u = users_[i];
       for (int r = 0; r < nb_rbgs_; ++r) in_cqi_[(size_t)i * nb_rbgs_ + r] = cqi_[(size_t)u * nb_rbgs_ + r];
-      in_avg_[i] = bearers_[u].average_transmission_rate;
+      /* ComputeSchedulingMetric :681-686: averageRate = 1; for every bearer in the record: averageRate += its average.
+       * The C ABI adds 1 to one number, so two bearers go in as ((1 + a0) + a1) - 1: a0, a1 >= 1, so the sum K is at least
+       * 2, K - 1 is exact in binary64 and 1 + (K - 1) == K -- the reference's summation order, bit for bit. */
+      double k = 1;
+      int n_present = 0;
+      for (int pr = 0; pr < kMaxBearers; ++pr)
+        if (data_[(size_t)i * kMaxBearers + pr] >= 0) {
+          k += bearers_[(size_t)u * kMaxBearers + pr].average_transmission_rate;
+          ++n_present;
+        }
+      in_avg_[i] = n_present == 1 ? bearers_[(size_t)u * kMaxBearers + (data_[(size_t)i * kMaxBearers] >= 0 ? 0 : 1)].average_transmission_rate
+                                  : k - 1;
     }
     if (!cqi_prb_.empty()) {
       in_prb_.resize((size_t)n * nb_rbs_);
@@ -186,8 +235,12 @@ class GpuDownlinkScheduler {
     in_hol_.resize(n);
     in_prio_.resize(n);
     for (int i = 0; i < n; ++i) {
-      in_hol_[i] = bearers_[users_[i]].hol_delay;
-      in_prio_[i] = bearers_[users_[i]].prio_has_data ? 1 : 0;
+      /* :694-711: the metric of a customised slice looks at the record's entry of the slice priority */
+      const int u = users_[i], sp = slice_priority_[user_to_slice_[u]];
+      const BearerState& b = bearers_[(size_t)u * kMaxBearers + sp];
+      in_hol_[i] = b.hol_delay;
+      const int dtt = data_[(size_t)i * kMaxBearers + sp]; /* m_dataToTransmit[slice_priority_[slice]] (0 when absent) */
+      in_prio_[i] = multi_bearer_ ? (dtt > 0 ? 1 : 0) : (b.prio_has_data ? 1 : 0);
     }
     in.hol_delay = in_hol_.data();
     in.prio_has_data = in_prio_.data();
@@ -260,24 +313,33 @@ class GpuDownlinkScheduler {
     }
   }
 
-  /* downlink-transport-scheduler.cpp:170-221 (one InfiniteBuffer bearer per user: dataToTransmit = 1e8) */
+  /* downlink-transport-scheduler.cpp:170-221 / downlink-nvs-scheduler.cpp:218-272: the granted bytes go to the user's
+   * bearers from the highest priority down, each at most its dataToTransmit; every bearer that sends counts the user's
+   * whole PRB list.  (The PF scheduler of sched 1 works per flow: one bearer per user there.) */
   void DoStopSchedule() {
+    size_t i = 0;
     for (const Allocation& a : allocations_) {
+      while (users_[i] != a.user_id) ++i; /* allocations_ follows users_ */
       int available = a.tbs_bits / 8;
-      if (available <= 0) continue;
-      int sent = available < 100000000 ? available : 100000000;
-      BearerState& b = bearers_[a.user_id];
-      b.transmitted_bytes += sent;
-      b.cumulative_bytes += sent;
-      b.cumulative_rbs += a.n_prbs;
-      if (log_err_) {
-        /* downlink-transport-scheduler.cpp:192-199, downlink-nvs-scheduler.cpp:240-247 ("app:", with user and slice);
-         * downlink-packet-scheduler.cpp:140-145 ("flow:", without).  One bearer per user: application id == user id. */
-        std::ostream& es = *log_err_;
-        es << ts_ << (sched_ == RS_SCHED_PF ? " flow: " : " app: ") << a.user_id << " cumu_bytes: " << b.cumulative_bytes
-           << " cumu_rbs: " << b.cumulative_rbs << " hol_delay: " << b.hol_delay;
-        if (sched_ != RS_SCHED_PF) es << " user: " << a.user_id << " slice: " << user_to_slice_[a.user_id];
-        es << std::endl;
+      for (int pr = kMaxBearers - 1; pr >= 0; --pr) {
+        if (available <= 0) break;
+        const int dtt = data_[i * kMaxBearers + pr];
+        if (dtt <= 0) continue;
+        const int sent = available < dtt ? available : dtt;
+        available -= sent;
+        BearerState& b = bearers_[(size_t)a.user_id * kMaxBearers + pr];
+        b.transmitted_bytes += sent;
+        b.cumulative_bytes += sent;
+        b.cumulative_rbs += a.n_prbs;
+        if (log_err_) {
+          /* downlink-transport-scheduler.cpp:192-199, downlink-nvs-scheduler.cpp:240-247 ("app:", with user and slice);
+           * downlink-packet-scheduler.cpp:140-145 ("flow:", without) */
+          std::ostream& es = *log_err_;
+          es << ts_ << (sched_ == RS_SCHED_PF ? " flow: " : " app: ") << b.application_id << " cumu_bytes: "
+             << b.cumulative_bytes << " cumu_rbs: " << b.cumulative_rbs << " hol_delay: " << b.hol_delay;
+          if (sched_ != RS_SCHED_PF) es << " user: " << a.user_id << " slice: " << user_to_slice_[a.user_id];
+          es << std::endl;
+        }
       }
     }
     ts_++;
@@ -293,12 +355,15 @@ class GpuDownlinkScheduler {
   std::vector<double> weight_;
   std::vector<int> alpha_, beta_, eps_, psi_, user_to_slice_;
   std::vector<double> slice_ewma_time_;
-  std::vector<BearerState> bearers_;
+  std::vector<BearerState> bearers_; /* [user][priority] */
   std::vector<uint8_t> cqi_, in_cqi_, cqi_prb_, in_prb_;
   std::vector<double> in_avg_, in_hol_;
   std::vector<uint8_t> in_prio_;
   std::vector<int> in_draws_, upper_rbg_, upper_user_;
   std::vector<int> users_, target_, quota_, rbg_to_user_, nprb_, fcqi_, mcs_, tbs_;
+  std::vector<int> data_;           /* [users_][kMaxBearers] m_dataToTransmit of the record, -1: no such bearer this TTI */
+  std::vector<int> slice_priority_; /* slice_priority_ (downlink-transport-scheduler.h:40) */
+  bool multi_bearer_ = false;
   std::vector<Allocation> allocations_;
   unsigned long ts_ = 0;
   std::ostream *log_out_ = nullptr, *log_err_ = nullptr;

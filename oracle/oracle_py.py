@@ -80,6 +80,7 @@ def lib():
         L.rso_cell_set_queue_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint8)]
         L.rso_cell_set_last_update.argtypes = [C.c_void_p, C.c_double]
         L.rso_cell_set_avg_rate.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.rso_cell_set_second_bearer_avg.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.rso_cell_step.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(_TtiOut)]
         L.rso_cell_allocate.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(_TtiOut)]
         L.rso_cell_allocate_nongreedy.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.c_int,
@@ -219,6 +220,15 @@ class Cell:
         q = np.ascontiguousarray(prio_has_data, np.uint8)
         assert h.shape == (self.U,) and q.shape == (self.U,)
         lib().rso_cell_set_queue_state(self.h, _p(h, C.c_double), _p(q, C.c_uint8))
+
+    def set_second_bearer_avg(self, avg2):
+        """avg2[u] >= 0: user u holds a second bearer with that average rate this TTI; None clears."""
+        if avg2 is None:
+            lib().rso_cell_set_second_bearer_avg(self.h, None)
+            return
+        a = np.ascontiguousarray(avg2, np.float64)
+        assert a.shape == (self.U,)
+        lib().rso_cell_set_second_bearer_avg(self.h, _p(a, C.c_double))
 
     def set_avg_rate(self, avg):
         a = np.ascontiguousarray(avg, np.float64)

@@ -280,6 +280,7 @@ struct rso_cell {
   std::vector<uint8_t> cqi_prb; /* [U][R*G] per-PRB CQI when given (EESM/TBS read every PRB), else empty */
   std::vector<double> hol;      /* [U] GetHeadOfLinePacketDelay() of the slice-priority bearer (alpha != 0 slices) */
   std::vector<uint8_t> prio_has_data; /* [U] m_dataToTransmit[slice_priority_[slice]] != 0 */
+  std::vector<double> avg2;     /* [U] average rate of the user's second bearer (MAX_BEARERS = 2), < 0: none */
   double eff_of_cqi[16];
 };
 
@@ -332,6 +333,9 @@ void rso_cell_set_queue_state(rso_cell* c, const double* hol, const uint8_t* pri
   c->prio_has_data.assign(prio_has_data, prio_has_data + c->U);
 }
 void rso_cell_set_avg_rate(rso_cell* c, const double* a) { c->avg.assign(a, a + c->U); }
+void rso_cell_set_second_bearer_avg(rso_cell* c, const double* a2) {
+  if (a2) c->avg2.assign(a2, a2 + c->U); else c->avg2.clear();
+}
 
 void rso_cell_get_state(const rso_cell* c, double* avg, int64_t* cum_bytes, int64_t* cum_rbs,
                         double* slice_state) {
@@ -365,10 +369,12 @@ void update_average_rate(rso_cell* c, double now) {
 }
 
 /* ref: downlink-transport-scheduler.cpp:677-713 and downlink-nvs-scheduler.cpp:360-390 (the NVS variant
- * always multiplies the head-of-line delay when alpha != 0).  One bearer per user feeds the average. */
+ * always multiplies the head-of-line delay when alpha != 0).  `averageRate = 1; for each bearer of the user:
+ * averageRate += its average` (:681-686), i.e. (1 + a) + a2 with two bearers. */
 double slice_metric(const rso_cell* c, int slice, double se, double avg_rate, int user = -1) {
   double average = 1;
   average += avg_rate;
+  if (user >= 0 && !c->avg2.empty() && c->avg2[user] >= 0) average += c->avg2[user];
   se = se * 180000 / 1000;
   average /= 1000.0;
   if (c->alpha[slice] == 0) return pow(se, c->eps[slice]) / pow(average, c->psi[slice]);
