@@ -92,14 +92,27 @@ def cpu_baseline(args, slices, seeds):
     wall = cores * n_ttis / rate
     return {"value": cores * n_ttis / wall, "unit": "TTIs/s", "cores": cores, "kind": "port",
             "sample": f"{cores} independent cells x {n_ttis} TTIs of the same workload, one oracle thread each "
-                      f"(thread count = where throughput stopped scaling, os.cpu_count()={os.cpu_count()}); "
+                      f"(thread count = where throughput stopped scaling, os.cpu_count()={os.cpu_count()}, "
+                      f"{_cpu_model()}); "
                       f"single core: {per_core:.0f} TTIs/s"}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=25,
+                    help="timed launches; the default measures 10 000 TTIs per cell (SURVEY 8d)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cells", type=int, default=512, help="independent cells per GPU")
     ap.add_argument("--ttis", type=int, default=400, help="TTIs per step (per launch)")
