@@ -41,6 +41,7 @@
 #include "rs_sort_emul.h"
 #include "rs_wave.h"
 #include "rs_sort_device.h"
+#include "rs_interslice.h"
 
 namespace {
 
@@ -800,218 +801,18 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       __builtin_amdgcn_s_setprio(3);
       int owner = -1;
       int got = 0; /* lane s: RBGs granted to slice s */
-      if (SCHED == 8) {
-        /* GreedyByRow, ref: :249-272 -- RBG ascending, argmax eff over slices under quota, first max
-         * wins.  eff is strictly increasing in CQI (0 for an empty slice), so integer keys compare alike. */
-        const int quota = lane < S ? m->quota[lane] : 0;
-        int my_slice = -1;
-        /* the next RBG's keys are loaded while this one is decided */
-        const uint32_t* colp = s_elems + (lane < S ? lane : 0);
-        uint32_t e_next = colp[0];
-        for (int r = 0; r < R; ++r) {
-          const int key = (int)(e_next >> 16);
-          e_next = colp[(r + 1 < R ? r + 1 : r) * S];
-          const bool ok = lane < S && got < quota;
-          const int packed = ok ? (key << 6) | (63 - lane) : -1;
-          const int bestp = wave_max(packed);
-          const int sl = bestp < 0 ? -1 : 63 - (bestp & 63);
-          if (lane == sl) got++;
-          if (lane == r) my_slice = sl;
-        }
-        if (lane < R && my_slice >= 0) {
-          int u = s_best_user[my_slice * R + lane];
-          owner = u == 0xFFFF ? -1 : u;
-        }
-      } else if (SCHED == 9) {
-        /* MaximizeCell greedy scan, ref: :362-369: sorted records in order, take the RBG if it is
-         * free and the slice is under quota */
-        const int N = R * S;
-        int left = lane < S ? m->quota[lane] : 0; /* lane s: quota[s] - granted[s] */
-        int my_slice = -1;                        /* lane r: slice that got RBG r */
-        int assigned = 0;
+      if constexpr (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103) {
+        /* DownlinkTransportScheduler's inter-slice policies (rs_interslice.h): lane r learns the slice of RBG r */
+        int my_slice;
+        if constexpr (SCHED == 8) my_slice = interslice_greedy_by_row(s_elems, m, S, R, got);
+        else if constexpr (SCHED == 101) my_slice = interslice_subopt(s_elems, m, (uint8_t*)(lds + o.sortx), S, R, got);
+        else if constexpr (SCHED == 103) my_slice = interslice_vogel(s_elems, m, S, R, got);
+        else {
 #ifdef RS_STAMPS
-        int scan_end = 0; /* diagnostic: how deep the scan went */
+          my_slice = interslice_maximize_cell(s_sorted, m, S, R, got, stamp_acc);
+#else
+          my_slice = interslice_maximize_cell(s_sorted, m, S, R, got);
 #endif
-        for (int c0 = 0; c0 < N && assigned < R; c0 += 64) {
-          const int i = c0 + lane;
-          const uint32_t e = i < N ? s_sorted[i] : 0;
-          const int rbg = (e >> 8) & 63, sl = e & 63;
-          /* records of this chunk that can still be taken: RBG free and slice under quota */
-          /* (the two lane reads stay outside any branch: ds_bpermute returns 0 for a masked-off source lane) */
-          const int rbg_owner = __shfl(my_slice, rbg, 64), sl_left = __shfl(left, sl, 64);
-          unsigned long long live = __ballot((i < N) & (rbg_owner < 0) & (sl_left > 0));
-          while (live) {
-            const int f = __ffsll((long long)live) - 1;
-            const int frbg = __builtin_amdgcn_readlane(rbg, f);
-            const int fsl = __builtin_amdgcn_readlane(sl, f);
-            const int sleft = __builtin_amdgcn_readlane(left, fsl);
-            live &= ~__ballot(rbg == frbg); /* the RBG is gone (this drops record f too) */
-            if (sleft == 1) live &= ~__ballot(sl == fsl); /* the slice just used its last RBG */
-            if (lane == fsl) left--;
-            if (lane == frbg) my_slice = fsl;
-            assigned++;
-#ifdef RS_STAMPS
-            scan_end = c0 + f;
-#endif
-          }
-        }
-#ifdef RS_STAMPS
-        if (tid == 0) { /* how deep the greedy scan went: last sorted position it looked at */
-          stamp_acc[9] += (unsigned long long)assigned;
-          stamp_acc[10] += (unsigned long long)scan_end;
-        }
-#endif
-        if (lane < S) got = m->quota[lane] - left;
-        if (lane < R && my_slice >= 0) {
-          int u = s_best_user[my_slice * R + lane];
-          owner = u == 0xFFFF ? -1 : u;
-        }
-      } else if (SCHED == 103) {
-        /* VogelApproximate, ref: downlink-transport-scheduler.cpp:378-451.  R rounds; in each one every free RBG (lanes = RBGs)
-         * looks for its best and "second" slice among the slices under quota, every such slice (lanes = slices) for its best and
-         * "second" free RBG, and the candidate with the largest difference gets assigned.  Three details of the reference are
-         * kept: (1) a new best does not demote the old best to second -- second is the largest value that was not a new best
-         * when it was met; (2) `max_diff` is an int: a candidate wins when its (double) difference exceeds the TRUNCATED
-         * running maximum, so the LAST candidate above the running truncated maximum wins, horizontal candidates (RBG
-         * ascending) before vertical ones (slice ascending); (3) comparisons are on efficiencies, which are strictly
-         * increasing in the CQI key (0 = no user), so keys are compared and only the differences use the doubles. */
-        const int quota = lane < S ? m->quota[lane] : 0;
-        int my_slice = -1; /* lane r: slice that got RBG r */
-        for (int round = 0; round < R; ++round) {
-          const unsigned long long elig = __ballot(lane < S && got < quota);
-          const unsigned long long freeb = __ballot(lane < R && my_slice < 0);
-          /* horizontal search: lane j = free RBG j, slices ascending (four LDS reads in flight per step) */
-          int h1 = -1, h2 = -1, hs = -1;
-          {
-            const uint32_t* row = s_elems + (lane < R ? lane : 0) * S;
-            for (int k0 = 0; k0 < S; k0 += 4) {
-              uint32_t e4[4];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) e4[q] = row[k0 + q < S ? k0 + q : S - 1];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int k = k0 + q;
-                if (k < S && ((elig >> k) & 1ull)) {
-                  const int key = (int)(e4[q] >> 16);
-                  if (h1 < 0 || key > h1) { hs = k; h1 = key; }
-                  else if (h2 < 0 || key > h2) h2 = key;
-                }
-              }
-            }
-          }
-          /* vertical search: lane k = slice k under quota, free RBGs ascending */
-          int v1 = -1, v2 = -1, vr = -1;
-          {
-            const uint32_t* col = s_elems + (lane < S ? lane : 0);
-            for (int j0 = 0; j0 < R; j0 += 4) {
-              uint32_t e4[4];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) e4[q] = col[(j0 + q < R ? j0 + q : R - 1) * S];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int j = j0 + q;
-                if (j < R && ((freeb >> j) & 1ull)) {
-                  const int key = (int)(e4[q] >> 16);
-                  if (v1 < 0 || key > v1) { vr = j; v1 = key; }
-                  else if (v2 < 0 || key > v2) v2 = key;
-                }
-              }
-            }
-          }
-          const bool hpart = (freeb >> lane) & 1ull, vpart = (elig >> lane) & 1ull;
-          const double hd = (h1 < 0 ? -1.0 : m->eff16[h1]) - (h2 < 0 ? -1.0 : m->eff16[h2]);
-          const double vd = (v1 < 0 ? -1.0 : m->eff16[v1]) - (v2 < 0 ? -1.0 : m->eff16[v2]);
-          /* running truncated maximum before each candidate (-1 at the start), candidates in the reference's order */
-          const int ht = hpart ? (int)hd : -1, vt = vpart ? (int)vd : -1;
-          const int hinc = wave_scan_max_incl(ht);
-          int hexc = __shfl_up(hinc, 1, 64);
-          if (lane == 0) hexc = -1;
-          const int hall = __builtin_amdgcn_readlane(hinc, 63);
-          const int vinc = wave_scan_max_incl(vt);
-          int vexc = __shfl_up(vinc, 1, 64);
-          if (lane == 0) vexc = -1;
-          if (vexc < hall) vexc = hall;
-          if (hexc < -1) hexc = -1;
-          if (vexc < -1) vexc = -1;
-          const unsigned long long hacc = __ballot(hpart && hd > (double)hexc);
-          const unsigned long long vacc = __ballot(vpart && vd > (double)vexc);
-          int pick_rbg = -1, pick_slice = -1;
-          if (vacc) {
-            const int k = 63 - __clzll((long long)vacc);
-            pick_slice = k;
-            pick_rbg = __builtin_amdgcn_readlane(vr, k);
-          } else if (hacc) {
-            const int j = 63 - __clzll((long long)hacc);
-            pick_rbg = j;
-            pick_slice = __builtin_amdgcn_readlane(hs, j);
-          }
-          if (pick_rbg < 0 || pick_slice < 0) break; /* reference: uninitialised coordinates (undefined behaviour) */
-          if (lane == pick_rbg) my_slice = pick_slice;
-          if (lane == pick_slice) got++;
-        }
-        if (lane < R && my_slice >= 0) {
-          int u = s_best_user[my_slice * R + lane];
-          owner = u == 0xFFFF ? -1 : u;
-        }
-      } else if (SCHED == 101) {
-        /* SubOpt, ref: downlink-transport-scheduler.cpp:274-349.  Every RBG (lanes = RBGs) starts at its best slice (first
-         * maximum); then one RBG per round moves from a slice above its quota to a slice below it -- the move with the
-         * smallest efficiency loss, first in (RBG ascending, `slice_fewer` iteration order) among equal losses.  That order
-         * is libstdc++'s unordered_map order after the ascending insertions (erasures keep it): lane 0 computes it once per
-         * TTI (rs_umap_order), lane p then holds the p-th key.  Counters live in lanes = slices; negative quotas count as 0. */
-        int my_slice = -1;
-        const uint32_t* row = s_elems + (lane < R ? lane : 0) * S;
-        {
-          int bestk = -1;
-          for (int k = 0; k < S; ++k) {
-            const int key = (int)(row[k] >> 16);
-            if (key > bestk) { bestk = key; my_slice = k; }
-          }
-          if (lane >= R) my_slice = -1;
-        }
-        for (int sl = 0; sl < S; ++sl) {
-          const int cnt = __popcll(__ballot(my_slice == sl));
-          if (lane == sl) got = cnt;
-        }
-        int quota = lane < S ? m->quota[lane] : 0;
-        quota = quota < 0 ? 0 : quota;
-        int more = (lane < S && got > quota) ? got - quota : 0;
-        int fewer = (lane < S && got < quota) ? quota - got : 0;
-        unsigned long long more_mask = __ballot(more > 0), fewer_mask = __ballot(fewer > 0);
-        uint8_t* um = (uint8_t*)(lds + o.sortx);
-        int n_ord = 0;
-        if (lane == 0 && more_mask && fewer_mask) n_ord = rs_umap_order(fewer_mask, um, um + 68, um + 196);
-        n_ord = __builtin_amdgcn_readfirstlane(n_ord);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int ordv = lane < n_ord ? um[196 + lane] : 0;
-        while (more_mask && fewer_mask) {
-          const bool cand = my_slice >= 0 && ((more_mask >> my_slice) & 1ull);
-          const double own_eff = m->eff16[row[my_slice >= 0 ? my_slice : 0] >> 16];
-          double least = 1.7976931348623157e308;
-          int to_sl = -1;
-          for (int q = 0; q < n_ord; ++q) {
-            const int key = __builtin_amdgcn_readlane(ordv, q);
-            if (!((fewer_mask >> key) & 1ull)) continue;
-            const double loss = own_eff - m->eff16[row[key] >> 16];
-            if (loss < least) { least = loss; to_sl = key; }
-          }
-          /* smallest loss over the candidate RBGs, lowest RBG among equals: losses are >= 0, their bit patterns order
-           * like the values */
-          const long long lb = __double_as_longlong(least);
-          const int hi = cand ? (int)(lb >> 32) : 0x7fffffff;
-          const int hmin = wave_min(hi);
-          const int lo = (cand && hi == hmin) ? (int)((uint32_t)lb ^ 0x80000000u) : 0x7fffffff;
-          const int lmin = wave_min(lo);
-          const unsigned long long hit = __ballot(cand && hi == hmin && lo == lmin);
-          if (!hit) break; /* reference asserts */
-          const int rbg = __ffsll((long long)hit) - 1;
-          const int from = __builtin_amdgcn_readlane(my_slice, rbg), to = __builtin_amdgcn_readlane(to_sl, rbg);
-          if (lane == rbg) my_slice = to;
-          if (lane == from) { got--; more--; }
-          if (lane == to) { got++; fewer--; }
-          more_mask = __ballot(more > 0 && got > 0);
-          fewer_mask = __ballot(fewer > 0);
         }
         if (lane < R && my_slice >= 0) {
           int u = s_best_user[my_slice * R + lane];
