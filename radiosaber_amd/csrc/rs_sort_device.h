@@ -147,6 +147,9 @@ __device__ void introsort_loop_levels(uint32_t* v, int N, uint16_t* posA, uint16
  * 64-position chunk per i).  Every lane of a sub-range reads the three median samples itself, so
  * the pivot is known without a publishing step; three workgroup barriers per level.
  */
+#ifndef RS_WAVE_FINISH_MAX
+#define RS_WAVE_FINISH_MAX 4 /* sub-ranges per wave at which the last levels go to single waves */
+#endif
 __device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
   /* bits [lo, hi) of a 64-bit mask, 0 <= lo, hi <= 64 */
   if (hi <= lo) return 0ull;
@@ -182,6 +185,78 @@ __device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
  * meet, a + b <= len - 3); the cut is an LDS atomicMin per sub-range (slot f>>4: live sub-ranges are longer
  * than 16, so their slots differ).  Counts come from per-chunk ballots + one prefix scan per wave.
  */
+/*
+ * One wave finishes sub-ranges of at most 64 elements on its own, several at a time when they fit side by side in its 64
+ * lanes (lane j holds position fb + j - lb of the sub-range that starts at lane lb and position fb): the same level step as
+ * below -- median of three to the front, stop ballots, swap decision from the two stop counts, exchange through `xbuf`, cut =
+ * leftmost candidate -- but the pivot candidates come from the other lanes' registers (ds_bpermute), the counts from one
+ * ballot pair, and no workgroup barrier is involved: the pieces go down level by level inside the wave until all are at most
+ * 16 long.  `l0` = end of my sub-range (0: lane unused), `depth` = introsort's remaining depth at entry (heap-sort fallback
+ * when it runs out).  Used for the last, sparsely populated levels: at 500 records they hold 9 / 4 / 2 / 1 sub-ranges of
+ * 20-30 elements on average.
+ */
+__device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* xbuf, int fb, int lb, int l0, int depth) {
+  const int lane = lane_id();
+  const bool mine = l0 != 0;
+  const int x = fb + lane - lb, shift = lb - fb; /* lane = position + shift */
+  const unsigned long long le_lane = ~0ull >> (63 - lane);
+  uint32_t e = mine ? v[x] : 0u;
+  int F = fb, L = l0; /* my piece; L == 0: retired */
+  while (__ballot(L != 0) != 0ull) {
+    const bool active = L != 0;
+    if (depth == 0) { /* std::__partial_sort fallback */
+      if (mine) v[x] = e;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (active && x == F) {
+        LdsArr a{v};
+        rs_sort::heap_sort(a, F, L);
+      }
+      return;
+    }
+    /* piece bounds in lane space; every lane takes part in the four register reads (a masked-off source lane would
+     * read as 0) */
+    const int pf = active ? F + shift : 0, pl = active ? L + shift : 2;
+    const int ja = pf + 1, jb = pf + (pl - pf) / 2, jc = pl - 1;
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_bpermute(pf << 2, (int)e);
+    const uint32_t sa = (uint32_t)__builtin_amdgcn_ds_bpermute(ja << 2, (int)e);
+    const uint32_t sb = (uint32_t)__builtin_amdgcn_ds_bpermute(jb << 2, (int)e);
+    const uint32_t sc = (uint32_t)__builtin_amdgcn_ds_bpermute(jc << 2, (int)e);
+    int pick;
+    uint32_t sp;
+    if (rs_sort::before(sa, sb)) {
+      if (rs_sort::before(sb, sc)) { pick = jb; sp = sb; }
+      else if (rs_sort::before(sa, sc)) { pick = jc; sp = sc; }
+      else { pick = ja; sp = sa; }
+    } else if (rs_sort::before(sa, sc)) { pick = ja; sp = sa; }
+    else if (rs_sort::before(sb, sc)) { pick = jc; sp = sc; }
+    else { pick = jb; sp = sb; }
+    if (active) {
+      if (lane == pf) e = sp;
+      else if (lane == pick) e = s0;
+    }
+    const int pk = (int)(sp >> 16), k = (int)(e >> 16);
+    const bool in = active && lane > pf;
+    const bool isA = in && k <= pk, isB = in && k >= pk;
+    const unsigned long long mA = __ballot(isA), mB = __ballot(isB);
+    /* A-stops of my piece left of me, B-stops of my piece right of me */
+    const int a = __popcll(mA & bit_range(ja, lane));
+    const int b = __popcll(mB & bit_range(ja, pl) & ~le_lane);
+    const bool swA = isA & (b > a), swB = isB & (a > b);
+    const int slot = swA ? F + a : L - 1 - b;
+    if (swA | swB) xbuf[slot] = e;
+    const unsigned long long mC = __ballot((isA & !swA) | swB) & bit_range(ja, pl);
+    if (swA | swB) e = xbuf[F + L - 1 - slot];
+    if (active) {
+      const int cut = __ffsll((long long)mC) - 1 - shift;
+      if (x < cut) L = cut; else F = cut;
+      if (L - F <= 16) L = 0;
+    }
+    --depth;
+  }
+  if (mine) v[x] = e;
+}
+
 template <int EPT>
 __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t* cuts, Misc* m,
                                      unsigned long long* sub, int seg_len = 0) {
@@ -207,10 +282,49 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     }
   }
   const int n_first = seg_len == 0 ? N : seg_len; /* length every std::sort call starts from */
-  if (tid < 48) m->n_level[tid] = (tid == 0 && n_first > 16) ? 1 : 0;
+  /* n_level[k]: sub-ranges alive at level k, plus 65536 for each one longer than 64 */
+  const int n_calls = seg_len == 0 ? 1 : idiv_small(N, seg_len);
+  if (tid < 48) m->n_level[tid] = (tid == 0 && n_first > 16) ? n_calls + (n_first > 64 ? n_calls << 16 : 0) : 0;
+  if (tid == 0) m->pad[0] = 0; /* entries in the list of sub-ranges handed to single waves */
   int depth = 2 * rs_sort::floor_log2(n_first > 1 ? n_first : 1);
   __syncthreads();
   for (int level = 0; level < 47; ++level, --depth) {
+    const int n_alive = m->n_level[level]; /* complete: the previous level ended with a barrier */
+    if (n_alive == 0) break;
+    if (depth != 0 && n_alive <= RS_WAVE_FINISH_MAX * nwaves) {
+      /* few sub-ranges left, none longer than 64: their first positions publish them, every wave takes its share and
+       * finishes them alone (finish_subranges_on_wave) */
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int x = i * nt + tid;
+        const bool leader = L[i] != 0 && x == F[i];
+        const unsigned long long mL = __ballot(leader);
+        if (mL != 0ull) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&m->pad[0], __popcll(mL));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (leader) cuts[base + __popcll(mL & lt_lane)] = F[i] | (L[i] << 16);
+        }
+      }
+      __syncthreads();
+      /* my share: entries wave, wave + nwaves, ... (lane t fetches the t-th of them), packed side by side while they fit */
+      const int n_mine = n_alive > wave ? (n_alive - wave + nwaves - 1) / nwaves : 0;
+      const int my_ent = lane < n_mine ? cuts[wave + lane * nwaves] : 0;
+      for (int t = 0; t < n_mine;) {
+        int fb = 0, lb = 0, l0 = 0, used = 0;
+        do {
+          const int ent = __builtin_amdgcn_readlane(my_ent, t);
+          const int f = ent & 0xffff, l = ent >> 16;
+          if (used + (l - f) > 64) break;
+          if (lane >= used && lane < used + (l - f)) { fb = f; lb = used; l0 = l; }
+          used += l - f;
+          ++t;
+        } while (t < n_mine);
+        finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth);
+      }
+      __syncthreads();
+      break;
+    }
     if (depth == 0) {
       /* std::__partial_sort fallback for every sub-range still longer than 16 */
 #pragma unroll
@@ -267,7 +381,6 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     RS_SUBSTAMP(0);
     __syncthreads();
     RS_SUBSTAMP(1);
-    if (m->n_level[level] == 0) break;
     /* R: stop counts -> swap decision; swapped elements to the exchange buffer, cut candidates to the slot */
     int pre; /* lane c: stops in chunks < c, A-stops in the low half, B-stops in the high half */
     {
@@ -303,7 +416,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     __syncthreads();
     RS_SUBSTAMP(3);
     /* S: receive the swapped element, then move to the child sub-range; sub-ranges of at most 16 retire */
-    bool any = false;
+    int alive = 0; /* wave-uniform: sub-ranges of the next level that start in my chunks (+ 65536 per one longer than 64) */
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       const int x = i * nt + tid;
@@ -316,10 +429,11 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
         }
         if (x < cut) L[i] = cut; else F[i] = cut;
         if (L[i] - F[i] <= 16) L[i] = 0;
-        any |= L[i] != 0;
       }
+      const bool leader = L[i] != 0 && x == F[i];
+      alive += __popcll(__ballot(leader)) + (__popcll(__ballot(leader && L[i] - F[i] > 64)) << 16);
     }
-    if (__ballot(any) && lane == 0) atomicAdd(&m->n_level[level + 1], 1);
+    if (alive != 0 && lane == 0) atomicAdd(&m->n_level[level + 1], alive);
     RS_SUBSTAMP(4);
     __syncthreads();
     RS_SUBSTAMP(5);
