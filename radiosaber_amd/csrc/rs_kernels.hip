@@ -211,13 +211,21 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   unsigned long long* sort_sub = sort_sub_store;
   unsigned long long stamp_prev = __builtin_readcyclecounter();
 #endif
+  /* position inside the CQI epoch and the epoch's index, kept as counters: a 64-bit modulo per TTI costs more than the
+   * quota phase */
+  long long epoch = 0;
+  int epoch_pos = 0;
+  if (!kDirect && p.cqi_mode == RS_CQI_EPOCHS) {
+    epoch = n_done / p.refresh;
+    epoch_pos = (int)(n_done - epoch * p.refresh);
+  }
   for (int tti = 0; tti < p.n_ttis; ++tti) {
     RS_STAMP(11);
     /* ---------------- P0: CQI refresh ---------------- */
     if (p.cqi_mode == RS_CQI_EPOCHS) {
       /* a launch that starts inside an epoch loads that epoch's grid first: LDS does not survive between launches */
-      if (kDirect || tti == 0 || n_done % p.refresh == 0) {
-        long long e = kDirect ? 0 : n_done / p.refresh;
+      if (kDirect || tti == 0 || epoch_pos == 0) {
+        long long e = kDirect ? 0 : epoch;
         if (e >= p.n_epochs) { local_err = RS_CQI_EPOCHS; e = p.n_epochs - 1; }
         /* HBM grid is [U][R] (one row per UE, like the reference's per-UE CQI vectors); LDS keeps it
          * RBG-major [R][Upad] so that the metric scan reads 8 consecutive UEs of one RBG per load */
@@ -940,6 +948,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     RS_STAMP(8);
     served_prev = m->served;
     n_done += 1;
+    if (++epoch_pos == p.refresh) { epoch_pos = 0; ++epoch; }
     if (!kDirect) t += 0.001; /* ref: src/core/eventScheduler/simulator.cc:117-126 */
   }
 
