@@ -308,7 +308,9 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       }
       __syncthreads();
       /* my share: entries wave, wave + nwaves, ... (lane t fetches the t-th of them), packed side by side while they fit */
-      const int n_mine = n_alive > wave ? (n_alive - wave + nwaves - 1) / nwaves : 0;
+      int n_mine = 0; /* entries j = wave + t * nwaves below n_alive (no division: nwaves is a run-time value) */
+#pragma unroll
+      for (int t = 0; t < RS_WAVE_FINISH_MAX; ++t) n_mine += wave + t * nwaves < n_alive ? 1 : 0;
       const int my_ent = lane < n_mine ? cuts[wave + lane * nwaves] : 0;
       for (int t = 0; t < n_mine;) {
         int fb = 0, lb = 0, l0 = 0, used = 0;
