@@ -554,7 +554,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           ue = ue > nvs_hi ? nvs_hi : ue;
         }
         double best = SCHED == 1 ? 0.0 : (SCHED == 7 ? -1.7976931348623157e308 : -1.0);
-        int bu = -1, bkey = 0;
+        int bu = -1;
+        float run_a = 0.0f; /* stage-1 value of the leader (0: none yet) */
+        bool exact = false; /* `best` is the leader's exact metric */
         int sl_eps = 1, sl_psi = 1;
         int sl_custom = 0; /* 1: alpha slice, 2: alpha slice with the HoL factor */
         if (SCHED != 1) {
@@ -578,8 +580,22 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         const float* numtab = one_num ? m->ones16 : s_num32; /* a table either way: no branch per user */
         /* this slice's window, indexed by user (drop-in NVS passes the served slice's users only: their own slice id) */
         const float* rcw = s_rcp32 + (SCHED == 1 ? 0 : m->rcp_off[(SCHED == 7 && kDirect) ? (int)p.user_slice[0] : seg]);
+        /* stage 2 of one user: the reference's expression, real IEEE FP64 division */
+        auto exact_metric = [&](int u, int c) -> double {
+          if (SCHED == 1) {
+            /* ref: dl-pf-packet-scheduler.cpp:128-140  (se*180000.)/avg */
+            return s_num[c] / s_avg[u];
+          }
+          /* ref: :688-693  pow(se_kbps, eps) / pow(avg_kbps, psi), eps, psi in {0,1} */
+          /* both table reads are issued whatever the slice's exponents are (no branch around an LDS read) */
+          const double num_c = s_num[c], den_u = s_avgk[u];
+          const double num = sl_eps ? num_c : 1.0, den = sl_psi ? den_u : 1.0;
+          if (sl_custom && p.prio && p.prio[u] == 0) return 0.0;
+          if (sl_custom == 2) return p.hol[u] * num / den; /* HoL * pow(se) / pow(avg), left to right */
+          return num / den;
+        };
 #ifdef RS_EXP_P3_SKIP
-        bu = ub; bkey = rowp[ub]; best = 1.0; /* timing experiment only: wrong results */
+        bu = ub; best = 1.0; exact = true; /* timing experiment only: wrong results */
         for (int blk = ue; blk < ue; blk += kP3Block) {
 #else
         /* (an empty segment must not enter: its 8-aligned start lies before its end, inside a neighbour's window) */
@@ -616,36 +632,62 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               best_a = fmaxf(best_a, a);
             }
           }
-          /* survivors: a~ >= (1 - 2^-19) max a~ and a~ > 0.  With a positive maximum the threshold is positive and the
-           * second test is implied; with an all-zero block an infinite threshold leaves no survivor */
-          const float thr = best_a > 0.0f ? best_a * kTol : __builtin_inff();
-          uint32_t cand = 0;
+          if (!sl_custom) {
+            /* The leader so far is known by its stage-1 value run_a; its exact metric is only worked out when somebody comes
+             * within the tolerance of it.  A block whose maximum is below (1 - 2^-19) run_a cannot win or tie; otherwise the
+             * users at or above (1 - 2^-19) of the larger of the two maxima are the only possible winners: a single one that
+             * leaves the old leader below the threshold simply takes over (no division at all -- the common case), several, or
+             * one next to a leader still in range, are compared exactly, ascending user order, strict '>'. */
+            if (best_a > 0.0f && best_a >= run_a * kTol) {
+              const float thr = fmaxf(best_a, run_a) * kTol;
+              uint32_t cand = 0;
 #pragma unroll
-          for (int k = 0; k < kP3Block; ++k) cand |= av[k] >= thr ? (1u << k) : 0u;
-          /* customised slices can rank every user at 0 (no prioritized data): the reference's scan then
-           * keeps the first user (0 > -1), so that user goes to stage 2 */
-          if (sl_custom && !cand) cand = 1u << ((ub > blk ? ub : blk) - blk);
-          while (cand) {
-            const int j = __ffs((int)cand) - 1;
-            cand &= cand - 1;
-            const int u = blk + j;
-            const int c = rowp[u];
-            double metric;
-            if (SCHED == 1) {
-              /* ref: dl-pf-packet-scheduler.cpp:128-140  (se*180000.)/avg */
-              metric = s_num[c] / s_avg[u];
-            } else {
-              /* ref: :688-693  pow(se_kbps, eps) / pow(avg_kbps, psi), eps, psi in {0,1} */
-              /* both table reads are issued whatever the slice's exponents are (no branch around an LDS read) */
-              const double num_c = s_num[c], den_u = s_avgk[u];
-              const double num = sl_eps ? num_c : 1.0, den = sl_psi ? den_u : 1.0;
-              if (sl_custom && p.prio && p.prio[u] == 0) metric = 0.0;
-              else if (sl_custom == 2) metric = p.hol[u] * num / den; /* HoL * pow(se) / pow(avg), left to right */
-              else metric = num / den;
+              for (int k = 0; k < kP3Block; ++k) cand |= av[k] >= thr ? (1u << k) : 0u;
+              const bool leader_in = run_a >= thr; /* false while there is no leader: thr > 0 */
+              if (!leader_in && (cand & (cand - 1u)) == 0u) {
+                bu = blk + __ffs((int)cand) - 1;
+                run_a = best_a;
+                exact = false;
+              } else {
+                if (leader_in) {
+                  if (!exact) best = exact_metric(bu, rowp[bu]);
+                } else {
+                  best = SCHED == 1 ? 0.0 : (SCHED == 7 ? -1.7976931348623157e308 : -1.0);
+                  bu = -1;
+                }
+                while (cand) {
+                  const int j = __ffs((int)cand) - 1;
+                  cand &= cand - 1;
+                  const int u = blk + j;
+                  const double metric = exact_metric(u, rowp[u]);
+                  if (metric > best) { best = metric; bu = u; }
+                }
+                exact = true;
+                run_a = *(const float*)((const char*)numtab + ((uint32_t)rowp[bu] << 2)) * rcw[bu];
+              }
             }
-            if (metric > best) { best = metric; bu = u; bkey = c; }
+          } else {
+            /* customised slices (drop-in mode only): every survivor of the block is evaluated.  Survivors: a~ >= (1 - 2^-19)
+             * max a~ and a~ > 0; with an all-zero block an infinite threshold leaves no survivor */
+            const float thr = best_a > 0.0f ? best_a * kTol : __builtin_inff();
+            uint32_t cand = 0;
+#pragma unroll
+            for (int k = 0; k < kP3Block; ++k) cand |= av[k] >= thr ? (1u << k) : 0u;
+            /* customised slices can rank every user at 0 (no prioritized data): the reference's scan then
+             * keeps the first user (0 > -1), so that user goes to stage 2 */
+            if (!cand) cand = 1u << ((ub > blk ? ub : blk) - blk);
+            while (cand) {
+              const int j = __ffs((int)cand) - 1;
+              cand &= cand - 1;
+              const int u = blk + j;
+              const double metric = exact_metric(u, rowp[u]);
+              if (metric > best) { best = metric; bu = u; }
+            }
+            exact = true;
           }
         }
+        const int bkey = bu >= 0 ? rowp[bu] : 0;
+        if ((SCHED == 1 || nvs_split) && !exact && bu >= 0) best = exact_metric(bu, bkey); /* the winners' metrics meet in P4 */
         s_best_user[it] = (uint16_t)bu;
         if (SCHED == 10) {
           /* UpperBound sorts one vector per slice (:229-233): slice-major */
