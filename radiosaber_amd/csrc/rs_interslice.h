@@ -51,38 +51,43 @@ __device__ __forceinline__ int interslice_maximize_cell(const uint32_t* s_sorted
   const int N = R * S;
   int left = lane < S ? m->quota[lane] : 0; /* lane s: quota[s] - granted[s] */
   int my_slice = -1;                        /* lane r: slice that got RBG r */
-  int assigned = 0;
 #ifdef RS_STAMPS
+  int assigned = 0;
   int scan_end = 0; /* diagnostic: how deep the scan went */
 #endif
   /* free RBGs and slices still under quota as two scalar masks: a record is live when both of its bits are set (a 64-bit
-   * shift per lane instead of two cross-lane reads); the next 64 records are fetched while this chunk is scanned */
+   * shift per lane instead of two cross-lane reads); the next 64 records are fetched while this chunk is scanned.  Every
+   * record lane carries the remaining quota of its own slice, so the three facts about the first live record (RBG, slice,
+   * is this the slice's last RBG) are three independent lane reads */
   unsigned long long free_rbg = R >= 64 ? ~0ull : (1ull << R) - 1ull;
   unsigned long long open_sl = __ballot(left > 0);
   uint32_t e_next = lane < N ? s_sorted[lane] : 0u;
-  for (int c0 = 0; c0 < N && assigned < R; c0 += 64) {
+  for (int c0 = 0; c0 < N && free_rbg != 0ull; c0 += 64) {
     const int i = c0 + lane;
     const uint32_t e = e_next;
     const int rbg = (e >> 8) & 63, sl = e & 63;
     /* records of this chunk that can still be taken: RBG free and slice under quota */
     unsigned long long live = __ballot((i < N) & (((free_rbg >> rbg) & (open_sl >> sl) & 1ull) != 0ull));
+    int sl_left = __shfl(left, sl, 64); /* quota left of my record's slice (all lanes take part) */
     asm volatile("" ::: "memory"); /* the fetch of the next chunk is issued here, not above the wait for this one */
     e_next = i + 64 < N ? s_sorted[i + 64] : 0u;
     while (live) {
       const int f = __ffsll((long long)live) - 1;
       const int frbg = __builtin_amdgcn_readlane(rbg, f);
       const int fsl = __builtin_amdgcn_readlane(sl, f);
-      const int sleft = __builtin_amdgcn_readlane(left, fsl);
+      const int fleft = __builtin_amdgcn_readlane(sl_left, f);
+      const unsigned long long same_sl = __ballot(sl == fsl);
       live &= ~__ballot(rbg == frbg); /* the RBG is gone (this drops record f too) */
       free_rbg &= ~(1ull << frbg);
-      if (sleft == 1) { /* the slice just used its last RBG */
-        live &= ~__ballot(sl == fsl);
+      if (fleft == 1) { /* the slice just used its last RBG */
+        live &= ~same_sl;
         open_sl &= ~(1ull << fsl);
       }
+      if (sl == fsl) sl_left--;
       if (lane == fsl) left--;
       if (lane == frbg) my_slice = fsl;
-      assigned++;
 #ifdef RS_STAMPS
+      assigned++;
       scan_end = c0 + f;
 #endif
     }
