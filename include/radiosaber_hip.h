@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 2 /* 2: rs_tti_in.rand_draws, schedulers 10 / 11 / 103, rs_trace_*, rs_hbm_copy_probe */
+#define RS_ABI_VERSION 2 /* 2: rs_tti_in.rand_draws, schedulers 10 / 11 / 101 / 103, rs_trace_*, rs_hbm_copy_probe, rs_lds_bytes_per_cell */
 
 /* status codes */
 enum {
