@@ -4,6 +4,7 @@
  * RBG r goes to (-1: none) and leaves in `got`, lane s, the RBGs granted to slice s; `m->quota[s]` holds the quotas.
  * Records are u32: CQI key of the slice's winner << 16 | rbg << 8 | slice (key 0: the slice has no user).  Efficiencies are
  * strictly increasing in the key, so comparisons use keys and only differences use the doubles (RsMisc::eff16).
+ * S_T / R_T: the shape as template constants in a shape-specialised build (0: run-time values).
  * Included by rs_kernels.hip and embedded for the run-time specialisation (rs_jit.cpp). */
 #ifndef RS_INTERSLICE_H_
 #define RS_INTERSLICE_H_
@@ -14,8 +15,10 @@
 
 namespace {
 
-__device__ __forceinline__ int interslice_greedy_by_row(const uint32_t* s_elems, const RsMisc* m, int S, int R, int& got) {
+template <int S_T, int R_T>
+__device__ __forceinline__ int interslice_greedy_by_row(const uint32_t* s_elems, const RsMisc* m, int S_rt, int R_rt, int& got) {
   const int lane = lane_id();
+  const int S = S_T ? S_T : S_rt, R = R_T ? R_T : R_rt; /* front-end constants in a shape-specialised build */
   /* GreedyByRow, ref: :249-272 -- RBG ascending, argmax eff over slices under quota, first max
    * wins.  eff is strictly increasing in CQI (0 for an empty slice), so integer keys compare alike. */
   const int quota = lane < S ? m->quota[lane] : 0;
@@ -37,12 +40,14 @@ __device__ __forceinline__ int interslice_greedy_by_row(const uint32_t* s_elems,
 }
 
 /* s_sorted: the R*S records in std::sort's order */
-__device__ __forceinline__ int interslice_maximize_cell(const uint32_t* s_sorted, const RsMisc* m, int S, int R, int& got
+template <int S_T, int R_T>
+__device__ __forceinline__ int interslice_maximize_cell(const uint32_t* s_sorted, const RsMisc* m, int S_rt, int R_rt, int& got
 #ifdef RS_STAMPS
                                                         , unsigned long long* stamp_acc
 #endif
 ) {
   const int lane = lane_id();
+  const int S = S_T ? S_T : S_rt, R = R_T ? R_T : R_rt; /* front-end constants in a shape-specialised build */
 #ifdef RS_STAMPS
   const int tid = threadIdx.x;
 #endif
@@ -102,8 +107,10 @@ __device__ __forceinline__ int interslice_maximize_cell(const uint32_t* s_sorted
   return my_slice;
 }
 
-__device__ __forceinline__ int interslice_vogel(const uint32_t* s_elems, const RsMisc* m, int S, int R, int& got) {
+template <int S_T, int R_T>
+__device__ __forceinline__ int interslice_vogel(const uint32_t* s_elems, const RsMisc* m, int S_rt, int R_rt, int& got) {
   const int lane = lane_id();
+  const int S = S_T ? S_T : S_rt, R = R_T ? R_T : R_rt; /* front-end constants in a shape-specialised build */
   /* VogelApproximate, ref: downlink-transport-scheduler.cpp:378-451.  R rounds; in each one every free RBG (lanes = RBGs)
    * looks for its best and "second" slice among the slices under quota, every such slice (lanes = slices) for its best and
    * "second" free RBG, and the candidate with the largest difference gets assigned.  Three details of the reference are
@@ -114,12 +121,32 @@ __device__ __forceinline__ int interslice_vogel(const uint32_t* s_elems, const R
    * increasing in the CQI key (0 = no user), so keys are compared and only the differences use the doubles. */
   const int quota = lane < S ? m->quota[lane] : 0;
   int my_slice = -1; /* lane r: slice that got RBG r */
+  /* the records do not change during the rounds: a shape-specialised build reads its row (lane = RBG) and its column
+   * (lane = slice) once, the keys stay in registers */
+  constexpr bool kRegs = S_T != 0 && R_T != 0 && S_T + R_T <= 64;
+  int rowk[kRegs ? S_T : 1], colk[kRegs ? R_T : 1];
+  if constexpr (kRegs) {
+    const uint32_t* row = s_elems + (lane < R ? lane : 0) * S;
+    const uint32_t* col = s_elems + (lane < S ? lane : 0);
+#pragma unroll
+    for (int k = 0; k < S_T; ++k) rowk[k] = (int)(row[k] >> 16);
+#pragma unroll
+    for (int j = 0; j < R_T; ++j) colk[j] = (int)(col[j * S] >> 16);
+  }
   for (int round = 0; round < R; ++round) {
     const unsigned long long elig = __ballot(lane < S && got < quota);
     const unsigned long long freeb = __ballot(lane < R && my_slice < 0);
     /* horizontal search: lane j = free RBG j, slices ascending (four LDS reads in flight per step) */
     int h1 = -1, h2 = -1, hs = -1;
-    {
+    if constexpr (kRegs) {
+#pragma unroll
+      for (int k = 0; k < S_T; ++k)
+        if ((elig >> k) & 1ull) {
+          const int key = rowk[k];
+          if (h1 < 0 || key > h1) { hs = k; h1 = key; }
+          else if (h2 < 0 || key > h2) h2 = key;
+        }
+    } else {
       const uint32_t* row = s_elems + (lane < R ? lane : 0) * S;
       for (int k0 = 0; k0 < S; k0 += 4) {
         uint32_t e4[4];
@@ -138,7 +165,15 @@ __device__ __forceinline__ int interslice_vogel(const uint32_t* s_elems, const R
     }
     /* vertical search: lane k = slice k under quota, free RBGs ascending */
     int v1 = -1, v2 = -1, vr = -1;
-    {
+    if constexpr (kRegs) {
+#pragma unroll
+      for (int j = 0; j < R_T; ++j)
+        if ((freeb >> j) & 1ull) {
+          const int key = colk[j];
+          if (v1 < 0 || key > v1) { vr = j; v1 = key; }
+          else if (v2 < 0 || key > v2) v2 = key;
+        }
+    } else {
       const uint32_t* col = s_elems + (lane < S ? lane : 0);
       for (int j0 = 0; j0 < R; j0 += 4) {
         uint32_t e4[4];
@@ -190,8 +225,10 @@ __device__ __forceinline__ int interslice_vogel(const uint32_t* s_elems, const R
 }
 
 /* um: RS_UMAP_SCRATCH_BYTES of LDS for rs_umap_order */
-__device__ __forceinline__ int interslice_subopt(const uint32_t* s_elems, const RsMisc* m, uint8_t* um, int S, int R, int& got) {
+template <int S_T, int R_T>
+__device__ __forceinline__ int interslice_subopt(const uint32_t* s_elems, const RsMisc* m, uint8_t* um, int S_rt, int R_rt, int& got) {
   const int lane = lane_id();
+  const int S = S_T ? S_T : S_rt, R = R_T ? R_T : R_rt; /* front-end constants in a shape-specialised build */
   /* SubOpt, ref: downlink-transport-scheduler.cpp:274-349.  Every RBG (lanes = RBGs) starts at its best slice (first
    * maximum); then one RBG per round moves from a slice above its quota to a slice below it -- the move with the
    * smallest efficiency loss, first in (RBG ascending, `slice_fewer` iteration order) among equal losses.  That order

@@ -854,14 +854,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       if constexpr (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103) {
         /* DownlinkTransportScheduler's inter-slice policies (rs_interslice.h): lane r learns the slice of RBG r */
         int my_slice;
-        if constexpr (SCHED == 8) my_slice = interslice_greedy_by_row(s_elems, m, S, R, got);
-        else if constexpr (SCHED == 101) my_slice = interslice_subopt(s_elems, m, (uint8_t*)(lds + o.sortx), S, R, got);
-        else if constexpr (SCHED == 103) my_slice = interslice_vogel(s_elems, m, S, R, got);
+        constexpr int kS = FIXED ? RS_JIT_S : 0, kR = FIXED ? RS_JIT_R : 0;
+        if constexpr (SCHED == 8) my_slice = interslice_greedy_by_row<kS, kR>(s_elems, m, S, R, got);
+        else if constexpr (SCHED == 101) my_slice = interslice_subopt<kS, kR>(s_elems, m, (uint8_t*)(lds + o.sortx), S, R, got);
+        else if constexpr (SCHED == 103) my_slice = interslice_vogel<kS, kR>(s_elems, m, S, R, got);
         else {
 #ifdef RS_STAMPS
-          my_slice = interslice_maximize_cell(s_sorted, m, S, R, got, stamp_acc);
+          my_slice = interslice_maximize_cell<kS, kR>(s_sorted, m, S, R, got, stamp_acc);
 #else
-          my_slice = interslice_maximize_cell(s_sorted, m, S, R, got);
+          my_slice = interslice_maximize_cell<kS, kR>(s_sorted, m, S, R, got);
 #endif
         }
         if (lane < R && my_slice >= 0) {
