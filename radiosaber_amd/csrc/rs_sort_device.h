@@ -291,7 +291,8 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
   for (int level = 0; level < 47; ++level, --depth) {
     const int n_alive = m->n_level[level]; /* complete: the previous level ended with a barrier */
     if (n_alive == 0) break;
-    if (depth != 0 && n_alive <= RS_WAVE_FINISH_MAX * nwaves) {
+    /* (a first level that fills every lane -- UpperBound's row of short vectors at one position per lane -- stays a workgroup level) */
+    if (depth != 0 && n_alive <= RS_WAVE_FINISH_MAX * nwaves && (level > 0 || EPT > 1 || n_alive == 1)) {
       /* few sub-ranges left, none longer than 64: their first positions publish them, every wave takes its share and
        * finishes them alone (finish_subranges_on_wave) */
 #pragma unroll
