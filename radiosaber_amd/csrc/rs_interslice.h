@@ -259,16 +259,46 @@ __device__ __forceinline__ int interslice_subopt(const uint32_t* s_elems, const 
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int ordv = lane < n_ord ? um[196 + lane] : 0;
+  /* A shape-specialised build keeps the efficiencies of its RBG's S records in registers and walks the slices in index order:
+   * "first in the hashtable's order among equal losses" becomes "smallest position in that order" (rankv: lane k holds the
+   * position of slice k), so the rounds read no LDS beyond the mover's new efficiency. */
+  constexpr bool kRegs = S_T != 0 && S_T <= 32;
+  double effk[kRegs ? S_T : 1];
+  int rankv = 255;
+  double own_eff = 0.0;
+  if constexpr (kRegs) {
+#pragma unroll
+    for (int k = 0; k < S_T; ++k) effk[k] = m->eff16[row[k] >> 16];
+    um[68 + lane] = 255; /* the bucket scratch of rs_umap_order is free again */
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n_ord) um[68 + ordv] = (uint8_t)lane;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    rankv = um[68 + lane];
+    own_eff = m->eff16[row[my_slice >= 0 ? my_slice : 0] >> 16];
+  }
   while (more_mask && fewer_mask) {
     const bool cand = my_slice >= 0 && ((more_mask >> my_slice) & 1ull);
-    const double own_eff = m->eff16[row[my_slice >= 0 ? my_slice : 0] >> 16];
     double least = 1.7976931348623157e308;
     int to_sl = -1;
-    for (int q = 0; q < n_ord; ++q) {
-      const int key = __builtin_amdgcn_readlane(ordv, q);
-      if (!((fewer_mask >> key) & 1ull)) continue;
-      const double loss = own_eff - m->eff16[row[key] >> 16];
-      if (loss < least) { least = loss; to_sl = key; }
+    if constexpr (kRegs) {
+      int best_rank = 1 << 30;
+#pragma unroll
+      for (int k = 0; k < S_T; ++k)
+        if ((fewer_mask >> k) & 1ull) {
+          const int rk = __builtin_amdgcn_readlane(rankv, k);
+          const double loss = own_eff - effk[k];
+          if (loss < least || (loss == least && rk < best_rank)) { least = loss; to_sl = k; best_rank = rk; }
+        }
+    } else {
+      own_eff = m->eff16[row[my_slice >= 0 ? my_slice : 0] >> 16];
+      for (int q = 0; q < n_ord; ++q) {
+        const int key = __builtin_amdgcn_readlane(ordv, q);
+        if (!((fewer_mask >> key) & 1ull)) continue;
+        const double loss = own_eff - m->eff16[row[key] >> 16];
+        if (loss < least) { least = loss; to_sl = key; }
+      }
     }
     /* smallest loss over the candidate RBGs, lowest RBG among equals: losses are >= 0, their bit patterns order
      * like the values */
@@ -282,6 +312,10 @@ __device__ __forceinline__ int interslice_subopt(const uint32_t* s_elems, const 
     const int rbg = __ffsll((long long)hit) - 1;
     const int from = __builtin_amdgcn_readlane(my_slice, rbg), to = __builtin_amdgcn_readlane(to_sl, rbg);
     if (lane == rbg) my_slice = to;
+    if constexpr (kRegs) {
+      const double to_eff = m->eff16[row[to] >> 16]; /* every lane reads (uniform `to`), the mover keeps it */
+      if (lane == rbg) own_eff = to_eff;
+    }
     if (lane == from) { got--; more--; }
     if (lane == to) { got++; fewer--; }
     more_mask = __ballot(more > 0 && got > 0);
