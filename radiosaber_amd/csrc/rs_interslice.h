@@ -123,13 +123,15 @@ __device__ __forceinline__ int interslice_vogel(const uint32_t* s_elems, const R
   int my_slice = -1; /* lane r: slice that got RBG r */
   /* the records do not change during the rounds: a shape-specialised build reads its row (lane = RBG) and its column
    * (lane = slice) once, the keys stay in registers */
-  constexpr bool kRegs = S_T != 0 && R_T != 0 && S_T + R_T <= 64;
-  int rowk[kRegs ? S_T : 1], colk[kRegs ? R_T : 1];
-  if constexpr (kRegs) {
+  constexpr bool kRowRegs = S_T != 0 && S_T <= 32, kColRegs = R_T != 0 && R_T <= 32;
+  int rowk[kRowRegs ? S_T : 1], colk[kColRegs ? R_T : 1];
+  if constexpr (kRowRegs) {
     const uint32_t* row = s_elems + (lane < R ? lane : 0) * S;
-    const uint32_t* col = s_elems + (lane < S ? lane : 0);
 #pragma unroll
     for (int k = 0; k < S_T; ++k) rowk[k] = (int)(row[k] >> 16);
+  }
+  if constexpr (kColRegs) {
+    const uint32_t* col = s_elems + (lane < S ? lane : 0);
 #pragma unroll
     for (int j = 0; j < R_T; ++j) colk[j] = (int)(col[j * S] >> 16);
   }
@@ -138,7 +140,7 @@ __device__ __forceinline__ int interslice_vogel(const uint32_t* s_elems, const R
     const unsigned long long freeb = __ballot(lane < R && my_slice < 0);
     /* horizontal search: lane j = free RBG j, slices ascending (four LDS reads in flight per step) */
     int h1 = -1, h2 = -1, hs = -1;
-    if constexpr (kRegs) {
+    if constexpr (kRowRegs) {
 #pragma unroll
       for (int k = 0; k < S_T; ++k)
         if ((elig >> k) & 1ull) {
@@ -165,7 +167,7 @@ __device__ __forceinline__ int interslice_vogel(const uint32_t* s_elems, const R
     }
     /* vertical search: lane k = slice k under quota, free RBGs ascending */
     int v1 = -1, v2 = -1, vr = -1;
-    if constexpr (kRegs) {
+    if constexpr (kColRegs) {
 #pragma unroll
       for (int j = 0; j < R_T; ++j)
         if ((freeb >> j) & 1ull) {
