@@ -15,6 +15,10 @@
 
 namespace {
 
+#ifndef RS_GBR_GROUP
+#define RS_GBR_GROUP 2 /* RBGs decided per step of GreedyByRow */
+#endif
+
 template <int S_T, int R_T>
 __device__ __forceinline__ int interslice_greedy_by_row(const uint32_t* s_elems, const RsMisc* m, int S_rt, int R_rt, int& got) {
   const int lane = lane_id();
@@ -23,18 +27,40 @@ __device__ __forceinline__ int interslice_greedy_by_row(const uint32_t* s_elems,
    * wins.  eff is strictly increasing in CQI (0 for an empty slice), so integer keys compare alike. */
   const int quota = lane < S ? m->quota[lane] : 0;
   int my_slice = -1;
-  /* the next RBG's keys are loaded while this one is decided */
+  /* RS_GBR_GROUP RBGs per step: their arg-max reductions run side by side (independent DPP chains) under the quotas as they
+   * stand at the start of the step.  Slices only ever close, so a result stays the arg-max as long as its slice is still open
+   * when its turn comes; otherwise (an earlier RBG of the step took the slice's last unit) it is redone.  The keys of the
+   * next step are loaded meanwhile. */
+  constexpr int GN = RS_GBR_GROUP;
   const uint32_t* colp = s_elems + (lane < S ? lane : 0);
-  uint32_t e_next = colp[0];
-  for (int r = 0; r < R; ++r) {
-    const int key = (int)(e_next >> 16);
-    e_next = colp[(r + 1 < R ? r + 1 : r) * S];
+  auto key_of = [&](int r) -> int { return (int)(colp[(r < R ? r : R - 1) * S] >> 16); };
+  auto pick = [&](int key) -> int {
     const bool ok = lane < S && got < quota;
-    const int packed = ok ? (key << 6) | (63 - lane) : -1;
-    const int bestp = wave_max(packed);
-    const int sl = bestp < 0 ? -1 : 63 - (bestp & 63);
-    if (lane == sl) got++;
-    if (lane == r) my_slice = sl;
+    const int bestp = wave_max(ok ? (key << 6) | (63 - lane) : -1);
+    return bestp < 0 ? -1 : 63 - (bestp & 63);
+  };
+  int kn[GN];
+#pragma unroll
+  for (int j = 0; j < GN; ++j) kn[j] = key_of(j);
+  for (int r = 0; r < R; r += GN) {
+    int kc[GN], pj[GN];
+    const bool ok = lane < S && got < quota;
+#pragma unroll
+    for (int j = 0; j < GN; ++j) {
+      kc[j] = kn[j];
+      kn[j] = key_of(r + GN + j);
+    }
+#pragma unroll
+    for (int j = 0; j < GN; ++j) pj[j] = wave_max(ok ? (kc[j] << 6) | (63 - lane) : -1);
+#pragma unroll
+    for (int j = 0; j < GN; ++j) {
+      if (r + j < R) {
+        int sj = pj[j] < 0 ? -1 : 63 - (pj[j] & 63);
+        if (j > 0 && sj >= 0 && __builtin_amdgcn_readlane(got, sj) >= __builtin_amdgcn_readlane(quota, sj)) sj = pick(kc[j]);
+        if (lane == sj) got++;
+        if (lane == r + j) my_slice = sj;
+      }
+    }
   }
   return my_slice;
 }
