@@ -219,6 +219,14 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     epoch = n_done / p.refresh;
     epoch_pos = (int)(n_done - epoch * p.refresh);
   }
+  /* EESM decision thresholds X[1..13] as wave-uniform values for the whole launch (13 scalar register pairs when they fit) */
+  double xthr_k[13];
+  {
+    const double xl = s_x[lane & 15];
+#pragma unroll
+    for (int k = 1; k <= 13; ++k)
+      xthr_k[k - 1] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xl), k), __builtin_amdgcn_readlane(__double2loint(xl), k));
+  }
   for (int tti = 0; tti < p.n_ttis; ++tti) {
     RS_STAMP(11);
     /* ---------------- P0: CQI refresh ---------------- */
@@ -915,7 +923,6 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       /* owner + 1 <= U <= 2047; a shape-specialised build knows how many bits that takes */
       constexpr int kOwnerBits = !FIXED ? 11 : RS_JIT_U < 63 ? 6 : RS_JIT_U < 127 ? 7 : RS_JIT_U < 255 ? 8
                                  : RS_JIT_U < 511 ? 9 : RS_JIT_U < 1023 ? 10 : 11;
-      const double xthr = s_x[lane & 15]; /* EESM decision thresholds X[1..13], one per lane */
       BitBallots<kOwnerBits> ob;
       ob.gather(owner + 1, lane < R && owner >= 0);
       const unsigned long long same = owner >= 0 ? ob.lanes_with(owner + 1) : 0ull;
@@ -948,11 +955,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           } else {
             fcqi = 1;
 #pragma unroll
-            for (int k = 1; k <= 13; ++k) { /* thresholds from lanes 1..13 of xthr: no LDS round trips on the serial path */
-              const double thr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xthr), k),
-                                                  __builtin_amdgcn_readlane(__double2loint(xthr), k));
-              fcqi += (x <= thr) ? 1 : 0;
-            }
+            for (int k = 1; k <= 13; ++k) fcqi += (x <= xthr_k[k - 1]) ? 1 : 0; /* thresholds: wave-uniform, read before the TTI loop */
           }
           mcs = m->mcs_of_cqi[fcqi];
           tbs = s_tbs[(nprb / G) * 16 + fcqi];
