@@ -9,33 +9,47 @@ every GPU holds `--cells` (512) independent cells of 20 slices x 25 UEs (500 UEs
 scheduler 9 (RadioSaber / MaximizeCell), PF parameters epsilon=1 psi=1, weights 0.05, backlogged
 flows, synthetic per-RBG CQI drawn i.i.d. from the reference trace corpus' histogram and redrawn
 every 40 TTIs, one libc-compatible rand() stream per cell.  One STEP = one kernel launch that runs
-`--ttis` (400) complete DoSchedule() iterations of every cell; all inputs (the CQI grids of every
-epoch, the cell state) are resident in HBM before the timed region starts.
+`--ttis` (2000) complete DoSchedule() iterations of every cell; all inputs (the CQI grids of every
+epoch, the cell state) are resident in HBM before the timed region starts.  The default timed region
+is 60 launches = 120 000 TTIs per cell, about two seconds.
 
 value = cells_total * ttis * steps / wall time, wall time bracketed by barrier + device sync on
-both sides, max over ranks.  Cells are independent, so ranks share nothing during the run; the only
-collective is the final all-reduce (RCCL) of the per-slice cumulative byte counters uint64[S].
+both sides, max over ranks.  Cells are independent, so ranks share nothing during the run (cell ids,
+rand() seeds and CQI grids are functions of the GLOBAL cell id); the only collective is the final
+all-reduce (RCCL) of the per-slice cumulative byte counters uint64[S].
 
 The JSON line also carries
-  roofline     algorithmic bytes (B_TTI = U*R + 16U + 4U + 4R + 16S per cell-TTI) of
-               one launch / that launch's HIP-event duration, against the 8 TB/s HBM3E peak;
-  cpu_baseline the CPU oracle (oracle/, the bit-exact restatement of the reference) timed on this
-               box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline        SURVEY.md 8d as the contract defines it: algorithmic bytes (B_TTI = U*R + 16U + 4U + 4R + 16S per
+                  cell-TTI, "streamed-CQI" accounting) of one launch / that launch's HIP-event duration, against the
+                  8 TB/s HBM3E peak -- a NOMINAL figure: the kernel keeps the CQI grid in LDS for 40 TTIs, so
+                  `resident_bytes_per_cell_tti` (compulsory traffic of the resident design) and `traffic` (HBM bytes per
+                  launch from the PMC passes recorded in profiles/traffic.json, NOT measured in this run: see
+                  `traffic_source`) say what actually moves;
+  roofline_issue  what really bounds the kernel: wave-instructions per cell-TTI (SQ_INSTS_* from profiles/inst_counts.json,
+                  tools/pmc_insts.sh) x this run's TTIs/s against the chip's VALU issue rate;
+  value_r64       the same batch on the as-shipped 64-RBG grid (N = 1 only);
+  cpu_baseline    the CPU oracle (oracle/, the bit-exact restatement of the reference) timed on this box's host cores with
+                  OpenMP over independent cells (rank 0, N = 1 only).
 """
-import argparse
-import json
 import os
-import sys
-import time
-from concurrent.futures import ThreadPoolExecutor
-from pathlib import Path
 
-import numpy as np
+# the host driver only supports dmabuf IPC: must be in the environment before HIP/HSA initialises (RCCL across processes)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import argparse  # noqa: E402
+import json  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
+from pathlib import Path  # noqa: E402
+
+import numpy as np  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# VALU issue peak: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction (same guide, cycle-constants table)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
 
 
 def algorithmic_bytes_per_tti(U, R, S):
@@ -43,58 +57,27 @@ def algorithmic_bytes_per_tti(U, R, S):
     return U * R + 8 * U + 8 * U + 4 * U + 4 * R + 2 * S * 8
 
 
-def cpu_baseline(args, slices, seeds):
-    """Time the oracle on the host cores: one independent cell per thread (ctypes drops the GIL)."""
-    from oracle import oracle_py as O
-    O.lib()
-    cores = os.cpu_count() or 1
-    hist = np.asarray(args.hist, np.float64)
-    p = hist / hist.sum()
-    U, R = slices.n_users, args.rbgs
+def resident_bytes_per_tti(U, R, S, n_ttis, refresh=40):
+    """Compulsory HBM traffic of the resident design per cell-TTI: the CQI grid once per refresh interval, the cell
+    state (avg f64, tx i32 in and out; cumulative bytes / RBs i64 read-modify-write; slice state; scalars) once per launch."""
+    state = U * (8 + 4) * 2 + U * 16 * 2 + S * 16 + 2 * 200
+    return U * R / refresh + state / n_ttis
 
-    rng = np.random.default_rng(1000)
 
-    def grids_for(n_ttis):
-        return rng.choice(np.arange(1, 16, dtype=np.uint8), size=((n_ttis + 39) // 40, U, R), p=p).astype(np.uint8)
-
-    def one(i, grids, n_ttis):
-        # cells differ by their rand() stream; the (read-only) CQI grids are shared between threads
-        cell = O.Cell(slices.ues_per_slice, R, args.rbg_size, args.sched, weights=slices.weight)
-        t0 = time.perf_counter()
-        cell.run_synth(grids, int(seeds[i % len(seeds)]), n_ttis, log=False)
-        return time.perf_counter() - t0
-
-    probe = one(0, grids_for(200), 200)  # calibrate: seconds per 200 TTIs on one core
-    per_core = 200.0 / probe
-
-    def run(threads, n_ttis, grids):
-        cells = [O.Cell(slices.ues_per_slice, R, args.rbg_size, args.sched, weights=slices.weight) for _ in range(threads)]
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(threads) as ex:
-            list(ex.map(lambda i: cells[i].run_synth(grids, int(seeds[i % len(seeds)]), n_ttis, log=False), range(threads)))
-        return threads * n_ttis / (time.perf_counter() - t0)
-
-    # os.cpu_count() can exceed what the container may use: find the thread count that actually scales
-    short = int(max(200, 1.0 * per_core))
-    g_short = grids_for(short)
-    best_t, best_rate, t = 1, per_core, 2
-    while t <= cores:
-        rate = run(t, short, g_short)
-        if rate > best_rate * 1.10:
-            best_t, best_rate = t, rate
-            t *= 2
-        else:
-            break
-    cores = best_t
-    n_ttis = int(max(200, min(40000, 10.0 * per_core)))
-    grids = grids_for(n_ttis)
-    rate = run(cores, n_ttis, grids)
-    wall = cores * n_ttis / rate
-    return {"value": cores * n_ttis / wall, "unit": "TTIs/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} independent cells x {n_ttis} TTIs of the same workload, one oracle thread each "
-                      f"(thread count = where throughput stopped scaling, os.cpu_count()={os.cpu_count()}, "
-                      f"{_cpu_model()}); "
-                      f"single core: {per_core:.0f} TTIs/s"}
+def _physical_cores():
+    """Distinct (package, core) pairs this process may run on."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    seen = set()
+    for cpu in allowed:
+        base = Path(f"/sys/devices/system/cpu/cpu{cpu}/topology")
+        try:
+            seen.add(((base / "physical_package_id").read_text().strip(), (base / "core_id").read_text().strip()))
+        except OSError:
+            seen.add(("?", str(cpu)))
+    return max(1, len(seen)), len(allowed)
 
 
 def _cpu_model():
@@ -108,14 +91,55 @@ def _cpu_model():
     return "unknown CPU"
 
 
+def cpu_baseline(args, slices, seeds):
+    """The oracle on the host cores: independent cells spread with OpenMP inside librs_oracle.so (rso_run_synth_many), one
+    thread per physical core; single-thread rate beside it.  BASELINE.md 3 / SURVEY 8(d)."""
+    from oracle import oracle_py as O
+    O.lib()
+    hist = np.asarray(args.hist, np.float64)
+    p = hist / hist.sum()
+    U, R = slices.n_users, args.rbgs
+    rng = np.random.default_rng(1000)
+
+    def grids_for(n_ttis):
+        return rng.choice(np.arange(1, 16, dtype=np.uint8), size=((n_ttis + 39) // 40, U, R), p=p).astype(np.uint8)
+
+    tmpl = O.Cell(slices.ues_per_slice, R, args.rbg_size, args.sched, weights=slices.weight)
+    # one thread, one cell: calibrates the sample size and is reported as the single-core rate
+    g = grids_for(400)
+    t0 = time.perf_counter()
+    O.run_synth_many(tmpl, 1, g, seeds[:1], 400, threads=1)
+    per_core = 400 / (time.perf_counter() - t0)
+    cores, logical = _physical_cores()
+    n_cells = 2 * cores
+    n_ttis = int(max(400, min(40000, 8.0 * per_core)))  # ~16 s of work per thread when scaling is linear
+    g = grids_for(n_ttis)
+    sd = np.resize(np.asarray(seeds, np.uint32), n_cells)
+    t0 = time.perf_counter()
+    _, used = O.run_synth_many(tmpl, n_cells, g, sd, n_ttis, threads=cores)
+    wall = time.perf_counter() - t0
+    rate = n_cells * n_ttis / wall
+    eff = rate / (per_core * used)
+    out = {"value": rate, "unit": "TTIs/s", "cores": used, "kind": "port",
+           "single_core_value": per_core, "scaling_vs_linear": eff, "cpu_model": _cpu_model(),
+           "physical_cores": cores, "logical_cpus": logical,
+           "sample": f"{n_cells} independent cells x {n_ttis} TTIs of the same workload, OpenMP over cells inside the "
+                     f"oracle (schedule(dynamic,1)), {used} threads = one per physical core; wall {wall:.1f} s"}
+    if eff < 0.5:
+        out["warning"] = (f"all-core rate is only {eff:.2f} x linear ({used} threads x {per_core:.0f} TTIs/s single-core): "
+                          "the baseline is not core-bound on this box")
+        print("cpu_baseline WARNING: " + out["warning"], file=sys.stderr)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=25,
-                    help="timed launches; the default measures 10 000 TTIs per cell (SURVEY 8d)")
+    ap.add_argument("--steps", type=int, default=60,
+                    help="timed launches; the default measures 120 000 TTIs per cell, about 2 s")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cells", type=int, default=512, help="independent cells per GPU")
-    ap.add_argument("--ttis", type=int, default=400, help="TTIs per step (per launch)")
+    ap.add_argument("--ttis", type=int, default=2000, help="TTIs per step (per launch)")
     ap.add_argument("--slices", type=int, default=20)
     ap.add_argument("--ues-per-slice", type=int, default=25)
     ap.add_argument("--rbgs", type=int, default=25)
@@ -123,6 +147,7 @@ def main():
     ap.add_argument("--sched", type=int, default=9)
     ap.add_argument("--threads", type=int, default=0, help="workgroup size per cell (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-r64", action="store_true", help="skip the extra 64-RBG measurement (value_r64)")
     ap.add_argument("--no-jit", action="store_true", help="use the kernels built into the library instead of the "
                     "shape-specialised one compiled at create time")
     args = ap.parse_args()
@@ -148,7 +173,6 @@ def main():
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -156,14 +180,24 @@ def main():
 
     S, U, R = args.slices, args.slices * args.ues_per_slice, args.rbgs
     slices = rs.SliceConfig([args.ues_per_slice] * S, weight=[1.0 / S] * S)
-    n_epochs = ((args.steps + args.warmup) * args.ttis + 39) // 40
-    batch = rs.BatchScheduler(slices, R, args.rbg_size, args.cells, sched=args.sched, device=local_rank,
-                              threads_per_cell=args.threads, jit=not args.no_jit)
-    # cell ids are global: rank r owns cells [r*cells, (r+1)*cells)
-    seeds = sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, args.cells))
-    batch.seed(seeds)
-    batch.synthesize_cqi(sharding.cqi_seed_for_cell_block(0x5AB3, rank), n_epochs)  # generated on the device, stay in HBM
+    want_jit = not args.no_jit
 
+    def make_batch(n_rbgs, rbg_size, launches, ttis):
+        b = rs.BatchScheduler(slices, n_rbgs, rbg_size, args.cells, sched=args.sched, device=local_rank,
+                              threads_per_cell=args.threads, jit=want_jit)
+        code, msg = b.jit_status()
+        if want_jit and code != 1:
+            # a headline measured on the slower built-in kernel must not pass unnoticed
+            raise SystemExit(f"bench.py: the shape-specialised kernel was requested but is not in use ({msg or code}); "
+                             "rerun with --no-jit to measure the built-in kernels on purpose")
+        # cell ids are global: rank r owns cells [r*cells, (r+1)*cells); seeds and CQI grids are keyed on them
+        b.seed(sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, args.cells)))
+        b.synthesize_cqi(0x5AB3, (launches * ttis + 39) // 40,  # generated on the device, stay in HBM
+                         first_cell=sharding.first_cell_for_rank(rank, world, args.cells))
+        return b
+
+    batch = make_batch(R, args.rbg_size, args.steps + args.warmup, args.ttis)
+    seeds = sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, args.cells))
     red_dev = "cuda" if backend == "nccl" else "cpu"  # where the tiny reductions live
 
     def sync_all():
@@ -193,6 +227,8 @@ def main():
         slice_bytes = slice_bytes.cpu()
     sharding.all_reduce_slice_bytes(slice_bytes, dist if world > 1 else None)
     total_bytes = int(slice_bytes.sum().item())
+    kernel_name = batch.kernel_name
+    batch.close()
 
     if rank == 0:
         total_ttis = world * args.cells * args.ttis * args.steps
@@ -200,12 +236,14 @@ def main():
         launch_s = float(np.mean(ms)) / 1e3
         b_tti = algorithmic_bytes_per_tti(U, R, S)
         achieved = b_tti * args.cells * args.ttis / launch_s / 1e9
-        traffic = None
+        key = f"sched{args.sched}_S{S}_U{U}_R{R}_cells{args.cells}"
+        traffic = traffic_src = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
-            tj = json.loads(tfile.read_text())
-            key = f"sched{args.sched}_S{S}_U{U}_R{R}_cells{args.cells}_ttis{args.ttis}"
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            ent = json.loads(tfile.read_text()).get(key)
+            if ent:  # recorded per TTI per cell so that it scales to this run's launch length
+                traffic = ent["hbm_bytes_per_cell_tti"] * args.cells * args.ttis
+                traffic_src = f"profiles/traffic.json[{key}]@{ent.get('commit', '?')} (PMC passes of an earlier run, not this one)"
         try:  # attainable HBM rate of this GPU (16 B/lane streaming copy, 1 GiB each way), beside the spec peak
             copy_gbs = rs.hbm_copy_probe(local_rank, 1 << 30, 10)
         except Exception as e:  # measurement nicety only
@@ -223,17 +261,43 @@ def main():
                        "cells_per_gpu": args.cells, "ttis_per_step": args.ttis, "slices": S, "ues": U, "rbgs": R,
                        "sched": args.sched, "parallelism": f"cells sharded over {world} GPU(s), no data-path collective"},
             "us_per_tti_per_cell": launch_s / args.ttis * 1e6,
-            "kernel": batch.kernel_name,
-            "kernel_ms_per_launch": [float(x) for x in ms],
+            "kernel": kernel_name,
+            "kernel_ms_per_launch": [round(float(x), 4) for x in ms],
             "total_slice_bytes": total_bytes,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_cell_tti": b_tti, "measured_copy_gbs": copy_gbs},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_frac_of_peak": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "algorithmic_bytes_per_cell_tti": b_tti,
+                         "resident_bytes_per_cell_tti": resident_bytes_per_tti(U, R, S, args.ttis),
+                         "note": "achieved/frac use SURVEY 8d's streamed-CQI bytes as the contract asks; the kernel keeps the "
+                                 "grid in LDS between refreshes, so `traffic` (PMC) is what moves and the kernel is "
+                                 "issue/latency-bound: see roofline_issue",
+                         "measured_copy_gbs": copy_gbs},
         }
+        ifile = ROOT / "profiles" / "inst_counts.json"
+        if ifile.exists():
+            ent = json.loads(ifile.read_text()).get(key)
+            if ent:
+                rate = value / world  # per GPU
+                line["roofline_issue"] = {
+                    "bound": "valu-issue + dependent-chain latency",
+                    "valu_per_cell_tti": ent["valu"], "salu_per_cell_tti": ent["salu"], "lds_per_cell_tti": ent["lds"],
+                    "valu_issue_frac": ent["valu"] * rate / VALU_ISSUE_PEAK,
+                    "valu_issue_peak_per_s": VALU_ISSUE_PEAK,
+                    "phase_shares": ent.get("phase_shares"),
+                    "source": f"profiles/inst_counts.json[{key}]@{ent.get('commit', '?')} (SQ_INSTS_* per cell-TTI from "
+                              "tools/pmc_insts.sh, phase shares from tools/phase_stamps.py; counts are per build, the rate is this run's)"}
+        if world == 1 and not args.no_r64 and (R, args.rbg_size) != (64, 8):
+            # the as-shipped grid: 100 MHz = 512 PRBs = 64 RBGs of 8 (SURVEY 8d asks for it beside the headline)
+            b64 = make_batch(64, 8, 4, args.ttis)
+            b64.run(args.ttis)
+            ms64 = b64.run_timed(args.ttis, 3)
+            b64.close()
+            line["value_r64"] = args.cells * args.ttis / (float(np.mean(ms64)) / 1e3)
+            line["us_per_tti_per_cell_r64"] = float(np.mean(ms64)) * 1e3 / args.ttis
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, slices, seeds)
         print(json.dumps(line), flush=True)
-    batch.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 2 /* 2: rs_tti_in.rand_draws, schedulers 10 / 11 / 101 / 103, rs_trace_*, rs_hbm_copy_probe, rs_lds_bytes_per_cell */
+#define RS_ABI_VERSION 3 /* 2: rs_tti_in.rand_draws, schedulers 10 / 11 / 101 / 103, rs_trace_*, rs_hbm_copy_probe, rs_lds_bytes_per_cell;
+                            3: rs_get_rbg_size, rs_dl_prbs_for_bandwidth, rs_batch_read_clock, rs_batch_jit_status,
+                               rs_batch_synthesize_cqi_at, rs_batch_run_logged_ex */
 
 /* status codes */
 enum {
@@ -97,6 +99,13 @@ int rs_device_count(void);         /* number of HIP devices (0 when none)       
  * final CQI of an allocation = 1 + #{k : x <= X[k]}, x = (sum of E over its PRBs) / nPRB; x == 0 -> 15.
  * Needs no GPU.  Returns RS_ERR_INVALID if the host libm is not monotone around a threshold. */
 int rs_link_tables(double eff[16], double kbps[16], double eesm_e[16], double eesm_x[16]);
+
+/* replaces get_rbg_size() (ref: src/utility/eesm-effective-sinr.h:82-103): PRBs per RBG of a cell with nb_rbs PRBs
+ * (<= 10: 1, <= 26: 2, <= 63: 3, <= 110: 4, <= 512: 8).  Above 512 the reference throws std::runtime_error: RS_ERR_INVALID. */
+int rs_get_rbg_size(int nb_rbs);
+/* replaces BandwidthManager's GetDlSubChannels().size() (ref: src/core/spectrum/bandwidth-manager.cpp:30-38, 52-108):
+ * 1.4 -> 6, 3 -> 15, 5 -> 25, 10 -> 50, 15 -> 75, 20 -> 100, 100 -> 512 PRBs, anything else 25 as the reference's else-branch. */
+int rs_dl_prbs_for_bandwidth(double bw_mhz);
 
 /* ------------------------------------------------------------------------------------------
  * Drop-in mode: one RBsAllocation() call.
@@ -182,7 +191,7 @@ typedef struct rs_batch_config {
                                 once the batch puts 4 or more cells on every CU                  */
   int32_t jit;               /* 1: compile the cell kernel for this batch's exact shape at create time
                                 (hiprtc, ~2 s, cached per process); results are identical, the built-in
-                                kernels are used if the compilation fails.  0: built-in kernels.
+                                kernels are used if the compilation fails (rs_batch_jit_status tells).  0: built-in kernels.
                                 The environment variable RS_JIT=0|1 overrides.                    */
 } rs_batch_config;
 
@@ -199,6 +208,10 @@ int rs_batch_upload_cqi_epochs(rs_batch* b, const uint8_t* h_cqi, int32_t n_epoc
 /* CQI source B: i.i.d. grids drawn on the device from a CQI histogram (weights of CQI 1..15),
  * counter-based generator keyed by (seed, cell, epoch, user, rbg).  Stays in HBM. */
 int rs_batch_synthesize_cqi(rs_batch* b, uint64_t seed, const double* cqi_weights /* [15] */, int32_t n_epochs);
+/* same with the batch's cells numbered first_cell .. first_cell + n_cells - 1: the generator is keyed by the GLOBAL cell id,
+ * so a cell's grids do not depend on how a job's cells are sharded over ranks (rs_batch_synthesize_cqi: first_cell = 0) */
+int rs_batch_synthesize_cqi_at(rs_batch* b, uint64_t seed, const double* cqi_weights /* [15] */, int32_t n_epochs,
+                               int64_t first_cell);
 /* read back the grids of one cell (either source) for the parity tests: [n_epochs][U][R] */
 int rs_batch_download_cqi_epochs(rs_batch* b, int32_t cell, uint8_t* h_cqi);
 /* CQI source C: the reference's trace replay.  h_trace = [n_traces][n_rows][R]; user u of cell c
@@ -245,6 +258,19 @@ int rs_batch_sync(rs_batch* b);
  * nPRB | final_cqi << 16 | mcs << 24, 0 = not scheduled); any may be NULL */
 int rs_batch_run_logged(rs_batch* b, int32_t n_ttis, int16_t* h_rbg_to_user, int32_t* h_tbs_bits,
                         int16_t* h_quota, int16_t* h_target, int32_t* h_uinfo);
+/* the same with every log optional in one struct, plus what the inter-slice step reads (parity tests pin
+ * GreedyByRow / MaximizeCell / Vogel on the device's own per-TTI inputs with it) */
+typedef struct rs_batch_log {
+  int16_t* rbg_to_user;  /* [n_cells][n_ttis][R] */
+  int32_t* tbs_bits;     /* [n_cells][n_ttis][U] */
+  int16_t* quota;        /* [n_cells][n_ttis][S] */
+  int16_t* target;       /* [n_cells][n_ttis][S] */
+  int32_t* uinfo;        /* [n_cells][n_ttis][U] */
+  uint32_t* slice_keys;  /* [n_cells][n_ttis][R][S], RS_SCHED_SEQUENTIAL / MAXCELL / UPPERBOUND / SUBOPT / VOGEL only:
+                            CQI of the slice's best user on the RBG (0: the slice has no user) | (user id + 1) << 8, i.e.
+                            flow_spectraleff / user_index of ref :545-567 */
+} rs_batch_log;
+int rs_batch_run_logged_ex(rs_batch* b, int32_t n_ttis, const rs_batch_log* log);
 /* `launches` back-to-back launches of n_ttis each, timed with HIP events on the batch's stream;
  * ms_per_launch[launches] receives each launch's duration */
 int rs_batch_run_timed(rs_batch* b, int32_t n_ttis, int32_t launches, float* ms_per_launch);
@@ -254,6 +280,12 @@ int rs_batch_run_timed(rs_batch* b, int32_t n_ttis, int32_t launches, float* ms_
  * slice_state [n_cells][S] (slice_rbs_offset_, or slice_ewma_time_ for NVS) */
 int rs_batch_read_state(rs_batch* b, double* avg_rate, int64_t* cum_bytes, int64_t* cum_rbs,
                         double* slice_state);
+/* the simulated clock of every cell (ref: src/core/eventScheduler/simulator.cc:117-126): t [n_cells] = time stamp of the next
+ * TTI, last_update [n_cells] = RadioBearer::m_lastUpdate; either may be NULL */
+int rs_batch_read_clock(rs_batch* b, double* t, double* last_update);
+/* 1: the shape-specialised (hiprtc) kernel is in use; 0: it was not asked for; -1: it was asked for and could not be
+ * built -- the built-in kernels run instead and msg receives the reason */
+int rs_batch_jit_status(rs_batch* b, char* msg, size_t msglen);
 /* per-slice cumulative bytes summed over the batch's cells, reduced on the device into
  * d_out[S] (device pointer, uint64) on the batch's stream -- the vector the multi-GPU run
  * all-reduces over RCCL (the reference's plot_throughput.py:26-56 sums it per slice post hoc) */

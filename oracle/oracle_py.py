@@ -38,7 +38,8 @@ class _TtiOut(C.Structure):
                 ("rbg_to_user", C.POINTER(C.c_int)), ("user_nprb", C.POINTER(C.c_int)),
                 ("user_final_cqi", C.POINTER(C.c_int)), ("user_mcs", C.POINTER(C.c_int)),
                 ("user_tbs_bits", C.POINTER(C.c_int)), ("served_slice", C.c_int),
-                ("upper_rbg", C.POINTER(C.c_int)), ("upper_user", C.POINTER(C.c_int))]
+                ("upper_rbg", C.POINTER(C.c_int)), ("upper_user", C.POINTER(C.c_int)),
+                ("slice_eff", C.POINTER(C.c_double)), ("slice_user", C.POINTER(C.c_int))]
 
 
 class _TraceRun(C.Structure):
@@ -90,6 +91,10 @@ def lib():
         L.rso_run_trace.argtypes = [C.c_void_p, C.POINTER(_TraceRun)] + [C.POINTER(C.c_int)] * 5
         L.rso_run_synth.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_uint,
                                     C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.rso_clock_ticks.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.rso_run_synth_many.argtypes = [C.POINTER(_Config), C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int,
+                                         C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_int)]
         L.rso_srand.argtypes = [C.POINTER(_Rng), C.c_uint]
         L.rso_rand.argtypes = [C.POINTER(_Rng)]
         for fn in ("rso_greedy_by_row", "rso_maximize_cell", "rso_vogel", "rso_subopt"):
@@ -126,6 +131,13 @@ def eesm(sinr_db):
 def final_cqi(cqi_per_prb):
     a = np.ascontiguousarray(cqi_per_prb, np.uint8)
     return lib().rso_final_cqi(_p(a, C.c_uint8), len(a))
+
+
+def clock_ticks(first_tti, n):
+    """Simulated time at the start of scheduled TTIs first_tti .. first_tti + n - 1, as the oracle's run loops form it."""
+    out = np.zeros(n, np.float64)
+    lib().rso_clock_ticks(first_tti, n, _p(out, C.c_double))
+    return out
 
 
 class Rng:
@@ -168,10 +180,13 @@ class TtiOut:
         self.user_tbs_bits = np.zeros(U, np.int32)
         self.upper_rbg = np.full((S, R), -1, np.int32)   # sched 10 only
         self.upper_user = np.full((S, R), -1, np.int32)
+        self.slice_eff = np.zeros((R, S), np.float64)    # transport schedulers: what the inter-slice step reads
+        self.slice_user = np.full((R, S), -1, np.int32)
         self.c = _TtiOut(_p(self.target_rbs, C.c_int), _p(self.quota_rbgs, C.c_int),
                          _p(self.rbg_to_user, C.c_int), _p(self.user_nprb, C.c_int),
                          _p(self.user_final_cqi, C.c_int), _p(self.user_mcs, C.c_int),
-                         _p(self.user_tbs_bits, C.c_int), -1, _p(self.upper_rbg, C.c_int), _p(self.upper_user, C.c_int))
+                         _p(self.user_tbs_bits, C.c_int), -1, _p(self.upper_rbg, C.c_int), _p(self.upper_user, C.c_int),
+                         _p(self.slice_eff, C.c_double), _p(self.slice_user, C.c_int))
 
     @property
     def served_slice(self):
@@ -192,10 +207,10 @@ class Cell:
         self.psi = np.ascontiguousarray(psi if psi is not None else np.ones(S), np.int32)
         self.alpha = np.ascontiguousarray(alpha if alpha is not None else np.zeros(S), np.int32)
         self.beta = np.ascontiguousarray(beta if beta is not None else np.zeros(S), np.int32)
-        cfg = _Config(S, self.U, n_rbgs, rbg_size, sched, _p(self.weights, C.c_double),
-                      _p(self.alpha, C.c_int), _p(self.beta, C.c_int), _p(self.eps, C.c_int),
-                      _p(self.psi, C.c_int), _p(self.u2s, C.c_int))
-        self.h = lib().rso_cell_create(C.byref(cfg))
+        self.cfg = _Config(S, self.U, n_rbgs, rbg_size, sched, _p(self.weights, C.c_double),
+                           _p(self.alpha, C.c_int), _p(self.beta, C.c_int), _p(self.eps, C.c_int),
+                           _p(self.psi, C.c_int), _p(self.u2s, C.c_int))
+        self.h = lib().rso_cell_create(C.byref(self.cfg))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -297,6 +312,21 @@ class Cell:
         if rc:
             raise RuntimeError(f"rso_run_synth rc={rc}")
         return logs
+
+
+def run_synth_many(template, n_cells, cqi_epochs, seeds, n_ttis, threads=0, refresh=40, phy_error_draws=0):
+    """n_cells independent cells configured like `template` (a Cell), OpenMP over the host cores.
+    Returns (total bytes granted, OpenMP team size)."""
+    e = np.ascontiguousarray(cqi_epochs, np.uint8)
+    assert e.shape[1:] == (template.U, template.R)
+    sd = np.ascontiguousarray(seeds, np.uint32)
+    assert sd.shape == (n_cells,)
+    total, used = C.c_int64(0), C.c_int(0)
+    rc = lib().rso_run_synth_many(C.byref(template.cfg), n_cells, _p(e, C.c_uint8), e.shape[0], refresh, _p(sd, C.c_uint),
+                                  phy_error_draws, n_ttis, threads, C.byref(total), C.byref(used))
+    if rc:
+        raise RuntimeError(f"rso_run_synth_many rc={rc}")
+    return int(total.value), int(used.value)
 
 
 def ref_lib(name):

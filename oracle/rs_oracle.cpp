@@ -11,6 +11,8 @@
  */
 #include "rs_oracle.h"
 
+#include <omp.h>
+
 #include <algorithm>
 #include <cassert>
 #include <cmath>
@@ -282,6 +284,9 @@ struct rso_cell {
   std::vector<uint8_t> prio_has_data; /* [U] m_dataToTransmit[slice_priority_[slice]] != 0 */
   std::vector<double> avg2;     /* [U] average rate of the user's second bearer (MAX_BEARERS = 2), < 0: none */
   double eff_of_cqi[16];
+  /* scratch of allocate_transport, kept between TTIs (no per-TTI heap traffic when many cells run on many threads) */
+  std::vector<double> scratch_metrics, scratch_slice_eff, scratch_max_rank;
+  std::vector<int> scratch_user_index;
 };
 
 extern "C" {
@@ -472,15 +477,19 @@ int allocate_transport(rso_cell* c, const double* avg, int rand0, int rand1, rso
   }
   for (int s = 0; s < S; s++) { out->target_rbs[s] = target[s]; out->quota_rbgs[s] = quota[s]; }
   /* :530-539 metric matrix */
-  std::vector<double> metrics((size_t)R * U);
+  std::vector<double>& metrics = c->scratch_metrics;
+  metrics.resize((size_t)R * U);
   for (int i = 0; i < R; i++)
     for (int j = 0; j < U; j++)
       metrics[(size_t)i * U + j] = slice_metric(c, c->u2s[j], c->eff_of_cqi[c->cqi[(size_t)j * R + i]], avg[j], j);
   /* :545-567 best user of every slice in every RBG, strict '>' from -1: first max wins */
-  std::vector<int> user_index((size_t)R * S, -1);
-  std::vector<double> slice_eff((size_t)R * S, 0);
+  std::vector<int>& user_index = c->scratch_user_index;
+  std::vector<double>& slice_eff = c->scratch_slice_eff;
+  std::vector<double>& max_rank = c->scratch_max_rank;
+  user_index.assign((size_t)R * S, -1);
+  slice_eff.assign((size_t)R * S, 0);
   for (int i = 0; i < R; i++) {
-    std::vector<double> max_rank(S, -1);
+    max_rank.assign(S, -1);
     for (int j = 0; j < U; j++) {
       int s = c->u2s[j];
       if (metrics[(size_t)i * U + j] > max_rank[s]) {
@@ -490,6 +499,8 @@ int allocate_transport(rso_cell* c, const double* avg, int rand0, int rand1, rso
       }
     }
   }
+  if (out->slice_eff)
+    for (int i = 0; i < R * S; i++) { out->slice_eff[i] = slice_eff[i]; out->slice_user[i] = user_index[i]; }
   if (c->sched == RSO_SCHED_UPPERBOUND) {
     /* UpperBound, ref: :223-246 and the inter_sched_ >= 4 branch of the apply step :603-616.  Every slice with a positive
      * quota sorts ITS R (rbg, eff) pairs with the same unstable std::sort call and takes its first quota[j] RBGs,
@@ -747,6 +758,17 @@ int rso_cell_step(rso_cell* c, double now, int rand0, int rand1, rso_tti_out* ou
   return rc;
 }
 
+/* The simulated clock: every subframe is scheduled at Now() + 0.001 in double (ref: core/eventScheduler/simulator.cc:117-126
+ * DoSchedule: timeStamp = time + Now(); componentManagers/FrameManager.cpp:186-188), so t_k = fl(t_{k-1} + 0.001) from 0.
+ * Pinned against the reference's own Simulator/Calendar compiled in place (oracle/_ref/libref_clock.so). */
+static inline double clock_advance(double t) { return t + 0.001; }
+
+void rso_clock_ticks(int first_tti, int n, double* out) {
+  double t = 0;
+  for (int k = 0; k < first_tti; k++) t = clock_advance(t);
+  for (int k = 0; k < n; k++) { out[k] = t; t = clock_advance(t); }
+}
+
 static bool uses_rand(int sched) {
   return sched == RSO_SCHED_SEQUENTIAL || sched == RSO_SCHED_MAXCELL || sched == RSO_SCHED_VOGEL || sched == RSO_SCHED_UPPERBOUND ||
          sched == RSO_SCHED_SUBOPT;
@@ -759,11 +781,11 @@ int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_map, int* log_
   rso_srand(&g, run->seed);
   for (long i = 0; i < run->rand_skip; i++) (void)rso_rand(&g);
   std::vector<int> target(S), quota(S), map(R), nprb(U), fcqi(U), mcs(U), tbs(U);
-  rso_tti_out out = {target.data(), quota.data(), map.data(), nprb.data(), fcqi.data(), mcs.data(), tbs.data(), -1, nullptr, nullptr};
+  rso_tti_out out = {target.data(), quota.data(), map.data(), nprb.data(), fcqi.data(), mcs.data(), tbs.data(), -1, nullptr, nullptr, nullptr, nullptr};
   /* simulated time: every event is scheduled at Now()+0.001 in double
    * (simulator.cc:117-126, FrameManager.cpp:186-188): t_k = fl(t_{k-1} + 0.001) */
   double t = 0;
-  for (int k = 0; k < run->first_tti; k++) t += 0.001;
+  for (int k = 0; k < run->first_tti; k++) t = clock_advance(t);
   rso_cell_set_last_update(c, 0.1); /* bearers are created by the application start event at 0.1 s */
   long last_sent = 0;               /* CqiManager::m_lastSent (uninitialised; behaves as 0) */
   bool reported = false;
@@ -796,7 +818,7 @@ int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_map, int* log_
     if (log_quota) memcpy(log_quota + (size_t)n * S, quota.data(), sizeof(int) * S);
     if (log_target) memcpy(log_target + (size_t)n * S, target.data(), sizeof(int) * S);
     if (log_tbs) memcpy(log_tbs + (size_t)n * U, tbs.data(), sizeof(int) * U);
-    t += 0.001;
+    t = clock_advance(t);
   }
   return 0;
 }
@@ -807,9 +829,9 @@ int rso_run_synth(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refr
   rso_rng g;
   rso_srand(&g, seed);
   std::vector<int> target(S), quota(S), map(R), nprb(U), fcqi(U), mcs(U), tbs(U);
-  rso_tti_out out = {target.data(), quota.data(), map.data(), nprb.data(), fcqi.data(), mcs.data(), tbs.data(), -1, nullptr, nullptr};
+  rso_tti_out out = {target.data(), quota.data(), map.data(), nprb.data(), fcqi.data(), mcs.data(), tbs.data(), -1, nullptr, nullptr, nullptr, nullptr};
   double t = 0;
-  for (int k = 0; k < 100; k++) t += 0.001;
+  for (int k = 0; k < 100; k++) t = clock_advance(t);
   rso_cell_set_last_update(c, 0.1);
   int served_prev = 0;
   for (int n = 0; n < n_ttis; n++) {
@@ -828,9 +850,35 @@ int rso_run_synth(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refr
     for (int u = 0; u < U; u++) served_prev += nprb[u] > 0;
     if (log_map) memcpy(log_map + (size_t)n * R, map.data(), sizeof(int) * R);
     if (log_tbs) memcpy(log_tbs + (size_t)n * U, tbs.data(), sizeof(int) * U);
-    t += 0.001;
+    t = clock_advance(t);
   }
   return 0;
+}
+
+/* bench.py's cpu_baseline leg: n_cells independent cells of one configuration, each with its own rand() stream, all reading the
+ * same CQI epochs (read-only), spread over the host cores with OpenMP ("OpenMP over independent cells on all
+ * host cores").  threads <= 0: the OpenMP default.  Returns 0 or the first failing cell's code; *threads_used = team size. */
+int rso_run_synth_many(const rso_config* cfg, int n_cells, const uint8_t* cqi_epochs, int n_epochs, int refresh,
+                       const unsigned* seeds, int phy_error_draws, int n_ttis, int threads, int64_t* total_bytes,
+                       int* threads_used) {
+  int rc_all = 0, used = 1;
+  int64_t bytes = 0;
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : bytes)
+  for (int i = 0; i < n_cells; i++) {
+    if (i == 0) used = omp_get_num_threads();
+    rso_cell* c = rso_cell_create(cfg);
+    int rc = rso_run_synth(c, cqi_epochs, n_epochs, refresh, seeds[i], phy_error_draws, n_ttis, nullptr, nullptr);
+    if (rc) {
+#pragma omp critical
+      if (!rc_all) rc_all = rc;
+    }
+    for (int u = 0; u < c->U; u++) bytes += c->cum_bytes[u];
+    rso_cell_destroy(c);
+  }
+  if (total_bytes) *total_bytes = bytes;
+  if (threads_used) *threads_used = used;
+  return rc_all;
 }
 
 }  // extern "C"

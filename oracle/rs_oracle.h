@@ -102,6 +102,8 @@ typedef struct {
   int served_slice;    /* sched 7: slice chosen by SelectSliceToServe, else -1 */
   int* upper_rbg;      /* optional (may be NULL), sched 10: [S][R] RBGs every slice took, in push order, -1 padded */
   int* upper_user;     /* optional, sched 10: [S][R] the user each of them went to                            */
+  double* slice_eff;   /* optional (may be NULL), sched 8/9/10/101/103: [R][S] flow_spectraleff, what the inter-slice step reads */
+  int* slice_user;     /* optional with slice_eff: [R][S] user_index (-1: the slice has no user)                */
 } rso_tti_out;
 
 rso_cell* rso_cell_create(const rso_config* cfg);
@@ -161,6 +163,14 @@ int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_rbg_to_user, i
  * with `seed`, two draws per TTI (+ the error-model draws if phy_error_draws). */
 int rso_run_synth(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed,
                   int phy_error_draws, int n_ttis, int* log_rbg_to_user, int* log_tbs_bits);
+
+/* the simulated clock at the start of scheduled TTI first_tti + k, k = 0..n-1 (simulator.cc:117-126) */
+void rso_clock_ticks(int first_tti, int n, double* out);
+
+/* many independent cells over the host cores (OpenMP): the cpu_baseline of bench.py */
+int rso_run_synth_many(const rso_config* cfg, int n_cells, const uint8_t* cqi_epochs, int n_epochs, int refresh,
+                       const unsigned* seeds, int phy_error_draws, int n_ttis, int threads, int64_t* total_bytes,
+                       int* threads_used);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,12 @@ class _TtiOut(C.Structure):
                 ("upper_rbg", C.POINTER(C.c_int32)), ("upper_user", C.POINTER(C.c_int32))]
 
 
+class _BatchLog(C.Structure):
+    _fields_ = [("rbg_to_user", C.POINTER(C.c_int16)), ("tbs_bits", C.POINTER(C.c_int32)),
+                ("quota", C.POINTER(C.c_int16)), ("target", C.POINTER(C.c_int16)), ("uinfo", C.POINTER(C.c_int32)),
+                ("slice_keys", C.POINTER(C.c_uint32))]
+
+
 # every symbol include/radiosaber_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "rs_last_error", "rs_abi_version", "rs_device_count", "rs_link_tables",
@@ -77,6 +83,8 @@ ABI_SYMBOLS = [
     "rs_batch_run_timed", "rs_batch_read_state", "rs_batch_slice_bytes_device",
     "rs_batch_slice_bytes", "rs_jit_selfcheck", "rs_batch_debug_stamps", "rs_batch_ttis_done", "rs_batch_stream", "rs_batch_kernel_name",
     "rs_trace_read_mapping", "rs_trace_read_ue_log", "rs_trace_load_dir", "rs_hbm_copy_probe", "rs_lds_bytes_per_cell",
+    "rs_get_rbg_size", "rs_dl_prbs_for_bandwidth", "rs_batch_synthesize_cqi_at", "rs_batch_run_logged_ex",
+    "rs_batch_read_clock", "rs_batch_jit_status",
 ]
 
 _lib = None
@@ -105,6 +113,12 @@ def lib():
     L.rs_batch_seed.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
     L.rs_batch_upload_cqi_epochs.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32]
     L.rs_batch_synthesize_cqi.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.c_int32]
+    L.rs_batch_synthesize_cqi_at.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_double), C.c_int32, C.c_int64]
+    L.rs_batch_run_logged_ex.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_BatchLog)]
+    L.rs_batch_read_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rs_batch_jit_status.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.rs_get_rbg_size.argtypes = [C.c_int]
+    L.rs_dl_prbs_for_bandwidth.argtypes = [C.c_double]
     L.rs_batch_download_cqi_epochs.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint8)]
     L.rs_batch_set_trace.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32,
                                      C.POINTER(C.c_int32)]
@@ -163,6 +177,16 @@ def jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCH
 
 def device_count():
     return lib().rs_device_count()
+
+
+def get_rbg_size(nb_rbs):
+    """PRBs per RBG (ref: src/utility/eesm-effective-sinr.h:82-103); raises above 512 PRBs like the reference throws."""
+    return _count(lib().rs_get_rbg_size(nb_rbs))
+
+
+def dl_prbs_for_bandwidth(bw_mhz):
+    """PRBs of a downlink bandwidth in MHz (ref: src/core/spectrum/bandwidth-manager.cpp:30-38, 52-108)."""
+    return lib().rs_dl_prbs_for_bandwidth(float(bw_mhz))
 
 
 def lds_bytes_per_cell(n_slices, n_users, n_rbgs, sched=RS_SCHED_MAXCELL, threads=512):
@@ -400,10 +424,11 @@ class BatchScheduler:
         _check(lib().rs_batch_upload_cqi_epochs(self._h, _p(a, C.c_uint8), a.shape[1]))
         self.n_epochs = a.shape[1]
 
-    def synthesize_cqi(self, seed, n_epochs, weights=TRACE_CQI_HISTOGRAM):
+    def synthesize_cqi(self, seed, n_epochs, weights=TRACE_CQI_HISTOGRAM, first_cell=0):
+        """Grids drawn on the device, keyed by (seed, first_cell + local cell, epoch, user, rbg)."""
         w = np.ascontiguousarray(weights, np.float64)
         assert w.shape == (15,)
-        _check(lib().rs_batch_synthesize_cqi(self._h, seed, _p(w, C.c_double), n_epochs))
+        _check(lib().rs_batch_synthesize_cqi_at(self._h, seed, _p(w, C.c_double), n_epochs, first_cell))
         self.n_epochs = n_epochs
 
     def download_cqi_epochs(self, cell):
@@ -428,16 +453,24 @@ class BatchScheduler:
     def sync(self):
         _check(lib().rs_batch_sync(self._h))
 
-    def run_logged(self, n_ttis):
+    def run_logged(self, n_ttis, slice_keys=False):
+        """slice_keys=True (transport schedulers) adds what the inter-slice step read: 'slice_cqi' [cells][ttis][R][S]
+        (CQI of the slice's best user, 0 = no user) and 'slice_user' (its id, -1 = none)."""
         m = np.zeros((self.n_cells, n_ttis, self.R), np.int16)
         tb = np.zeros((self.n_cells, n_ttis, self.U), np.int32)
         q = np.zeros((self.n_cells, n_ttis, self.S), np.int16)
         tg = np.zeros((self.n_cells, n_ttis, self.S), np.int16)
         ui = np.zeros((self.n_cells, n_ttis, self.U), np.int32)
-        _check(lib().rs_batch_run_logged(self._h, n_ttis, _p(m, C.c_int16), _p(tb, C.c_int32), _p(q, C.c_int16),
-                                         _p(tg, C.c_int16), _p(ui, C.c_int32)))
-        return {"rbg_to_user": m, "tbs_bits": tb, "quota": q, "target": tg, "nprb": ui & 0xFFFF,
-                "final_cqi": (ui >> 16) & 0xFF, "mcs": (ui >> 24) & 0xFF}
+        keys = np.zeros((self.n_cells, n_ttis, self.R, self.S), np.uint32) if slice_keys else None
+        lg = _BatchLog(_p(m, C.c_int16), _p(tb, C.c_int32), _p(q, C.c_int16), _p(tg, C.c_int16), _p(ui, C.c_int32),
+                       _p(keys, C.c_uint32) if slice_keys else None)
+        _check(lib().rs_batch_run_logged_ex(self._h, n_ttis, C.byref(lg)))
+        out = {"rbg_to_user": m, "tbs_bits": tb, "quota": q, "target": tg, "nprb": ui & 0xFFFF,
+               "final_cqi": (ui >> 16) & 0xFF, "mcs": (ui >> 24) & 0xFF}
+        if slice_keys:
+            out["slice_cqi"] = (keys & 0xFF).astype(np.int32)
+            out["slice_user"] = (keys >> 8).astype(np.int32) - 1
+        return out
 
     def run_timed(self, n_ttis, launches):
         ms = np.zeros(launches, np.float32)
@@ -452,6 +485,19 @@ class BatchScheduler:
         _check(lib().rs_batch_read_state(self._h, _p(avg, C.c_double), _p(cb, C.c_int64), _p(cr, C.c_int64),
                                          _p(sl, C.c_double)))
         return {"avg_rate": avg, "cum_bytes": cb, "cum_rbs": cr, "slice_state": sl}
+
+    def clock(self):
+        """(t, last_update): the simulated time of the next TTI and RadioBearer::m_lastUpdate, per cell."""
+        t = np.zeros(self.n_cells, np.float64)
+        lu = np.zeros(self.n_cells, np.float64)
+        _check(lib().rs_batch_read_clock(self._h, _p(t, C.c_double), _p(lu, C.c_double)))
+        return t, lu
+
+    def jit_status(self):
+        """(code, message): 1 = shape-specialised kernel in use, 0 = not requested, -1 = requested but the build failed."""
+        buf = C.create_string_buffer(512)
+        rc = lib().rs_batch_jit_status(self._h, buf, 512)
+        return rc, buf.value.decode(errors="replace")
 
     def slice_bytes(self):
         out = np.zeros(self.S, np.uint64)

@@ -30,7 +30,7 @@ struct RsJitKernel;
 extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, char* err, size_t errlen);
 extern "C" hipError_t rs_jit_launch(RsJitKernel* k, const RsLaunch* p, hipStream_t stream);
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,
-                                      uint64_t seed, const uint32_t* cdf16, hipStream_t stream);
+                                      uint64_t seed, int64_t first_cell, const uint32_t* cdf16, hipStream_t stream);
 extern "C" hipError_t rs_launch_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t stream);
 extern "C" hipError_t rs_launch_slice_bytes(const int64_t* cum_bytes, const uint8_t* user_slice, int n_cells, int U,
                                             int S, unsigned long long* d_out, hipStream_t stream);
@@ -145,6 +145,29 @@ int rs_device_count(void) {
   return n;
 }
 
+/* ref: src/utility/eesm-effective-sinr.h:82-103 (the reference throws above 512 PRBs) */
+int rs_get_rbg_size(int nb_rbs) {
+  if (nb_rbs < 1) return fail(RS_ERR_INVALID, "nb_rbs %d < 1", nb_rbs);
+  if (nb_rbs <= 10) return 1;
+  if (nb_rbs <= 26) return 2;
+  if (nb_rbs <= 63) return 3;
+  if (nb_rbs <= 110) return 4;
+  if (nb_rbs <= 512) return 8;
+  return fail(RS_ERR_INVALID, "nb_rbs %d > 512: the reference's get_rbg_size throws", nb_rbs);
+}
+
+/* ref: src/core/spectrum/bandwidth-manager.cpp:30-38, 52-108: PRBs of a downlink bandwidth; any other value falls back to 5 MHz */
+int rs_dl_prbs_for_bandwidth(double bw_mhz) {
+  if (bw_mhz == 1.4) return 6;
+  if (bw_mhz == 3) return 15;
+  if (bw_mhz == 5) return 25;
+  if (bw_mhz == 10) return 50;
+  if (bw_mhz == 15) return 75;
+  if (bw_mhz == 20) return 100;
+  if (bw_mhz == 100) return 512;
+  return 25;
+}
+
 int rs_link_tables(double eff[16], double kbps[16], double eesm_e[16], double eesm_x[16]) {
   eff[0] = kbps[0] = eesm_e[0] = eesm_x[0] = 0;
   for (int c = 1; c <= 15; c++) {
@@ -216,6 +239,8 @@ struct rs_batch {
   unsigned long long* d_slice_bytes = nullptr;
   unsigned long long* d_stamps = nullptr;
   RsJitKernel* jit = nullptr; /* shape-specialised kernel (owned by the process-wide cache) */
+  bool jit_wanted = false;
+  char jit_msg[512] = ""; /* why the shape-specialised kernel is not in use (empty: it is, or it was not asked for) */
   int64_t ttis_done = 0;
   RsLaunch base{};
 };
@@ -231,7 +256,7 @@ int validate(const rs_config* c, bool direct) {
   if (c->n_rbgs * c->rbg_size > 512) return fail(RS_ERR_INVALID, "more than 512 PRBs (reference get_rbg_size throws)");
   if (c->sched != RS_SCHED_PF && c->sched != RS_SCHED_NVS && c->sched != RS_SCHED_SEQUENTIAL && c->sched != RS_SCHED_MAXCELL &&
       c->sched != RS_SCHED_VOGEL && c->sched != RS_SCHED_SUBOPT && c->sched != RS_SCHED_UPPERBOUND && c->sched != RS_SCHED_NVS_NONGREEDY)
-    return fail(RS_ERR_INVALID, "sched %d not supported (1, 7, 8, 9)", c->sched);
+    return fail(RS_ERR_INVALID, "sched %d not supported (1, 7, 8, 9, 10, 11, 101, 103)", c->sched);
   if (!c->slice_weight || !c->algo_alpha || !c->algo_epsilon || !c->algo_psi || !c->user_to_slice)
     return fail(RS_ERR_INVALID, "null slice/user array");
   for (int s = 0; s < c->n_slices; s++) {
@@ -336,6 +361,8 @@ int batch_alloc(rs_batch* b) {
         else v = 5 * kTbs[nprb / 5 - 1][i] + (nprb % 5 == 0 ? t.tbs_row_m1[i] : kTbs[nprb % 5 - 1][i]);
         te[(size_t)n * 27 + i] = v;
       }
+    for (int32_t v : te)
+      if (v / 8 > RS_TX_BYTES_MASK) return fail(RS_ERR_INVALID, "a transport block of %d bits does not fit the packed tx word", v);
     HIP_TRY(hipMalloc(&b->d_tbs_eff, 4 * te.size()));
     HIP_TRY(hipMemcpy(b->d_tbs_eff, te.data(), 4 * te.size(), hipMemcpyHostToDevice));
   }
@@ -432,8 +459,12 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   int want_jit = cfg->jit;
   if (const char* e = getenv("RS_JIT")) want_jit = atoi(e);
   if (want_jit && !direct) {
-    /* failure is not an error: g_err keeps the reason, the built-in kernels stay in use */
-    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, g_err, sizeof g_err);
+    /* failure is not an error of this call: the built-in kernels stay in use and the batch keeps the reason
+     * (rs_batch_jit_status); rs_last_error() is left alone */
+    b->jit_wanted = true;
+    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, b->jit_msg, sizeof b->jit_msg);
+    if (b->jit) b->jit_msg[0] = 0;
+    else if (!b->jit_msg[0]) snprintf(b->jit_msg, sizeof b->jit_msg, "hiprtc build failed");
   }
   return b;
 }
@@ -444,16 +475,13 @@ int check_device_err(rs_batch* b) {
   HIP_TRY(hipMemcpy(&e, b->d_err, 4, hipMemcpyDeviceToHost));
   if (e) {
     HIP_TRY(hipMemset(b->d_err, 0, 4));
-#ifdef RS_STAMPS
-  HIP_TRY(hipMalloc(&b->d_stamps, 8 * 20 * (size_t)b->n_cells));
-  HIP_TRY(hipMemset(b->d_stamps, 0, 8 * 20 * (size_t)b->n_cells));
-#endif
     return fail(RS_ERR_RANGE, e == RS_CQI_EPOCHS ? "ran past the last CQI epoch" : "trace row outside the uploaded rows");
   }
   return RS_OK;
 }
 
-int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d_target, int32_t* d_tbs, int32_t* d_uinfo) {
+int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d_target, int32_t* d_tbs, int32_t* d_uinfo,
+           uint32_t* d_keys = nullptr) {
   if (n_ttis < 1) return fail(RS_ERR_INVALID, "n_ttis %d < 1", n_ttis);
   if (b->cqi_mode == RS_CQI_NONE) return fail(RS_ERR_STATE, "no CQI source set");
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
@@ -464,6 +492,7 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
   L.trace = b->d_trace; L.n_traces = b->n_traces; L.n_rows = b->n_rows; L.row_mod = b->row_mod;
   L.user_trace = b->d_user_trace;
   L.log_map = d_map; L.log_quota = d_quota; L.log_target = d_target; L.log_tbs = d_tbs; L.log_uinfo = d_uinfo;
+  L.log_keys = d_keys;
   if (b->jit) HIP_TRY(rs_jit_launch(b->jit, &L, b->stream));
   else HIP_TRY(rs_launch_cells(&L, b->threads, b->stream));
   b->ttis_done += n_ttis;
@@ -514,7 +543,11 @@ int rs_batch_upload_cqi_epochs(rs_batch* b, const uint8_t* h_cqi, int32_t n_epoc
 }
 
 int rs_batch_synthesize_cqi(rs_batch* b, uint64_t seed, const double* w, int32_t n_epochs) {
-  if (!b || !w || n_epochs < 1) return fail(RS_ERR_INVALID, "bad argument");
+  return rs_batch_synthesize_cqi_at(b, seed, w, n_epochs, 0);
+}
+
+int rs_batch_synthesize_cqi_at(rs_batch* b, uint64_t seed, const double* w, int32_t n_epochs, int64_t first_cell) {
+  if (!b || !w || n_epochs < 1 || first_cell < 0) return fail(RS_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   double tot = 0;
   for (int i = 0; i < 15; i++) {
@@ -535,7 +568,7 @@ int rs_batch_synthesize_cqi(rs_batch* b, uint64_t seed, const double* w, int32_t
   const size_t bytes = (size_t)b->n_cells * n_epochs * stride;
   if (b->d_epochs) { HIP_TRY(hipFree(b->d_epochs)); b->d_epochs = nullptr; }
   HIP_TRY(hipMalloc(&b->d_epochs, bytes));
-  HIP_TRY(rs_launch_synth(b->d_epochs, (int64_t)stride, b->n_cells, n_epochs, b->U, b->R, seed, cdf, b->stream));
+  HIP_TRY(rs_launch_synth(b->d_epochs, (int64_t)stride, b->n_cells, n_epochs, b->U, b->R, seed, first_cell, cdf, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->grid_stride = (int64_t)stride;
   b->n_epochs = n_epochs;
@@ -597,28 +630,41 @@ int rs_batch_run(rs_batch* b, int32_t n_ttis) {
 
 int rs_batch_run_logged(rs_batch* b, int32_t n_ttis, int16_t* h_map, int32_t* h_tbs, int16_t* h_quota,
                         int16_t* h_target, int32_t* h_uinfo) {
-  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  rs_batch_log lg;
+  memset(&lg, 0, sizeof lg);
+  lg.rbg_to_user = h_map; lg.tbs_bits = h_tbs; lg.quota = h_quota; lg.target = h_target; lg.uinfo = h_uinfo;
+  return rs_batch_run_logged_ex(b, n_ttis, &lg);
+}
+
+int rs_batch_run_logged_ex(rs_batch* b, int32_t n_ttis, const rs_batch_log* lg) {
+  if (!b || !lg) return fail(RS_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   if (n_ttis < 1) return fail(RS_ERR_INVALID, "n_ttis %d < 1", n_ttis);
+  const bool transport = b->sched == RS_SCHED_SEQUENTIAL || b->sched == RS_SCHED_MAXCELL || b->sched == RS_SCHED_UPPERBOUND ||
+                         b->sched == RS_SCHED_SUBOPT || b->sched == RS_SCHED_VOGEL;
+  if (lg->slice_keys && !transport) return fail(RS_ERR_INVALID, "slice_keys: only the DownlinkTransportScheduler policies have them");
   const size_t rows = (size_t)b->n_cells * n_ttis;
   int16_t *d_map = nullptr, *d_quota = nullptr, *d_target = nullptr;
   int32_t *d_tbs = nullptr, *d_uinfo = nullptr;
+  uint32_t* d_keys = nullptr;
   ScratchBuffers scratch;
   HIP_TRY(scratch.alloc(&d_map, 2 * rows * b->R));
   HIP_TRY(scratch.alloc(&d_quota, 2 * rows * b->S));
   HIP_TRY(scratch.alloc(&d_target, 2 * rows * b->S));
   HIP_TRY(scratch.alloc(&d_tbs, 4 * rows * b->U));
   HIP_TRY(scratch.alloc(&d_uinfo, 4 * rows * b->U));
+  if (lg->slice_keys) HIP_TRY(scratch.alloc(&d_keys, 4 * rows * b->R * b->S));
   HIP_TRY(hipMemsetAsync(d_tbs, 0, 4 * rows * b->U, b->stream));
   HIP_TRY(hipMemsetAsync(d_uinfo, 0, 4 * rows * b->U, b->stream));
-  int rc = launch(b, n_ttis, d_map, d_quota, d_target, d_tbs, d_uinfo);
+  int rc = launch(b, n_ttis, d_map, d_quota, d_target, d_tbs, d_uinfo, d_keys);
   if (!rc) rc = rs_batch_sync(b);
   if (!rc) {
-    if (h_map) HIP_TRY(hipMemcpy(h_map, d_map, 2 * rows * b->R, hipMemcpyDeviceToHost));
-    if (h_quota) HIP_TRY(hipMemcpy(h_quota, d_quota, 2 * rows * b->S, hipMemcpyDeviceToHost));
-    if (h_target) HIP_TRY(hipMemcpy(h_target, d_target, 2 * rows * b->S, hipMemcpyDeviceToHost));
-    if (h_tbs) HIP_TRY(hipMemcpy(h_tbs, d_tbs, 4 * rows * b->U, hipMemcpyDeviceToHost));
-    if (h_uinfo) HIP_TRY(hipMemcpy(h_uinfo, d_uinfo, 4 * rows * b->U, hipMemcpyDeviceToHost));
+    if (lg->rbg_to_user) HIP_TRY(hipMemcpy(lg->rbg_to_user, d_map, 2 * rows * b->R, hipMemcpyDeviceToHost));
+    if (lg->quota) HIP_TRY(hipMemcpy(lg->quota, d_quota, 2 * rows * b->S, hipMemcpyDeviceToHost));
+    if (lg->target) HIP_TRY(hipMemcpy(lg->target, d_target, 2 * rows * b->S, hipMemcpyDeviceToHost));
+    if (lg->tbs_bits) HIP_TRY(hipMemcpy(lg->tbs_bits, d_tbs, 4 * rows * b->U, hipMemcpyDeviceToHost));
+    if (lg->uinfo) HIP_TRY(hipMemcpy(lg->uinfo, d_uinfo, 4 * rows * b->U, hipMemcpyDeviceToHost));
+    if (lg->slice_keys) HIP_TRY(hipMemcpy(lg->slice_keys, d_keys, 4 * rows * b->R * b->S, hipMemcpyDeviceToHost));
   }
   return rc;
 }
@@ -651,6 +697,25 @@ int rs_batch_read_state(rs_batch* b, double* avg, int64_t* cum_bytes, int64_t* c
   if (cum_rbs) HIP_TRY(hipMemcpy(cum_rbs, b->d_cumr, 8 * n, hipMemcpyDeviceToHost));
   if (slice_state) HIP_TRY(hipMemcpy(slice_state, b->d_sstate, 8 * (size_t)b->n_cells * b->S, hipMemcpyDeviceToHost));
   return RS_OK;
+}
+
+int rs_batch_read_clock(rs_batch* b, double* t, double* last_update) {
+  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  std::vector<RsCellScalars> sc(b->n_cells);
+  HIP_TRY(hipMemcpy(sc.data(), b->d_scal, sizeof(RsCellScalars) * b->n_cells, hipMemcpyDeviceToHost));
+  for (int c = 0; c < b->n_cells; c++) {
+    if (t) t[c] = sc[c].t;
+    if (last_update) last_update[c] = sc[c].last_update;
+  }
+  return RS_OK;
+}
+
+int rs_batch_jit_status(rs_batch* b, char* msg, size_t msglen) {
+  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  if (msg && msglen) snprintf(msg, msglen, "%s", b->jit_msg);
+  return b->jit ? 1 : (b->jit_wanted ? -1 : 0);
 }
 
 int rs_batch_slice_bytes_device(rs_batch* b, uint64_t* d_out) {

@@ -21,6 +21,11 @@ typedef unsigned long size_t;
 #endif
 
 #define RS_WAVE 64
+/* tx word of a shape-specialised batch kernel: bytes granted since the last EWMA update | PRBs << 20 | "counted" << 30 */
+#define RS_TX_BYTES_MASK 0xFFFFF
+#define RS_TX_NPRB_SHIFT 20
+#define RS_TX_NPRB_MASK 0x3FF
+#define RS_TX_COUNTED (1 << 30)
 #define RS_PF_SEG 32 /* sched 1: users are scanned in segments of this many for the per-RBG argmax */
 
 /* per-cell scratch in LDS (host needs its size for the LDS carve) */
@@ -191,6 +196,7 @@ struct RsLaunch {
   int16_t* log_target;       /* [cells][n_ttis][S] */
   int32_t* log_tbs;          /* [cells][n_ttis][U], pre-zeroed */
   int32_t* log_uinfo;        /* [cells][n_ttis][U], pre-zeroed: nprb | final_cqi<<16 | mcs<<24 */
+  uint32_t* log_keys;        /* [cells][n_ttis][R][S] transport schedulers: CQI key of the slice's best user | (user+1)<<8 */
   int32_t* err;              /* device error word */
   unsigned long long* stamps; /* diagnostic build (-DRS_STAMPS): [cells][20] phase cycles, else unused */
   /* LDS carve (byte offsets from the dynamic LDS base) */

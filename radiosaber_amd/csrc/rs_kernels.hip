@@ -124,8 +124,33 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   const RsTables* tab = p.tab;
   RsCellScalars* scal = p.scal + cell;
 
+  /* RadioBearer::m_cumulativeBytes / m_cumulativeRBs (ref: src/flows/radio-bearer.cpp:100-124).  A shape-specialised build
+   * keeps them in registers of the thread that owns the user in P1: the serving lane of P5 leaves bytes | nPRB << 20 in
+   * s_tx[u], the owner unpacks it when the next EWMA update consumes it, and the totals go to HBM once per launch (the
+   * built-in kernels, whose users-per-thread count is a run-time value, add to HBM with fire-and-forget atomics instead).
+   * Bit 30 of the stored tx word: "already in the HBM totals" (the last TTI's service, flushed with the launch). */
+  constexpr bool kCumRegs = FIXED && !DIRECT;
+  constexpr int kKU = kCumRegs ? (RS_JIT_U + RS_JIT_NT - 1) / RS_JIT_NT : 1;
+  long long cum_b[kKU], cum_r[kKU];
+#pragma unroll
+  for (int k = 0; k < kKU; ++k) { cum_b[k] = 0; cum_r[k] = 0; }
   /* ---------------- load the cell ---------------- */
-  for (int u = tid; u < U; u += nt) {
+#pragma unroll
+  for (int ku = 0; ku < (kCumRegs ? kKU : 1); ++ku) {
+    if (!kCumRegs) break;
+    const int u = tid + ku * nt;
+    if (u < U) {
+      s_avg[u] = p.avg[(size_t)cell * U + u];
+      int v = p.tx_bytes[(size_t)cell * U + u];
+      if (v & RS_TX_COUNTED) { /* counted by the previous launch's flush: the consumption below must not count it again */
+        cum_b[ku] -= v & RS_TX_BYTES_MASK;
+        cum_r[ku] -= (v >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK;
+        v &= ~RS_TX_COUNTED;
+      }
+      s_tx[u] = v;
+    }
+  }
+  for (int u = tid; u < U && !kCumRegs; u += nt) {
     s_avg[u] = p.avg[(size_t)cell * U + u];
     s_tx[u] = p.tx_bytes[(size_t)cell * U + u];
     if (kDirect) { /* rs_schedule_tti: one row of per-user outputs, cleared here instead of by a memset */
@@ -276,10 +301,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     {
       const bool do_ewma = !kDirect && !(t == last_update);
       const double dt = t - last_update;
-      for (int u = tid, ku = 0; u < U; u += nt, ++ku) {
+      auto ewma_user = [&](int u, int ku) {
         double a = s_avg[u];
         if (do_ewma) {
-          double rate = (double)(s_tx[u] * 8) / dt;
+          int txb = s_tx[u];
+          if (kCumRegs) {
+            cum_r[ku < kKU ? ku : 0] += (txb >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK;
+            txb &= RS_TX_BYTES_MASK;
+            cum_b[ku < kKU ? ku : 0] += txb;
+          }
+          double rate = (double)(txb * 8) / dt;
           const double beta = 0.02;
           a = ((1 - beta) * a) + (beta * rate);
           if (a < 1) a = 1;
@@ -308,6 +339,13 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         } else {
           s_rcp32[u] = __builtin_amdgcn_rcpf((float)a);
         }
+      };
+      if constexpr (kCumRegs) {
+#pragma unroll
+        for (int ku = 0; ku < kKU; ++ku)
+          if (tid + ku * nt < U) ewma_user(tid + ku * nt, ku);
+      } else {
+        for (int u = tid, ku = 0; u < U; u += nt, ++ku) ewma_user(u, ku);
       }
       if (!kDirect) last_update = t;
     }
@@ -709,6 +747,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       }
     }
     __syncthreads();
+    if (kTransport && p.log_keys) {
+      /* parity tests only: what the inter-slice step is about to read, [R][S] per TTI: CQI key of the slice's best user
+       * (0: no user) | (user + 1) << 8 -- flow_spectraleff / user_index of ref :545-567 */
+      for (int i = tid; i < R * S; i += nt) {
+        const int r = SCHED == 10 ? i % R : i / S, sg = SCHED == 10 ? i / R : i % S;
+        const int bu = s_best_user[sg * R + r];
+        p.log_keys[((size_t)cell * p.n_ttis + tti) * R * S + r * S + sg] = (s_elems[i] >> 16) | ((bu == 0xFFFF ? 0u : (uint32_t)bu + 1u) << 8);
+      }
+    }
     RS_STAMP(2);
 
     /* ---------------- P4: inter-slice assignment ---------------- */
@@ -825,9 +872,13 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         int bytes = tbs / 8;
         if (bytes > 100000000) bytes = 100000000;
         if (bytes > 0) {
-          s_tx[u] += bytes;
-          atomicAdd((unsigned long long*)&p.cum_bytes[(size_t)cell * U + u], (unsigned long long)bytes);
-          atomicAdd((unsigned long long*)&p.cum_rbs[(size_t)cell * U + u], (unsigned long long)nprb);
+          if (kCumRegs) {
+            s_tx[u] += bytes | (nprb << RS_TX_NPRB_SHIFT);
+          } else {
+            s_tx[u] += bytes;
+            atomicAdd((unsigned long long*)&p.cum_bytes[(size_t)cell * U + u], (unsigned long long)bytes);
+            atomicAdd((unsigned long long*)&p.cum_rbs[(size_t)cell * U + u], (unsigned long long)nprb);
+          }
         }
         atomicAdd(&m->served, 1);
         if (p.log_map) {
@@ -963,10 +1014,14 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           int bytes = tbs / 8;
           if (bytes > 100000000) bytes = 100000000;
           if (bytes > 0) {
-            s_tx[owner] += bytes;
-            /* RadioBearer::m_cumulativeBytes / m_cumulativeRBs live in HBM: fire-and-forget atomics */
-            atomicAdd((unsigned long long*)&p.cum_bytes[(size_t)cell * U + owner], (unsigned long long)bytes);
-            atomicAdd((unsigned long long*)&p.cum_rbs[(size_t)cell * U + owner], (unsigned long long)nprb);
+            if (kCumRegs) {
+              s_tx[owner] += bytes | (nprb << RS_TX_NPRB_SHIFT); /* the owner thread of P1 counts it (registers) */
+            } else {
+              s_tx[owner] += bytes;
+              /* RadioBearer::m_cumulativeBytes / m_cumulativeRBs live in HBM: fire-and-forget atomics */
+              atomicAdd((unsigned long long*)&p.cum_bytes[(size_t)cell * U + owner], (unsigned long long)bytes);
+              atomicAdd((unsigned long long*)&p.cum_rbs[(size_t)cell * U + owner], (unsigned long long)nprb);
+            }
           }
         }
       }
@@ -999,7 +1054,21 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   }
 
   /* ---------------- store the cell ---------------- */
-  for (int u = tid; u < U; u += nt) {
+#pragma unroll
+  for (int ku = 0; ku < (kCumRegs ? kKU : 1); ++ku) {
+    if (!kCumRegs) break;
+    const int u = tid + ku * nt;
+    if (u < U) {
+      /* totals = what the EWMA updates consumed + the last TTI's service still waiting in s_tx (marked as counted) */
+      const int v = s_tx[u];
+      const long long b = cum_b[ku] + (v & RS_TX_BYTES_MASK), r = cum_r[ku] + ((v >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK);
+      if (b != 0) p.cum_bytes[(size_t)cell * U + u] += b;
+      if (r != 0) p.cum_rbs[(size_t)cell * U + u] += r;
+      p.avg[(size_t)cell * U + u] = s_avg[u];
+      p.tx_bytes[(size_t)cell * U + u] = v ? (v | RS_TX_COUNTED) : 0;
+    }
+  }
+  for (int u = tid; u < U && !kCumRegs; u += nt) {
     p.avg[(size_t)cell * U + u] = s_avg[u];
     p.tx_bytes[(size_t)cell * U + u] = s_tx[u];
   }
@@ -1061,7 +1130,7 @@ struct RsCdf {
 };
 
 __global__ void rs_synth_cqi_kernel(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U,
-                                    int R, uint64_t seed, RsCdf cdf) {
+                                    int R, uint64_t seed, int64_t first_cell, RsCdf cdf) {
   const int64_t grids = (int64_t)n_cells * n_epochs;
   const int64_t per_grid16 = grid_stride >> 4;
   const int64_t total = grids * per_grid16;
@@ -1074,7 +1143,10 @@ __global__ void rs_synth_cqi_kernel(uint8_t* epochs, int64_t grid_stride, int n_
       int64_t idx = o + k;
       uint8_t v = 0;
       if (idx < (int64_t)U * R) {
-        uint64_t h = splitmix64(seed ^ splitmix64((uint64_t)g * 0x100000001B3ull + (uint64_t)idx));
+        /* keyed by (seed, GLOBAL cell id, epoch, user, rbg): a cell's grids do not depend on how the cells are sharded over
+         * ranks nor on how many epochs were generated */
+        const uint64_t gcell = (uint64_t)(first_cell + g / n_epochs), ep = (uint64_t)(g % n_epochs);
+        uint64_t h = splitmix64(seed ^ splitmix64(splitmix64(gcell * 0x100000001B3ull + ep) + (uint64_t)idx));
         uint32_t x = (uint32_t)(h >> 32);
         int q = 0;
 #pragma unroll
@@ -1162,7 +1234,7 @@ extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes) {
 }
 
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,
-                                      uint64_t seed, const uint32_t* cdf16, hipStream_t stream) {
+                                      uint64_t seed, int64_t first_cell, const uint32_t* cdf16, hipStream_t stream) {
   RsCdf cdf;
   for (int i = 0; i < 16; ++i) cdf.c[i] = cdf16[i];
   int64_t total = (int64_t)n_cells * n_epochs * (grid_stride >> 4);
@@ -1170,7 +1242,7 @@ extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int 
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(rs_synth_cqi_kernel, dim3(blocks), dim3(256), 0, stream, epochs, grid_stride, n_cells, n_epochs,
-                     U, R, seed, cdf);
+                     U, R, seed, first_cell, cdf);
   return hipGetLastError();
 }
 

@@ -18,14 +18,17 @@ def cell_ids_for_rank(rank: int, world: int, cells_per_rank: int) -> np.ndarray:
 
 
 def seeds_for_cells(cell_ids: np.ndarray) -> np.ndarray:
-    """srand() argument of every cell: a fixed function of the GLOBAL cell id, so a cell's whole
-    trajectory is independent of how many ranks the job runs on."""
+    """srand() argument of every cell: a fixed function of the GLOBAL cell id.  Together with the synthetic CQI grids,
+    which the device generator keys on the global cell id too (BatchScheduler.synthesize_cqi(first_cell=...)), a cell's
+    whole trajectory is independent of how many ranks the job runs on (tests/test_gpu_round2.py checks it on the GPU)."""
     g = np.asarray(cell_ids, np.uint64)
     return ((g * np.uint64(2654435761) + np.uint64(SEED_BASE)) % np.uint64(2**31 - 1)).astype(np.uint32)
 
 
-def cqi_seed_for_cell_block(base_seed: int, rank: int) -> int:
-    return (base_seed + 0x9E3779B1 * rank) & 0xFFFFFFFFFFFFFFFF
+def first_cell_for_rank(rank: int, world: int, cells_per_rank: int) -> int:
+    """Global id of the rank's first cell: the `first_cell` argument of BatchScheduler.synthesize_cqi (one base seed on
+    every rank)."""
+    return int(cell_ids_for_rank(rank, world, cells_per_rank)[0])
 
 
 def all_reduce_slice_bytes(t, dist=None):

@@ -15,6 +15,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_usable():
+    """A HIP device and the built library (device_count() never initialises a context)."""
+    try:
+        import radiosaber_amd
+        return radiosaber_amd.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests/` on a box without an MI355X must show the CPU-side results, not RS_ERR_NO_DEVICE noise: gpu tests are
+    skipped there (the GPU box runs them with -m gpu; the product itself has no CPU path to fall back to)."""
+    if any("gpu" in it.keywords for it in items) and not _gpu_usable():
+        skip = pytest.mark.skip(reason="no MI355X visible (gpu tests run with -m gpu on the GPU box)")
+        for it in items:
+            if "gpu" in it.keywords:
+                it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure), built on demand."""

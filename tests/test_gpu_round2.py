@@ -1,0 +1,174 @@
+"""GPU tests added in round 2 (through the C ABI): reference-compiled pins exercised on the device's own values, the
+multi-GPU sharding on real device results, the register-resident cumulative counters, RCCL loaded once."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, synth_cqi
+from test_oracle_pins import cqi_keys_of_eff, ref_maximize_cell
+
+pytestmark = pytest.mark.gpu
+
+HIST = (152600, 56656, 270880, 2088792, 3509504, 1595568, 4145392, 5295816, 1903424,
+        6890232, 4770864, 2842552, 3579624, 96000, 1227696)
+
+
+@pytest.mark.parametrize("jit", [False, True])
+def test_device_clock_matches_reference_event_core(rs, jit):
+    """t_k and m_lastUpdate on the device against the time stamps the reference's own Simulator/Calendar produced
+    (tests/golden/ref_clock.json, recorded from oracle/_ref/libref_clock.so), over launches of uneven length."""
+    ref = np.array([float.fromhex(x) for x in json.loads((GOLDEN / "ref_clock.json").read_text())["subframe_start"]])
+    sc = rs.SliceConfig([5] * 4)
+    b = rs.BatchScheduler(sc, 12, 2, 3, sched=9, jit=jit)
+    b.seed(np.arange(3, dtype=np.uint32) + 1)
+    b.synthesize_cqi(5, 16)
+    t, lu = b.clock()
+    assert (t == ref[100]).all() and (lu == 0.1).all()
+    done = 0
+    for n in (1, 39, 2, 158, 77, 300):
+        b.run(n)
+        done += n
+        t, lu = b.clock()
+        assert (t == ref[100 + done]).all(), done
+        assert (lu == ref[100 + done - 1]).all(), done
+    b.close()
+
+
+@pytest.mark.parametrize("shape", [([5] * 20, 25, 4), ([25] * 20, 25, 4), ([5] * 20, 64, 8)])
+def test_maximize_cell_on_device_tti_inputs_matches_reference_unit_code(rs, oracle, shape):
+    """The (flow_spectraleff, quota) the DEVICE handed to its inter-slice step, TTI by TTI, go through the reference's own
+    MaximizeCell (unittest/test_tp_algos.cpp compiled in place, oracle/_ref/libref_tp_algos.so): the RBG -> slice map it
+    returns must be the one the device applied.  The same dump is compared with the oracle's flow_spectraleff /
+    user_index, which pins the metric + arg-max stage (a5, a6) at the intermediate level too."""
+    L = oracle.ref_lib("libref_tp_algos.so")
+    if L is None:
+        pytest.skip("oracle/_ref/libref_tp_algos.so did not travel")
+    ues, R, G = shape
+    n_cells, n_ttis = 2, 90
+    sc = rs.SliceConfig(ues)
+    grids = synth_cqi(21, (n_cells, 3, sc.n_users, R), HIST)
+    seeds = np.arange(n_cells, dtype=np.uint32) + 4242
+    for jit in (False, True):
+        b = rs.BatchScheduler(sc, R, G, n_cells, sched=9, jit=jit)
+        b.seed(seeds)
+        b.upload_cqi_epochs(grids)
+        got = b.run_logged(n_ttis, slice_keys=True)
+        b.close()
+        u2s = sc.user_to_slice
+        for c in range(n_cells):
+            cell = oracle.Cell(ues, R, G, oracle.SCHED_MAXCELL)
+            g = oracle.Rng(int(seeds[c]))
+            ticks = oracle.clock_ticks(100, n_ttis)
+            cell.set_last_update(0.1)
+            out = cell.new_out()
+            for n in range(n_ttis):
+                if n % 40 == 0:
+                    cell.set_cqi(grids[c, n // 40])
+                assert cell.step(float(ticks[n]), g.rand(), g.rand(), out) == 0
+                keys = np.ascontiguousarray(got["slice_cqi"][c, n], np.int32)
+                assert (keys == cqi_keys_of_eff(out.slice_eff)).all(), (c, n)
+                assert (got["slice_user"][c, n] == out.slice_user).all(), (c, n)
+                want = ref_maximize_cell(L, keys, got["quota"][c, n].astype(np.int32))
+                m = got["rbg_to_user"][c, n].astype(np.int64)
+                dev = np.where(m >= 0, u2s[np.maximum(m, 0)], -1)
+                assert (dev == want).all(), (c, n)
+
+
+def _run_shard(rs, sharding, sc, R, G, rank, world, cells_per_rank, n_ttis, jit):
+    b = rs.BatchScheduler(sc, R, G, cells_per_rank, sched=9, jit=jit)
+    b.seed(sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, cells_per_rank)))
+    b.synthesize_cqi(0x5AB3, (n_ttis + 39) // 40, first_cell=sharding.first_cell_for_rank(rank, world, cells_per_rank))
+    grids = [b.download_cqi_epochs(c) for c in range(cells_per_rank)]
+    b.run(n_ttis)
+    st, sb = b.state(), b.slice_bytes()
+    b.close()
+    return st, sb, grids
+
+
+@pytest.mark.parametrize("jit", [False, True])
+def test_cell_trajectories_do_not_depend_on_the_sharding(rs, jit):
+    """Global cells 0..7 as ONE batch and as W = 2 shards of 4 (what bench.py does per rank): identical CQI grids,
+    per-cell counters and PF state, and the per-slice byte totals add up exactly (the vector RCCL all-reduces)."""
+    from radiosaber_amd import sharding
+    sc = rs.SliceConfig([5] * 20)
+    R, G, n_ttis = 25, 4, 130
+    one, sb_one, g_one = _run_shard(rs, sharding, sc, R, G, 0, 1, 8, n_ttis, jit)
+    total = np.zeros(20, np.uint64)
+    for rank in range(2):
+        st, sb, g = _run_shard(rs, sharding, sc, R, G, rank, 2, 4, n_ttis, jit)
+        sl = slice(4 * rank, 4 * rank + 4)
+        for c in range(4):
+            assert (g[c] == g_one[4 * rank + c]).all()
+        assert (st["cum_bytes"] == one["cum_bytes"][sl]).all() and (st["cum_rbs"] == one["cum_rbs"][sl]).all()
+        assert st["avg_rate"].tobytes() == one["avg_rate"][sl].tobytes()
+        total += sb
+    assert (total == sb_one).all() and int(sb_one.sum()) == int(one["cum_bytes"].sum())
+
+
+def test_cumulative_counters_in_registers_across_launches(rs, oracle):
+    """The shape-specialised kernel keeps cumu_bytes / cumu_rbs in registers and flushes once per launch; the service of a
+    launch's last TTI is counted at the flush and must not be counted again by the next launch's first EWMA update.
+    1-TTI launches, uneven launches and one long launch must all equal the oracle, for 1 and 2 users per thread."""
+    ues, R, G = [25] * 20, 25, 4
+    sc = rs.SliceConfig(ues)
+    grids = synth_cqi(8, (1, 4, sc.n_users, R), HIST)
+    cell = oracle.Cell(ues, R, G, oracle.SCHED_MAXCELL)
+    cell.run_synth(grids[0], 99, 150, log=False)
+    want = cell.state()
+    for threads, plan in ((512, [150]), (512, [1] * 7 + [143]), (256, [40, 1, 1, 68, 40]), (64, [75, 75])):
+        b = rs.BatchScheduler(sc, R, G, 1, sched=9, jit=True, threads_per_cell=threads)
+        assert b.jit_status()[0] == 1, b.jit_status()
+        b.seed(np.array([99], np.uint32))
+        b.upload_cqi_epochs(grids)
+        done = 0
+        for n in plan:
+            b.run(n)
+            done += n
+            st = b.state()
+            assert int(st["cum_rbs"].sum()) == done * R * G  # every RBG granted every TTI, visible after every launch
+        assert (st["cum_bytes"][0] == want["cum_bytes"]).all() and (st["cum_rbs"][0] == want["cum_rbs"]).all()
+        assert st["avg_rate"][0].tobytes() == want["avg_rate"].tobytes()
+        b.close()
+
+
+def test_jit_status_is_reported(rs):
+    sc = rs.SliceConfig([5] * 4)
+    b = rs.BatchScheduler(sc, 12, 2, 1, sched=9, jit=True)
+    assert b.jit_status() == (1, "") and b.kernel_name == "rs_cell_kernel_jit"
+    b.close()
+    b = rs.BatchScheduler(sc, 12, 2, 1, sched=9, jit=False)
+    assert b.jit_status()[0] == 0 and b.kernel_name != "rs_cell_kernel_jit"
+    b.close()
+
+
+def test_rccl_single_rank_all_reduce_of_slice_bytes(rs):
+    """RCCL loaded and used once on this box: a one-rank `nccl` process group all-reduces the device-resident uint64[S]
+    per-slice byte vector exactly as bench.py's N > 1 path does."""
+    import torch
+    import torch.distributed as dist
+    from radiosaber_amd import sharding
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sc = rs.SliceConfig([5] * 20)
+        b = rs.BatchScheduler(sc, 25, 4, 4, sched=9, jit=True)
+        b.seed(sharding.seeds_for_cells(sharding.cell_ids_for_rank(0, 1, 4)))
+        b.synthesize_cqi(0x5AB3, 2)
+        b.run(60)
+        t = torch.zeros(20, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        b.slice_bytes_into(t.data_ptr())
+        b.sync()
+        before = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)  # world size 1: the collective itself runs (RCCL), the sum is the vector
+        torch.cuda.synchronize()
+        assert torch.equal(t, before) and int(t.sum().item()) == int(b.state()["cum_bytes"].sum())
+        assert (t.cpu().numpy().astype(np.uint64) == b.slice_bytes()).all()
+        b.close()
+    finally:
+        dist.destroy_process_group()

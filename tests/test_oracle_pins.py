@@ -265,6 +265,149 @@ def test_clock_and_first_ewma(oracle):
     assert (logs["rbg_to_user"] == 0).all()
 
 
+def _ref_clock(oracle, n):
+    L = _ref(oracle, "libref_clock.so")
+    L.ref_clock_run.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    out = np.zeros(n)
+    app_now, app_before = C.c_double(), C.c_int()
+    assert L.ref_clock_run(n, 0.1, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(app_now), C.byref(app_before)) == n
+    return out, app_now.value, app_before.value
+
+
+def test_clock_matches_reference_event_core(oracle):
+    """The oracle's t_k against the reference's own Simulator/Calendar compiled in place (oracle/_ref/libref_clock.so):
+    subframes scheduled at Now() + 0.001 (simulator.cc:117-126), the application start event at exactly 0.1 s, which the
+    calendar runs after subframe 99 and before subframe 100 (t_100 = 0.10000000000000007 > 0.1)."""
+    ref, app_now, app_before = _ref_clock(oracle, 700)
+    assert (oracle.clock_ticks(0, 700) == ref).all()
+    assert (oracle.clock_ticks(100, 300) == ref[100:400]).all()
+    assert app_now == 0.1 and app_before == 100 and ref[99] < 0.1 < ref[100]
+    assert ref[100] == KA["t_100"] and ref[101] - ref[100] == KA["dt_101"]
+    # the first EWMA interval of a bearer created at 0.1 s
+    assert ref[100] - app_now == float.fromhex("0x1.4p-54")
+
+
+def test_clock_matches_committed_reference_fixture(oracle):
+    """Same pin from the recorded outputs of libref_clock.so (tests/golden/ref_clock.json, tools/make_clock_fixture.py):
+    holds where oracle/_ref is absent."""
+    fx = json.loads((GOLDEN / "ref_clock.json").read_text())
+    ref = np.array([float.fromhex(x) for x in fx["subframe_start"]])
+    assert (oracle.clock_ticks(0, len(ref)) == ref).all()
+    assert float.fromhex(fx["app_start_now"]) == 0.1 and fx["subframes_before_app_start"] == 100
+    if oracle.ref_lib("libref_clock.so") is not None:
+        live, _, _ = _ref_clock(oracle, len(ref))
+        assert (live == ref).all(), "fixture is stale: rerun tools/make_clock_fixture.py"
+
+
+def test_prb_grid_matches_reference(oracle, rs):
+    """100 MHz -> 512 PRBs -> RBG size 8 -> 64 RBGs (bandwidth-manager.cpp:38,98-102; eesm-effective-sinr.h:82-103): the
+    product's rs_dl_prbs_for_bandwidth / rs_get_rbg_size against the reference's BandwidthManager compiled in place and its
+    recorded outputs."""
+    fx = json.loads((GOLDEN / "ref_clock.json").read_text())["dl_prbs"]
+    for bw, n in fx.items():
+        assert rs.dl_prbs_for_bandwidth(float(bw)) == n
+    assert rs.dl_prbs_for_bandwidth(100) == 512 and rs.get_rbg_size(512) == 8
+    L = oracle.ref_lib("libref_bw.so")
+    if L is not None:
+        L.ref_dl_subchannels.argtypes = [C.c_double]
+        for bw in (1.4, 3, 5, 10, 15, 20, 100, 7, 0, 99.9):
+            assert rs.dl_prbs_for_bandwidth(bw) == L.ref_dl_subchannels(bw)
+    E = oracle.ref_lib("libref_eesm.so")
+    for n in range(1, 513):
+        assert rs.get_rbg_size(n) == oracle.lib().rso_rbg_size(n)
+        if E is not None:
+            assert rs.get_rbg_size(n) == E.ref_get_rbg_size(n)
+    with pytest.raises(rs.RadioSaberError):
+        rs.get_rbg_size(513)
+
+
+def cqi_keys_of_eff(eff):
+    """flow_spectraleff (0 or one of the 15 CQI efficiencies, strictly increasing in the CQI) -> integer CQI keys."""
+    table = np.array([0.0] + KA["eff_of_cqi"])
+    keys = np.searchsorted(table, eff)
+    assert (table[keys] == eff).all()
+    return np.ascontiguousarray(keys, np.int32)
+
+
+def ref_maximize_cell(L, keys, quota):
+    R, S = keys.shape
+    out = np.empty(R, np.int32)
+    q = np.ascontiguousarray(quota, np.int32)
+    L.ref_maximize_cell_int.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.ref_maximize_cell_int(keys.ctypes.data_as(C.POINTER(C.c_int)), q.ctypes.data_as(C.POINTER(C.c_int)), R, S,
+                            out.ctypes.data_as(C.POINTER(C.c_int)))
+    return out
+
+
+def test_maximize_cell_on_real_tti_inputs_matches_reference_unit_code(oracle):
+    """The reference's own MaximizeCell (unittest/test_tp_algos.cpp compiled in place) fed with the (flow_spectraleff, quota)
+    of real TTIs -- PF state evolving over 120 TTIs, three CQI epochs, 25 and 64 RBGs -- must give the RBG -> slice map the
+    oracle's TTI loop applied."""
+    L = _ref(oracle, "libref_tp_algos.so")
+    import radiosaber_amd as rsm
+    for ues, R, G, w in (([5] * 20, 25, 4, None), ([25] * 20, 25, 4, None), ([5] * 20, 64, 8, None),
+                         ([10] * 5, 25, 4, [0.62, 0.3, 0.05, 0.02, 0.01])):
+        cell = oracle.Cell(ues, R, G, oracle.SCHED_MAXCELL, weights=w)
+        U = cell.U
+        from conftest import synth_cqi
+        grids = synth_cqi(3, (3, U, R), rsm.TRACE_CQI_HISTOGRAM)
+        g = oracle.Rng(12345)
+        ticks = oracle.clock_ticks(100, 120)
+        cell.set_last_update(0.1)
+        out = cell.new_out()
+        for n in range(120):
+            if n % 40 == 0:
+                cell.set_cqi(grids[n // 40])
+            assert cell.step(float(ticks[n]), g.rand(), g.rand(), out) == 0
+            keys = cqi_keys_of_eff(out.slice_eff)
+            want = ref_maximize_cell(L, keys, out.quota_rbgs)
+            u2s = cell.u2s
+            got = np.where(out.rbg_to_user >= 0, u2s[np.maximum(out.rbg_to_user, 0)], -1)
+            assert (got == want).all(), (ues, R, n)
+            # and the user the apply step picked is the slice's best user on that RBG
+            for r in range(R):
+                if want[r] >= 0:
+                    assert out.rbg_to_user[r] == out.slice_user[r, want[r]]
+
+
+def test_run_synth_many_equals_single_runs(oracle):
+    import radiosaber_amd as rsm
+    from conftest import synth_cqi
+    tmpl = oracle.Cell([5] * 20, 25, 4, oracle.SCHED_MAXCELL)
+    grids = synth_cqi(9, (2, tmpl.U, 25), rsm.TRACE_CQI_HISTOGRAM)
+    seeds = np.arange(6, dtype=np.uint32) + 77
+    total, used = oracle.run_synth_many(tmpl, 6, grids, seeds, 80, threads=3)
+    assert used == 3
+    want = 0
+    for s in seeds:
+        c = oracle.Cell([5] * 20, 25, 4, oracle.SCHED_MAXCELL)
+        c.run_synth(grids, int(s), 80, log=False)
+        want += int(c.state()["cum_bytes"].sum())
+    assert total == want
+
+
+PIN_KINDS = ("_ref", "appendix-a", "libc", "structural", "unpinned")
+
+
+def test_pin_ledger_covers_every_oracle_entry_point():
+    """tests/PINS.md must name every function oracle/rs_oracle.h declares, with a known pin kind."""
+    root = GOLDEN.parents[1]
+    header = (root / "oracle" / "rs_oracle.h").read_text()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    declared = set(re.findall(r"\b(rso_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) > 30
+    rows = [ln for ln in (root / "tests" / "PINS.md").read_text().splitlines() if ln.startswith("| `rso_")]
+    named = set()
+    for ln in rows:
+        cols = [c.strip() for c in ln.strip("|").split("|")]
+        assert len(cols) == 4, ln
+        named.update(re.findall(r"`(rso_[a-z_0-9]+)", cols[0]))
+        kinds = re.findall(r"`([a-z_\-]+)`", cols[2])
+        assert kinds and all(k in PIN_KINDS for k in kinds), f"unknown pin kind in: {ln}"
+    assert declared - named == set(), f"oracle entry points without a ledger row: {sorted(declared - named)}"
+    assert named - declared == set(), f"ledger rows for functions that no longer exist: {sorted(named - declared)}"
+
+
 def test_appendix_a_trace_replay(oracle, traces):
     """The reference's own run: first scheduled TTI and the counters after 200 TTIs."""
     cfg = KA["config"]

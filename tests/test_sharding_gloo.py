@@ -58,6 +58,7 @@ def test_shards_partition_the_cells():
     assert (allc == np.arange(world * cells)).all()
     s = sharding.seeds_for_cells(allc)
     assert len(np.unique(s)) == len(s) and s.max() < 2**31 - 1
+    assert [sharding.first_cell_for_rank(r, world, cells) for r in (0, 1, 7)] == [0, 512, 3584]
     # a cell's seed does not depend on the number of ranks
     assert (sharding.seeds_for_cells(sharding.cell_ids_for_rank(3, 4, 1024))[:512] ==
             sharding.seeds_for_cells(sharding.cell_ids_for_rank(6, 8, 512))).all()

@@ -2,7 +2,7 @@
 """Copy the rocprofv3 summaries gpurun merged into gpurun_out/ into profiles/ and derive
 profiles/traffic.json (HBM bytes per launch of the cell kernel from the PMC passes).
 
-    python tools/summarize_rocprof.py r01 sched9_S20_U500_R25_cells512_ttis400
+    python tools/summarize_rocprof.py r02          (the workload key comes from the profiled bench line)
 
 Counter handling per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE are collected in separate passes, both are in KiB, and on gfx950 FETCH_SIZE reports half
@@ -18,8 +18,15 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-tag, key = sys.argv[1], sys.argv[2]
+import subprocess
+
+tag = sys.argv[1]
 out = ROOT / "profiles"
+bench_line = json.loads([ln for ln in (ROOT / "gpurun_out" / "prof_kt.log").read_text().splitlines() if ln.startswith("{")][-1])
+cfg = bench_line["config"]
+key = f"sched{cfg['sched']}_S{cfg['slices']}_U{cfg['ues']}_R{cfg['rbgs']}_cells{cfg['cells_per_gpu']}"
+cell_ttis = cfg["cells_per_gpu"] * cfg["ttis_per_step"]
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 
 
 def one(pattern):
@@ -49,10 +56,11 @@ write_b = statistics.mean(write) * 1024
 traffic = {"kernel": cell["Name"], "launches_profiled": len(fetch),
            "FETCH_SIZE_KiB_mean": statistics.mean(fetch), "WRITE_SIZE_KiB_mean": statistics.mean(write),
            "hbm_read_bytes_per_launch": fetch_b, "hbm_write_bytes_per_launch": write_b,
-           "hbm_bytes_per_launch": fetch_b + write_b,
+           "hbm_bytes_per_launch": fetch_b + write_b, "ttis_per_launch": cfg["ttis_per_step"],
+           "hbm_bytes_per_cell_tti": (fetch_b + write_b) / cell_ttis, "commit": commit, "round": tag,
            "kernel_trace_avg_ns": float(cell["AverageNs"]), "kernel_trace_calls": int(cell["Calls"]),
-           "note": "FETCH_SIZE doubled per the gfx950 correction; WRITE_SIZE includes the 8-byte "
-                   "cum_bytes/cum_rbs atomics (2 per served UE per TTI)"}
+           "note": "FETCH_SIZE doubled per the gfx950 correction; cumulative byte / RB counters ride in registers and "
+                   "are flushed once per launch (round 1: two 8-byte atomics per served UE per TTI)"}
 tf = out / "traffic.json"
 tj = json.loads(tf.read_text()) if tf.exists() else {}
 tj[key] = traffic
