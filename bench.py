@@ -80,6 +80,21 @@ def _physical_cores():
     return max(1, len(seen)), len(allowed)
 
 
+def _cgroup_cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max / v1 cfs quota); None = unlimited."""
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+        per = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -105,26 +120,35 @@ def cpu_baseline(args, slices, seeds):
         return rng.choice(np.arange(1, 16, dtype=np.uint8), size=((n_ttis + 39) // 40, U, R), p=p).astype(np.uint8)
 
     tmpl = O.Cell(slices.ues_per_slice, R, args.rbg_size, args.sched, weights=slices.weight)
-    # one thread, one cell: calibrates the sample size and is reported as the single-core rate
+    # one thread, one cell: the single-core rate
     g = grids_for(400)
     t0 = time.perf_counter()
     O.run_synth_many(tmpl, 1, g, seeds[:1], 400, threads=1)
     per_core = 400 / (time.perf_counter() - t0)
-    cores, logical = _physical_cores()
+    physical, logical = _physical_cores()
+    quota = _cgroup_cpu_quota()
+    # one thread per physical core the container may actually use (a cgroup CPU quota caps the usable cores below nproc)
+    cores = physical if quota is None else max(1, min(physical, int(quota + 0.5)))
     n_cells = 2 * cores
-    n_ttis = int(max(400, min(40000, 8.0 * per_core)))  # ~16 s of work per thread when scaling is linear
-    g = grids_for(n_ttis)
-    sd = np.resize(np.asarray(seeds, np.uint32), n_cells)
-    t0 = time.perf_counter()
-    _, used = O.run_synth_many(tmpl, n_cells, g, sd, n_ttis, threads=cores)
-    wall = time.perf_counter() - t0
-    rate = n_cells * n_ttis / wall
+
+    def run(n_ttis):
+        sd = np.resize(np.asarray(seeds, np.uint32), n_cells)
+        gg = grids_for(n_ttis)
+        t0 = time.perf_counter()
+        _, used = O.run_synth_many(tmpl, n_cells, gg, sd, n_ttis, threads=cores)
+        return n_cells * n_ttis / (time.perf_counter() - t0), used
+
+    probe_rate, _ = run(200)  # short all-core probe: sizes the timed sample to ~15 s whatever the box delivers
+    n_ttis = int(max(200, min(40000, 15.0 * probe_rate / n_cells)))
+    rate, used = run(n_ttis)
+    wall = n_cells * n_ttis / rate
     eff = rate / (per_core * used)
     out = {"value": rate, "unit": "TTIs/s", "cores": used, "kind": "port",
            "single_core_value": per_core, "scaling_vs_linear": eff, "cpu_model": _cpu_model(),
-           "physical_cores": cores, "logical_cpus": logical,
+           "physical_cores": physical, "logical_cpus": logical, "cgroup_cpu_quota": quota,
            "sample": f"{n_cells} independent cells x {n_ttis} TTIs of the same workload, OpenMP over cells inside the "
-                     f"oracle (schedule(dynamic,1)), {used} threads = one per physical core; wall {wall:.1f} s"}
+                     f"oracle (schedule(dynamic,1)), {used} threads = one per usable physical core "
+                     f"({physical} physical cores, cgroup CPU quota {quota}); wall {wall:.1f} s"}
     if eff < 0.5:
         out["warning"] = (f"all-core rate is only {eff:.2f} x linear ({used} threads x {per_core:.0f} TTIs/s single-core): "
                           "the baseline is not core-bound on this box")
