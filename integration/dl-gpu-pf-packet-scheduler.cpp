@@ -1,0 +1,104 @@
+/* dl-gpu-pf-packet-scheduler.cpp -- see dl-gpu-pf-packet-scheduler.h. */
+#include "dl-gpu-pf-packet-scheduler.h"
+
+#include <stdexcept>
+
+#include "../../../core/spectrum/bandwidth-manager.h"
+#include "../../../device/ENodeB.h"
+#include "../../../device/NetworkNode.h"
+#include "../../../flows/radio-bearer.h"
+#include "../../../phy/lte-phy.h"
+#include "../mac-entity.h"
+
+DL_GPU_PF_PacketScheduler::DL_GPU_PF_PacketScheduler(std::string config_fname, int max_flows, int hip_device)
+    : DL_PF_PacketScheduler(config_fname), ctx_(NULL), hip_device_(hip_device), max_flows_(max_flows), nb_rbs_(0) {}
+
+DL_GPU_PF_PacketScheduler::~DL_GPU_PF_PacketScheduler() { rs_destroy(ctx_); }
+
+void DL_GPU_PF_PacketScheduler::RBsAllocation() {
+  FlowsToSchedule* flows = GetFlowsToSchedule(); /* one record per bearer with packets, RRC container order */
+  const int nb_rbs = GetMacEntity()->GetDevice()->GetPhy()->GetBandwidthManager()->GetDlSubChannels().size();
+  const int rbg_size = rs_get_rbg_size(nb_rbs);
+  if (rbg_size < 0) throw std::runtime_error(rs_last_error());
+  /* the reference rounds the RBG count UP here (:190) and clips the last RBG; the C ABI takes whole RBGs only */
+  if (nb_rbs % rbg_size) throw std::runtime_error("DL_GPU_PF_PacketScheduler: nb_rbs is not a multiple of the RBG size");
+  const int R = nb_rbs / rbg_size;
+  const int n = (int)flows->size();
+  if (n > max_flows_) throw std::runtime_error("DL_GPU_PF_PacketScheduler: more flows than max_flows");
+  if (!ctx_) {
+    /* no slices in this scheduler: one slice holding every flow slot */
+    static const double kWeight = 1.0;
+    static const int kZero = 0, kOne = 1;
+    std::vector<int> u2s(max_flows_, 0);
+    rs_config cfg;
+    cfg.n_slices = 1;
+    cfg.n_users = max_flows_;
+    cfg.n_rbgs = R;
+    cfg.rbg_size = rbg_size;
+    cfg.sched = RS_SCHED_PF;
+    cfg.device = hip_device_;
+    cfg.slice_weight = &kWeight;
+    cfg.algo_alpha = &kZero;
+    cfg.algo_beta = &kZero;
+    cfg.algo_epsilon = &kOne;
+    cfg.algo_psi = &kOne;
+    cfg.user_to_slice = u2s.data();
+    cfg.stream = NULL;
+    ctx_ = rs_create(&cfg);
+    if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
+    nb_rbs_ = nb_rbs;
+  }
+  if (nb_rbs != nb_rbs_) throw std::runtime_error("DL_GPU_PF_PacketScheduler: the PRB grid changed after the first TTI");
+
+  /* the "users" of the C ABI are this scheduler's flows, ids = positions in the flow list (user_id NULL) */
+  std::vector<uint8_t> cqi_prb((size_t)n * nb_rbs);
+  std::vector<double> avg(n);
+  for (int i = 0; i < n; i++) {
+    FlowToSchedule* f = flows->at(i);
+    /* the break at :253-265 (transport block >= dataToTransmit * 8) never fires for InfiniteBuffer flows (1e8 bytes);
+     * finite queues need it -- the C ABI has no input for it, so refuse rather than allocate differently */
+    if (f->GetDataToTransmit() < 100000000)
+      throw std::runtime_error("DL_GPU_PF_PacketScheduler: finite queues are not supported by the GPU path (backlogged flows only)");
+    const std::vector<int> fb = f->GetCqiFeedbacks();
+    for (int k = 0; k < nb_rbs; k++) cqi_prb[(size_t)i * nb_rbs + k] = (uint8_t)fb.at(k);
+    avg[i] = f->GetBearer()->GetAverageTransmissionRate(); /* metric (se * 180000.) / avg, dl-pf-packet-scheduler.cpp:128-140 */
+  }
+  rs_tti_in in;
+  in.n_users = n;
+  in.user_id = NULL;
+  in.cqi = NULL;
+  in.avg_rate = avg.data();
+  in.rand0 = in.rand1 = 0; /* this scheduler draws nothing */
+  in.cqi_prb = cqi_prb.data();
+  in.hol_delay = NULL;
+  in.prio_has_data = NULL;
+  in.rand_draws = NULL;
+  int target = 0, quota = 0;
+  std::vector<int> map(R), nprb(n), fcqi(n), mcs(n), tbs(n);
+  rs_tti_out out;
+  out.target_rbs = &target;
+  out.quota_rbgs = &quota;
+  out.rbg_to_user = map.data();
+  out.user_nprb = nprb.data();
+  out.user_final_cqi = fcqi.data();
+  out.user_mcs = mcs.data();
+  out.user_tbs_bits = tbs.data();
+  out.upper_rbg = out.upper_user = NULL;
+  if (rs_schedule_tti(ctx_, &in, &out) != RS_OK) throw std::runtime_error(std::string("rs_schedule_tti: ") + rs_last_error());
+
+  /* :268-322 -- allocation lists, allocated bits, PDCCH records */
+  for (int r = 0; r < R; r++)
+    if (map[r] >= 0)
+      for (int j = r * rbg_size; j < (r + 1) * rbg_size; j++) flows->at(map[r])->GetListOfAllocatedRBs()->push_back(j);
+  PdcchMapIdealControlMessage* pdcchMsg = new PdcchMapIdealControlMessage();
+  for (int i = 0; i < n; i++) {
+    FlowToSchedule* flow = flows->at(i);
+    if (flow->GetListOfAllocatedRBs()->size() == 0) continue;
+    flow->UpdateAllocatedBits(tbs[i]);
+    for (size_t rb = 0; rb < flow->GetListOfAllocatedRBs()->size(); rb++)
+      pdcchMsg->AddNewRecord(PdcchMapIdealControlMessage::DOWNLINK, flow->GetListOfAllocatedRBs()->at(rb),
+                             flow->GetBearer()->GetDestination(), mcs[i]);
+  }
+  if (pdcchMsg->GetMessage()->size() > 0) GetMacEntity()->GetDevice()->GetPhy()->SendIdealControlMessage(pdcchMsg);
+  delete pdcchMsg;
+}
