@@ -362,7 +362,7 @@ int batch_alloc(rs_batch* b) {
         te[(size_t)n * 27 + i] = v;
       }
     for (int32_t v : te)
-      if (v / 8 > RS_TX_BYTES_MASK) return fail(RS_ERR_INVALID, "a transport block of %d bits does not fit the packed tx word", v);
+      if (v / 8 > RS_MAX_BYTES_PER_TTI) return fail(RS_ERR_INVALID, "a transport block of %d bits does not fit the per-launch byte counters", v);
     HIP_TRY(hipMalloc(&b->d_tbs_eff, 4 * te.size()));
     HIP_TRY(hipMemcpy(b->d_tbs_eff, te.data(), 4 * te.size(), hipMemcpyHostToDevice));
   }
@@ -484,6 +484,17 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
            uint32_t* d_keys = nullptr) {
   if (n_ttis < 1) return fail(RS_ERR_INVALID, "n_ttis %d < 1", n_ttis);
   if (b->cqi_mode == RS_CQI_NONE) return fail(RS_ERR_STATE, "no CQI source set");
+  if (n_ttis > RS_MAX_TTIS_PER_LAUNCH) {
+    /* longer runs go out as several launches (state carries over; the per-launch counters of the kernel are 32-bit) */
+    if (d_map || d_tbs || d_uinfo || d_keys) return fail(RS_ERR_INVALID, "logged runs are limited to %d TTIs per call", RS_MAX_TTIS_PER_LAUNCH);
+    for (int done = 0; done < n_ttis;) {
+      const int chunk = n_ttis - done < RS_MAX_TTIS_PER_LAUNCH ? n_ttis - done : RS_MAX_TTIS_PER_LAUNCH;
+      const int rc = launch(b, chunk, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+      if (rc) return rc;
+      done += chunk;
+    }
+    return RS_OK;
+  }
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   RsLaunch L = b->base;
   L.n_ttis = n_ttis;

@@ -26,10 +26,19 @@ typedef unsigned long size_t;
 #define RS_TX_NPRB_SHIFT 20
 #define RS_TX_NPRB_MASK 0x3FF
 #define RS_TX_COUNTED (1 << 30)
+/* a shape-specialised kernel counts a launch's bytes per user in 32 bits: 32 768 TTIs x < 2^16 bytes per TTI */
+#define RS_MAX_TTIS_PER_LAUNCH 32768
+#define RS_MAX_BYTES_PER_TTI 65535
 #define RS_PF_SEG 32 /* sched 1: users are scanned in segments of this many for the per-RBG argmax */
 
 /* per-cell scratch in LDS (host needs its size for the LDS carve) */
 #define RS_MAX_SEGS 256 /* > 4096/17 sub-ranges longer than 16 on one recursion level */
+/* hand-shake words of one serial phase (speculative next-TTI scan, rs_kernels.hip): waves that finished the speculative EWMA /
+ * the speculative scan, "the allocation is decided", and the number of items whose winner was served */
+struct RsSpecFlags {
+  int32_t ctr_p1, ctr_p3, greedy_done, n_fix;
+};
+#define RS_FIX_CAP 960 /* u16 entries of RsMisc::hist behind the 128-byte served bitmap */
 struct RsMisc {
   unsigned long long maskA[64], maskB[64]; /* level-synchronous introsort: stop ballots per chunk */
   int32_t seg_begin[68];
@@ -49,6 +58,7 @@ struct RsMisc {
   double eff16[16];              /* Vogel: flow_spectraleff of a key (key 0 = empty slice = 0.0) */
   uint8_t eps_psi[64];           /* per slice: bit 0 = algo_epsilon, bit 1 = algo_psi (read by every work item of P3) */
   int32_t rcp_off[64];           /* per slice: window start in the reciprocal array minus the slice's 8-aligned first user */
+  RsSpecFlags spec[2];           /* by TTI parity */
 };
 
 /* LDS carve of one cell (byte offsets from the dynamic LDS base), a pure function of the cell shape so
@@ -100,7 +110,9 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
   c.off_tbs = off; off += rs_round_up(4 * 16 * (R + 1), 16); /* TBS bits of n RBGs at a final CQI */
   c.off_elems = off; off += rs_round_up(pf_like ? 8 * c.n_items : 4 * R * S, 16);
   c.off_sorted = off; off += (sched == 7 && nvs_seg != 0) ? 0 : rs_round_up(4 * R * S, 16);
-  c.off_items = off; off += rs_round_up(2 * c.n_items, 16);
+  /* winners per work item; the schedulers with a speculative next-TTI scan keep two TTIs' worth (by parity) */
+  const bool spec = sched == 8 || sched == 9 || sched == 101 || sched == 103;
+  c.off_items = off; off += rs_round_up((spec ? 4 : 2) * c.n_items, 16);
   /* level-synchronous introsort scratch: cut per sub-range (+ bounds/pivots when the state lives in LDS) */
   /* register form (ept <= 4): one cut slot per 16 positions; LDS form: bounds, pivots and cuts per position */
   c.off_sortx = off; off += (sched == 9 || sched == 10) ? rs_round_up(c.ept <= 4 ? 4 * (R * S / 16 + 2) : 8 * R * S, 16)

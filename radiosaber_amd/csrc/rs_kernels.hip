@@ -101,6 +101,17 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
                               p.off_sorted, p.off_items, p.off_sortx, p.off_cqi, p.Upad, p.n_seg, p.n_items};
   constexpr bool kTransport = (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103 || SCHED == 10);
   const int quota_wave = nwaves - 1; /* P2 runs on the last wave, beside the other waves' P3 */
+  /* Speculative next-TTI metric scan.  In the schedulers whose inter-slice step and link adaptation run on
+   * wave 0 alone, the other waves use that time to prepare TTI t+1 as if nobody were served in TTI t: the EWMA decay of every
+   * user ((1 - beta) * avg, no bytes) and the best user of every (RBG, slice).  Serving a user can only LOWER its metric, so
+   * an item whose speculative winner was not served keeps that winner exactly (first-maximum rule included); the few items
+   * whose winner was served (~13 %) are listed and rescanned with the true averages after the TTI's closing barrier. */
+  constexpr bool kSpecSched = !DIRECT && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
+#ifdef RS_NO_SPEC
+  const bool spec_enabled = false;
+#else
+  const bool spec_enabled = kSpecSched && nwaves >= 2;
+#endif
 
   double* s_avg = (double*)lds;
   double* s_avgk = (double*)(lds + o.avgk);
@@ -112,7 +123,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   float* s_num32 = (float*)(s_x + 16);
   double* s_w = (double*)(lds + o.slice);
   double* s_sstate = s_w + 64;
-  uint16_t* s_best_user = (uint16_t*)(lds + o.items);
+  uint16_t* s_best_user = (uint16_t*)(lds + o.items); /* kSpecSched: two buffers of n_items, by TTI parity */
   double* s_best_metric = (double*)(lds + o.elems); /* sched 1 only (aliases elems) */
   uint32_t* s_elems = (uint32_t*)(lds + o.elems);
   uint32_t* s_sorted = (uint32_t*)(lds + o.sorted);
@@ -131,7 +142,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * Bit 30 of the stored tx word: "already in the HBM totals" (the last TTI's service, flushed with the launch). */
   constexpr bool kCumRegs = FIXED && !DIRECT;
   constexpr int kKU = kCumRegs ? (RS_JIT_U + RS_JIT_NT - 1) / RS_JIT_NT : 1;
-  long long cum_b[kKU], cum_r[kKU];
+  /* 32-bit per launch: the host splits runs so that n_ttis * (largest transport block in bytes) < 2^31 (RS_MAX_TTIS_PER_LAUNCH) */
+  int cum_b[kKU], cum_r[kKU];
 #pragma unroll
   for (int k = 0; k < kKU; ++k) { cum_b[k] = 0; cum_r[k] = 0; }
   /* ---------------- load the cell ---------------- */
@@ -172,6 +184,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     m->ones16[tid] = 1.0f;
     m->eff16[tid] = tab->eff[tid];
   }
+  if (tid < 2) { m->spec[tid].ctr_p1 = 0; m->spec[tid].ctr_p3 = 0; m->spec[tid].greedy_done = 0; m->spec[tid].n_fix = 0; }
   if (tid < S) {
     m->eps_psi[tid] = (uint8_t)((p.eps[tid] ? 1 : 0) | (p.psi[tid] ? 2 : 0));
     s_w[tid] = p.weight[tid];
@@ -205,7 +218,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       if (lane < S) m->rcp_off[lane] = wb - (ub & ~7);
     }
     __syncthreads();
-    for (int u = tid; u < U; u += nt) s_uoff[u] = (int16_t)m->rcp_off[p.user_slice[u]];
+    /* window offsets are multiples of 8 (>= 0): bit 0 carries the slice's algo_psi, so that P1 needs no other per-user table */
+    for (int u = tid; u < U; u += nt) s_uoff[u] = (int16_t)(m->rcp_off[p.user_slice[u]] | (p.psi[p.user_slice[u]] ? 1 : 0));
   }
   double t = scal->t;
   double last_update = scal->last_update;
@@ -221,10 +235,6 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   if (wave == quota_wave && lane < 31) rng.r = scal->rng_r[lane];
   const int nb_rbs = R * G;
   int local_err = 0;
-  /* bit k: the k-th user of this thread (u = tid + k*nt) belongs to a slice with psi == 1 */
-  uint32_t psi_mask = 0;
-  if (SCHED != 1)
-    for (int u = tid, k = 0; u < U; u += nt, ++k) psi_mask |= (p.psi[p.user_slice[u]] ? 1u : 0u) << k;
   __syncthreads();
 
 #ifndef RS_STAMPS
@@ -252,6 +262,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     for (int k = 1; k <= 13; ++k)
       xthr_k[k - 1] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xl), k), __builtin_amdgcn_readlane(__double2loint(xl), k));
   }
+  bool have_spec = false; /* this TTI's EWMA, metric scan and quotas were prepared during the previous TTI's serial phase */
   for (int tti = 0; tti < p.n_ttis; ++tti) {
     RS_STAMP(11);
     /* ---------------- P0: CQI refresh ---------------- */
@@ -297,12 +308,42 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
       }
     }
+    /* which buffers this TTI's winners and records live in (see kSpecSched) */
+    const int n_items_rt = o.n_items;
+    uint16_t* const cur_bu = s_best_user + ((kSpecSched && (tti & 1)) ? n_items_rt : 0);
+    uint16_t* const nxt_bu = s_best_user + ((kSpecSched && !(tti & 1)) ? n_items_rt : 0);
+    /* sched 9 scans s_sorted in the serial phase, so the next TTI's records can go straight to s_elems; the policies that read
+     * the records themselves (8, 101, 103) alternate between s_elems and the otherwise unused s_sorted */
+    constexpr bool kAltRec = kSpecSched && SCHED != 9;
+    uint32_t* const cur_rec = (kAltRec && (tti & 1)) ? s_sorted : s_elems;
+    uint32_t* const nxt_rec = (kAltRec && !(tti & 1)) ? s_sorted : s_elems;
+    RsSpecFlags* const fl_cur = &m->spec[tti & 1];        /* flags of this TTI's serial phase */
+    RsSpecFlags* const fl_prev = &m->spec[(tti & 1) ^ 1]; /* ... of the previous one (read by the fix-up below) */
+    uint32_t* const served_bits = (uint32_t*)m->hist;     /* [32] users served in the serial phase (m->hist is free then) */
+    uint16_t* const fix_list = m->hist + 64;              /* items to rescan, RS_FIX_CAP entries */
+    /* items the scanning waves take in the serial phase: whole rounds of nt - 64 lanes (at least one round) */
+    auto spec_items = [&](int n) {
+      const int nsp_ = nt > 64 ? nt - 64 : 64; /* (one-wave cells never speculate) */
+      const int rounds = n / nsp_;
+      return rounds == 0 ? n : rounds * nsp_;
+    };
+    /* PF terms of a user whose average is `a`: exact denominator and stage-1 reciprocal (ref: :685-689) */
+    auto pf_terms = [&](int u, double a) {
+      double k = 1;
+      k += a;
+      k /= 1000.0;
+      s_avgk[u] = k;
+      const int uo = s_uoff[u];
+      /* stage-1 ranking only, never part of a result; psi == 0 slices rank on the numerator */
+      s_rcp32[u + (uo & ~7)] = (uo & 1) ? __builtin_amdgcn_rcpf((float)k) : 1.0f; /* v_rcp_f32, 1 ulp */
+    };
     /* ---------------- P1: PF EWMA (ref: src/flows/radio-bearer.cpp:139-164) ---------------- */
-    {
+    if (!have_spec) {
       const bool do_ewma = !kDirect && !(t == last_update);
       const double dt = t - last_update;
       auto ewma_user = [&](int u, int ku) {
         double a = s_avg[u];
+        if (kSpecSched && a < 1) a = 1; /* a speculative update leaves the unclamped product behind (see the serial phase) */
         if (do_ewma) {
           int txb = s_tx[u];
           if (kCumRegs) {
@@ -318,14 +359,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           s_tx[u] = 0;
         }
         if (SCHED != 1) {
-          /* ref: :685-689  averageRate = 1 + sum(avg); averageRate /= 1000.0 */
-          double k = 1;
-          k += a;
-          k /= 1000.0;
-          s_avgk[u] = k;
-          /* stage-1 ranking only, never part of a result; psi == 0 slices rank on the numerator */
-          float r32 = ((psi_mask >> ku) & 1u) ? __builtin_amdgcn_rcpf((float)k) : 1.0f; /* v_rcp_f32, 1 ulp */
-          if (queue_mode_in) {
+          if (!queue_mode_in) {
+            pf_terms(u, a);
+          } else {
+            /* ref: :685-689  averageRate = 1 + sum(avg); averageRate /= 1000.0 */
+            double k = 1;
+            k += a;
+            k /= 1000.0;
+            s_avgk[u] = k;
+            const int uo = s_uoff[u];
+            float r32 = (uo & 1) ? __builtin_amdgcn_rcpf((float)k) : 1.0f;
             /* customised slice (ref: :694-711): metric 0 while the prioritized bearer is empty, times the
              * head-of-line delay when beta (sched 7: always) -- folded into the stage-1 factor */
             const int sl = p.user_slice[u];
@@ -334,8 +377,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               const bool use_hol = SCHED == 7 || SCHED == 11 || p.beta[sl] != 0;
               r32 = !has ? 0.0f : (use_hol ? r32 * (float)p.hol[u] : r32);
             }
+            s_rcp32[u + (uo & ~7)] = r32;
           }
-          s_rcp32[u + s_uoff[u]] = r32;
         } else {
           s_rcp32[u] = __builtin_amdgcn_rcpf((float)a);
         }
@@ -348,16 +391,34 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         for (int u = tid, ku = 0; u < U; u += nt, ++ku) ewma_user(u, ku);
       }
       if (!kDirect) last_update = t;
+      __syncthreads();
+    } else {
+      /* the previous serial phase has already updated every average for this TTI (speculatively, then exactly for the
+       * served users); what is left is bookkeeping: the owners count the bytes granted in the previous TTI */
+      if constexpr (kCumRegs) {
+#pragma unroll
+        for (int ku = 0; ku < kKU; ++ku) {
+          const int u = tid + ku * nt;
+          if (u < U) {
+            const int v = s_tx[u];
+            if (v != 0) {
+              cum_r[ku] += (v >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK;
+              cum_b[ku] += v & RS_TX_BYTES_MASK;
+              s_tx[u] = 0;
+            }
+          }
+        }
+      }
+      last_update = t;
     }
-    __syncthreads();
     RS_STAMP(0);
 
     /* ---------------- P2: quotas / slice choice (one wave, lanes = slices) ---------------- */
-    if (wave == quota_wave) {
+    auto quota_phase = [&](int served_before) {
       int r0 = p.rand0, r1 = p.rand1;
       if (!kDirect) {
         if (p.phy_draws)
-          for (int i = 0; i < served_prev; i++) (void)rng.next();
+          for (int i = 0; i < served_before; i++) (void)rng.next();
         if (kTransport) {
           r0 = rng.next();
           r1 = rng.next();
@@ -434,7 +495,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         m->target[lane] = 0;
         m->quota[lane] = 0;
       }
-    }
+    };
+    if (wave == quota_wave && !have_spec) quota_phase(served_prev);
     int seg_lo = 0;   /* NVS: the served slice */
     int nvs_runs = 1; /* sched 7: runs of the served slice scanned in P3 */
     if (SCHED == 7 || SCHED == 11) {
@@ -575,20 +637,21 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
 
     /* ---------------- P3: best user of every (RBG, segment) ---------------- */
-    if constexpr (SCHED != 11) {
-      /* sched 7: the served slice in 8-aligned runs of nvs_seg users, so that a slice of a few dozen users keeps several waves
-       * busy instead of R lanes; the run winners meet in P4 */
-      const int nvs_seg = FIXED ? kCv.nvs_seg : p.nvs_seg;
-      int nvs_lo = 0, nvs_hi = 0, nvs_first = 0;
-      const bool nvs_split = SCHED == 7 && nvs_seg != 0;
-      if (nvs_split) {
-        nvs_lo = kDirect ? 0 : m->seg_begin[seg_lo];
-        nvs_hi = kDirect ? U : m->seg_begin[seg_lo + 1];
-        nvs_first = nvs_lo & ~7;
-        nvs_runs = idiv_small(nvs_hi - nvs_first + nvs_seg - 1, nvs_seg);
-      }
-      const int n_items = nvs_split ? R * nvs_runs : o.n_items;
-      for (int it = tid; it < n_items; it += nt) {
+    /* sched 7: the served slice in 8-aligned runs of nvs_seg users, so that a slice of a few dozen users keeps several waves
+     * busy instead of R lanes; the run winners meet in P4 */
+    const int nvs_seg = FIXED ? kCv.nvs_seg : p.nvs_seg;
+    int nvs_lo = 0, nvs_hi = 0, nvs_first = 0;
+    const bool nvs_split = SCHED == 7 && nvs_seg != 0;
+    if (nvs_split) {
+      nvs_lo = kDirect ? 0 : m->seg_begin[seg_lo];
+      nvs_hi = kDirect ? U : m->seg_begin[seg_lo + 1];
+      nvs_first = nvs_lo & ~7;
+      nvs_runs = idiv_small(nvs_hi - nvs_first + nvs_seg - 1, nvs_seg);
+    }
+    const int n_items = nvs_split ? R * nvs_runs : o.n_items;
+    /* one work item = (segment, RBG): winner to bu_out[it], its record (transport schedulers) to rec_out */
+    auto scan_item = [&](int it, uint16_t* bu_out, uint32_t* rec_out) {
+      {
         int sg = it / R, r = it - sg * R; /* r fastest: neighbouring lanes read neighbouring CQI bytes */
         int seg = SCHED == 7 ? seg_lo : sg;
         int ub = m->seg_begin[seg], ue = m->seg_begin[seg + 1];
@@ -621,7 +684,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
          * the 32 products of a block in registers, takes their maximum, then marks the survivors. */
         const float kTol = 0x1.ffffcp-1f; /* 1 - 2^-19 */
         /* sched 7 scans runs of 8..32 users: a shape-specialised build ranks exactly one run per block */
-        constexpr int kP3Block = (SCHED == 7 && FIXED && kCv.nvs_seg != 0) ? kCv.nvs_seg : RS_P3_BLOCK;
+        /* (the speculating schedulers carry this scan twice, here and in the serial phase: 32 products per block would spill) */
+        constexpr int kP3Block = (SCHED == 7 && FIXED && kCv.nvs_seg != 0) ? kCv.nvs_seg
+                                 : ((kSpecSched && RS_P3_BLOCK > 16) ? 16 : RS_P3_BLOCK);
         const bool one_num = SCHED != 1 && !sl_eps;
         const float* numtab = one_num ? m->ones16 : s_num32; /* a table either way: no branch per user */
         /* this slice's window, indexed by user (drop-in NVS passes the served slice's users only: their own slice id) */
@@ -734,17 +799,31 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
         const int bkey = bu >= 0 ? rowp[bu] : 0;
         if ((SCHED == 1 || nvs_split) && !exact && bu >= 0) best = exact_metric(bu, bkey); /* the winners' metrics meet in P4 */
-        s_best_user[it] = (uint16_t)bu;
+        bu_out[it] = (uint16_t)bu;
         if (SCHED == 10) {
           /* UpperBound sorts one vector per slice (:229-233): slice-major */
-          s_elems[sg * R + r] = ((uint32_t)bkey << 16) | ((uint32_t)r << 8) | (uint32_t)sg;
+          rec_out[sg * R + r] = ((uint32_t)bkey << 16) | ((uint32_t)r << 8) | (uint32_t)sg;
         } else if (kTransport) {
           /* MaximizeCell's vector is RBG-major, slice-minor (:357-360) */
-          s_elems[r * S + sg] = ((uint32_t)bkey << 16) | ((uint32_t)r << 8) | (uint32_t)sg;
+          rec_out[r * S + sg] = ((uint32_t)bkey << 16) | ((uint32_t)r << 8) | (uint32_t)sg;
         } else if (SCHED == 1 || nvs_split) {
           s_best_metric[it] = best;
         }
       }
+    };
+    if constexpr (SCHED != 11) {
+      /* fix-up of a speculated TTI: only the items whose speculative winner was served in the previous TTI (listed by the
+       * scanning waves) are scanned again, now with the true averages; a list that overflowed means all of them.  One loop
+       * for both cases: the scan is inlined once here and once in the serial phase. */
+      /* The serial phase scans whole rounds only (every scanning lane one item per round): the items beyond them were not
+       * speculated at all and are scanned here, behind the listed ones -- a second, nearly empty round in the serial phase
+       * would cost a whole item's latency there, here they ride along in lanes that are idle anyway. */
+      const int n_fix = have_spec ? rs_lds_load(&fl_prev->n_fix) : 0;
+      const bool listed = have_spec && n_fix <= RS_FIX_CAP;
+      const int n_spec = spec_items(n_items); /* items the serial phase speculated: [0, n_spec) */
+      const int n_scan = listed ? n_fix + (n_items - n_spec) : n_items;
+      for (int j = tid; j < n_scan; j += nt)
+        scan_item(listed ? (j < n_fix ? (int)fix_list[j] : n_spec + (j - n_fix)) : j, cur_bu, cur_rec);
     }
     __syncthreads();
     if (kTransport && p.log_keys) {
@@ -752,8 +831,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
        * (0: no user) | (user + 1) << 8 -- flow_spectraleff / user_index of ref :545-567 */
       for (int i = tid; i < R * S; i += nt) {
         const int r = SCHED == 10 ? i % R : i / S, sg = SCHED == 10 ? i / R : i % S;
-        const int bu = s_best_user[sg * R + r];
-        p.log_keys[((size_t)cell * p.n_ttis + tti) * R * S + r * S + sg] = (s_elems[i] >> 16) | ((bu == 0xFFFF ? 0u : (uint32_t)bu + 1u) << 8);
+        const int bu = cur_bu[sg * R + r];
+        p.log_keys[((size_t)cell * p.n_ttis + tti) * R * S + r * S + sg] = (cur_rec[i] >> 16) | ((bu == 0xFFFF ? 0u : (uint32_t)bu + 1u) << 8);
       }
     }
     RS_STAMP(2);
@@ -904,19 +983,37 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
     /* the rest of the TTI runs on wave 0: lanes = slices for the quota counters, lanes = RBGs for
      * the allocation; the RBG->slice map stays in registers */
+    /* Does the NEXT TTI refresh the CQI grid?  Then nothing can be prepared for it now (its grid is not in LDS yet). */
+    bool spec_next = false;
+    if (kSpecSched && spec_enabled && tti + 1 < p.n_ttis) {
+      if (p.cqi_mode == RS_CQI_EPOCHS) {
+        spec_next = epoch_pos + 1 != p.refresh;
+      } else if (p.cqi_mode == RS_CQI_TRACE) {
+        const double t_next = t + 0.001;
+        spec_next = reported && !(((int)(t_next * 1000) - last_sent) >= 40);
+      }
+    }
     if (SCHED != 10 && wave == 0) {
       /* the only running wave of this cell until the end-of-TTI barrier: ask the SIMD's arbiter to prefer it
        * over the co-resident cell's waves (measured +3 % with two cells per CU) */
       __builtin_amdgcn_s_setprio(3);
       int owner = -1;
       int got = 0; /* lane s: RBGs granted to slice s */
+      int my_target = 0, my_quota = 0; /* lane s: this TTI's values (the quota wave may overwrite the LDS copies for TTI t+1) */
+      if (kSpecSched) {
+        my_target = m->target[lane];
+        my_quota = m->quota[lane];
+        /* the other flag set belongs to the NEXT serial phase: its last reader (this TTI's fix-up) is behind a barrier */
+        if (lane == 0) { fl_prev->ctr_p1 = 0; fl_prev->ctr_p3 = 0; fl_prev->greedy_done = 0; fl_prev->n_fix = 0; }
+        if (spec_next && lane < 32) served_bits[lane] = 0u;
+      }
       if constexpr (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103) {
         /* DownlinkTransportScheduler's inter-slice policies (rs_interslice.h): lane r learns the slice of RBG r */
         int my_slice;
         constexpr int kS = FIXED ? RS_JIT_S : 0, kR = FIXED ? RS_JIT_R : 0;
-        if constexpr (SCHED == 8) my_slice = interslice_greedy_by_row<kS, kR>(s_elems, m, S, R, got);
-        else if constexpr (SCHED == 101) my_slice = interslice_subopt<kS, kR>(s_elems, m, (uint8_t*)(lds + o.sortx), S, R, got);
-        else if constexpr (SCHED == 103) my_slice = interslice_vogel<kS, kR>(s_elems, m, S, R, got);
+        if constexpr (SCHED == 8) my_slice = interslice_greedy_by_row<kS, kR>(cur_rec, m, S, R, got);
+        else if constexpr (SCHED == 101) my_slice = interslice_subopt<kS, kR>(cur_rec, m, (uint8_t*)(lds + o.sortx), S, R, got);
+        else if constexpr (SCHED == 103) my_slice = interslice_vogel<kS, kR>(cur_rec, m, S, R, got);
         else {
 #ifdef RS_STAMPS
           my_slice = interslice_maximize_cell<kS, kR>(s_sorted, m, S, R, got, stamp_acc);
@@ -925,7 +1022,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #endif
         }
         if (lane < R && my_slice >= 0) {
-          int u = s_best_user[my_slice * R + lane];
+          int u = cur_bu[my_slice * R + lane];
           owner = u == 0xFFFF ? -1 : u;
         }
       } else if (SCHED == 1) {
@@ -979,7 +1076,19 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       const unsigned long long same = owner >= 0 ? ob.lanes_with(owner + 1) : 0ull;
       const bool leader = owner >= 0 && (same & ((1ull << lane) - 1ull)) == 0;
       const unsigned long long lead_mask = __ballot(leader);
+      served_prev = __popcll(lead_mask);
+      /* ref: :618-620 slice_rbs_offset_ = target - final_rbgs*rbg_size */
+      if (kTransport && lane < S) s_sstate[lane] = (double)((kSpecSched ? my_target : m->target[lane]) - got * G);
+      if (lane == 0) m->served = served_prev;
+      if (kSpecSched && spec_next) {
+        /* the allocation is decided: tell the scanning waves who was served (their speculative winners among these need a
+         * second look) and let the quota wave start TTI t+1's quotas (slice offsets and the served count are in place) */
+        if (leader) atomicOr(&served_bits[owner >> 5], 1u << (owner & 31));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) atomicExch(&fl_cur->greedy_done, 1);
+      }
       int tbs = 0, nprb = 0, fcqi = 0, mcs = 0;
+      int tbs_bytes_next = 0; /* bytes of this TTI's grant, for the served user's next EWMA update (speculated TTIs) */
       {
         /* ref: :638-651 -- PRBs in RBG-ascending order, G identical adds per RBG
          * (src/utility/eesm-effective-sinr.h:33-46 with the exp() values tabulated by the host) */
@@ -1017,25 +1126,41 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             if (kCumRegs) {
               s_tx[owner] += bytes | (nprb << RS_TX_NPRB_SHIFT); /* the owner thread of P1 counts it (registers) */
             } else {
-              s_tx[owner] += bytes;
+              /* the next EWMA update consumes the bytes: in a speculated TTI that happens right below, on this lane */
+              if (!(kSpecSched && spec_next)) s_tx[owner] += bytes;
               /* RadioBearer::m_cumulativeBytes / m_cumulativeRBs live in HBM: fire-and-forget atomics */
               atomicAdd((unsigned long long*)&p.cum_bytes[(size_t)cell * U + owner], (unsigned long long)bytes);
               atomicAdd((unsigned long long*)&p.cum_rbs[(size_t)cell * U + owner], (unsigned long long)nprb);
             }
           }
+          if (kSpecSched && spec_next) tbs_bytes_next = bytes;
         }
       }
-      served_prev = __popcll(lead_mask);
-      /* ref: :618-620 slice_rbs_offset_ = target - final_rbgs*rbg_size */
-      if (kTransport && lane < S) s_sstate[lane] = (double)(m->target[lane] - got * G);
-      if (lane == 0) m->served = served_prev;
+      if (kSpecSched && spec_next) {
+        /* Exact EWMA of the served users for TTI t+1 (ref: src/flows/radio-bearer.cpp:139-164): the scanning waves left
+         * (1 - beta) * avg, unclamped, in s_avg; adding beta * rate gives the reference's sum of the two rounded products.
+         * Not before every speculative scan is over: they must all have seen one state, the speculative one. */
+        while (rs_lds_load(&fl_cur->ctr_p3) < nwaves - 1) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (leader) {
+          const double t_next = t + 0.001;
+          const double dt_next = t_next - t; /* Now - m_lastUpdate of the next update: m_lastUpdate is this TTI's time */
+          double a = s_avg[owner];
+          const double rate = (double)(tbs_bytes_next * 8) / dt_next;
+          const double beta = 0.02;
+          a = a + (beta * rate);
+          if (a < 1) a = 1;
+          s_avg[owner] = a;
+          pf_terms(owner, a);
+        }
+      }
       /* optional log */
       if (p.log_map) {
         size_t row = (size_t)cell * p.n_ttis + tti;
         if (lane < R) p.log_map[row * R + lane] = (int16_t)owner;
         if (lane < S) {
-          if (p.log_quota) p.log_quota[row * S + lane] = (int16_t)m->quota[lane];
-          if (p.log_target) p.log_target[row * S + lane] = (int16_t)m->target[lane];
+          if (p.log_quota) p.log_quota[row * S + lane] = (int16_t)(kSpecSched ? my_quota : m->quota[lane]);
+          if (p.log_target) p.log_target[row * S + lane] = (int16_t)(kSpecSched ? my_target : m->target[lane]);
         }
         if (leader) {
           if (p.log_tbs) p.log_tbs[row * U + owner] = tbs;
@@ -1043,10 +1168,55 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
       }
     }
+    if (kSpecSched && spec_next && wave != 0) {
+      /* ---------------- the other waves meanwhile: TTI t+1 as if nobody were served in TTI t ---------------- */
+      const int nsp = nt - 64, me = tid - 64; /* scanning threads and my index among them */
+      /* P1: avg' = (1 - beta) * avg + beta * 0 = (1 - beta) * avg exactly; the unclamped product stays in s_avg (a served
+       * user's exact update adds beta * rate to it), the PF terms use the clamped value */
+      for (int u = me; u < U; u += nsp) {
+        double a = s_avg[u];
+        if (a < 1) a = 1;
+        const double beta = 0.02;
+        const double us = (1 - beta) * a;
+        s_avg[u] = us;
+        pf_terms(u, us < 1 ? 1.0 : us);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) atomicAdd(&fl_cur->ctr_p1, 1);
+      while (rs_lds_load(&fl_cur->ctr_p1) < nwaves - 1) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      /* P3 on the speculative state */
+      const int n_spec = spec_items(n_items);
+      for (int it = me; it < n_spec; it += nsp) scan_item(it, nxt_bu, nxt_rec);
+      /* which of my winners were served?  (wave 0 publishes the served set as soon as the allocation is decided) */
+      while (rs_lds_load(&fl_cur->greedy_done) == 0) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      for (int it0 = (wave - 1) * 64; it0 < n_spec; it0 += nsp) {
+        const int it = it0 + lane;
+        bool need = false;
+        if (it < n_spec) {
+          const int w = nxt_bu[it];
+          need = w != 0xFFFF && ((served_bits[w >> 5] >> (w & 31)) & 1u) != 0u;
+        }
+        const unsigned long long mk = __ballot(need);
+        if (mk != 0ull) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&fl_cur->n_fix, __popcll(mk));
+          base = __builtin_amdgcn_readfirstlane(base);
+          const int slot = base + __popcll(mk & ((1ull << lane) - 1ull));
+          if (need && slot < RS_FIX_CAP) fix_list[slot] = (uint16_t)it;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) atomicAdd(&fl_cur->ctr_p3, 1);
+      /* TTI t+1's quotas: slice offsets and the served count of TTI t are final since the allocation was decided */
+      if (wave == quota_wave) quota_phase(rs_lds_load(&m->served));
+    }
     __builtin_amdgcn_s_setprio(0);
     RS_STAMP(7);
     __syncthreads();
     RS_STAMP(8);
+    have_spec = kSpecSched && spec_next;
     served_prev = m->served;
     n_done += 1;
     if (++epoch_pos == p.refresh) { epoch_pos = 0; ++epoch; }
@@ -1061,15 +1231,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     if (u < U) {
       /* totals = what the EWMA updates consumed + the last TTI's service still waiting in s_tx (marked as counted) */
       const int v = s_tx[u];
-      const long long b = cum_b[ku] + (v & RS_TX_BYTES_MASK), r = cum_r[ku] + ((v >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK);
+      const long long b = (long long)cum_b[ku] + (v & RS_TX_BYTES_MASK), r = (long long)cum_r[ku] + ((v >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK);
       if (b != 0) p.cum_bytes[(size_t)cell * U + u] += b;
       if (r != 0) p.cum_rbs[(size_t)cell * U + u] += r;
-      p.avg[(size_t)cell * U + u] = s_avg[u];
+      p.avg[(size_t)cell * U + u] = (kSpecSched && s_avg[u] < 1) ? 1.0 : s_avg[u];
       p.tx_bytes[(size_t)cell * U + u] = v ? (v | RS_TX_COUNTED) : 0;
     }
   }
   for (int u = tid; u < U && !kCumRegs; u += nt) {
-    p.avg[(size_t)cell * U + u] = s_avg[u];
+    p.avg[(size_t)cell * U + u] = (kSpecSched && s_avg[u] < 1) ? 1.0 : s_avg[u];
     p.tx_bytes[(size_t)cell * U + u] = s_tx[u];
   }
   if (tid < S) p.slice_state[(size_t)cell * S + tid] = s_sstate[tid];

@@ -10,6 +10,13 @@
 
 namespace {
 
+/* a load from LDS that the compiler may neither cache in a register nor turn into a flat access: the flag words other waves
+ * of the workgroup write (workgroup-scope relaxed atomic load = one ds_read_b32) */
+__device__ __forceinline__ int rs_lds_load(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+
 typedef RsMisc Misc;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
