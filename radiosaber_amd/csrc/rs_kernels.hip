@@ -45,6 +45,12 @@
 
 namespace {
 
+#ifndef RS_SPEC_NAP
+#define RS_SPEC_NAP 2 /* s_sleep argument (x 64 cycles) while the scanning waves wait for the allocation */
+#endif
+#ifndef RS_SPEC_PRIO
+#define RS_SPEC_PRIO 0 /* issue priority of the scanning waves during the serial phase */
+#endif
 #ifndef RS_P3_BLOCK
 #define RS_P3_BLOCK 32 /* users ranked per stage-1 block (multiple of 8, <= 32) */
 #endif
@@ -62,6 +68,22 @@ namespace {
   } while (0)
 #else
 #define RS_STAMP(i) do { } while (0)
+#endif
+#ifndef RS_STAMPS_W1_TID
+#define RS_STAMPS_W1_TID 64
+#endif
+#if defined(RS_STAMPS) && defined(RS_STAMPS_W1)
+/* second diagnostic clock: the first scanning thread (wave 1) during the serial phase, into the sort's sub-stamp slots */
+#define RS_STAMP1(i)                                               \
+  do {                                                             \
+    if (tid == RS_STAMPS_W1_TID) {                                 \
+      unsigned long long now_ = __builtin_readcyclecounter();      \
+      sort_sub[i] += now_ - stamp1_prev;                           \
+      stamp1_prev = now_;                                          \
+    }                                                              \
+  } while (0)
+#else
+#define RS_STAMP1(i) do { } while (0)
 #endif
 
 /*
@@ -245,6 +267,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   unsigned long long sort_sub_store[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long* sort_sub = sort_sub_store;
   unsigned long long stamp_prev = __builtin_readcyclecounter();
+  unsigned long long stamp1_prev = 0;
 #endif
   /* position inside the CQI epoch and the epoch's index, kept as counters: a 64-bit modulo per TTI costs more than the
    * quota phase */
@@ -324,8 +347,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     /* items the scanning waves take in the serial phase: whole rounds of nt - 64 lanes (at least one round) */
     auto spec_items = [&](int n) {
       const int nsp_ = nt > 64 ? nt - 64 : 64; /* (one-wave cells never speculate) */
+#ifdef RS_SPEC_ALL
+      return n;
+#else
       const int rounds = n / nsp_;
       return rounds == 0 ? n : rounds * nsp_;
+#endif
     };
     /* PF terms of a user whose average is `a`: exact denominator and stage-1 reciprocal (ref: :685-689) */
     auto pf_terms = [&](int u, double a) {
@@ -414,48 +441,61 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     RS_STAMP(0);
 
     /* ---------------- P2: quotas / slice choice (one wave, lanes = slices) ---------------- */
-    auto quota_phase = [&](int served_before) {
+    /* the quota phase of the transport schedulers in two halves: the draws and the two rotations (which slice receives
+     * the remainders) depend on the rand() stream only; the targets need slice_rbs_offset_ of the previous TTI.  In a
+     * speculated TTI the quota wave runs the first half while wave 0 is still deciding the allocation. */
+    bool q_has = false;
+    int q_nonempty = 0;
+    bool q_first0 = false, q_first1 = false; /* my slice receives the remainder of the PRBs / of the RBGs */
+    auto quota_draws = [&](int served_before) {
       int r0 = p.rand0, r1 = p.rand1;
       if (!kDirect) {
         if (p.phy_draws)
           for (int i = 0; i < served_before; i++) (void)rng.next();
-        if (kTransport) {
-          r0 = rng.next();
-          r1 = rng.next();
-        }
+        r0 = rng.next();
+        r1 = rng.next();
       }
+      /* ref: :463-521 */
+      const bool in = lane < S;
+      q_has = in && (m->seg_begin[lane + 1] > m->seg_begin[lane]);
+      q_nonempty = __popcll(__ballot(q_has));
+      /* first non-empty slice in the rotation k = (i + rand) % S, i = 0..S-1 */
+      const int r0m = (int)((unsigned)r0 % (unsigned)S), r1m = (int)((unsigned)r1 % (unsigned)S);
+      int pos0 = lane - r0m;
+      pos0 = pos0 < 0 ? pos0 + S : pos0;
+      pos0 = q_has ? pos0 : 1 << 20;
+      q_first0 = pos0 == wave_min(pos0);
+      int pos1 = lane - r1m;
+      pos1 = pos1 < 0 ? pos1 + S : pos1;
+      pos1 = q_has ? pos1 : 1 << 20;
+      q_first1 = pos1 == wave_min(pos1);
+    };
+    auto quota_targets = [&]() {
+      const bool in = lane < S;
+      int target = 0;
+      if (q_has) target = (int)(nb_rbs * s_w[lane] + s_sstate[lane]);
+      int extra = nb_rbs - wave_sum(target);
+      const int share = idiv_small(extra, q_nonempty), rem = extra - share * q_nonempty; /* C '/' and '%' */
+      if (q_has) {
+        target += share;
+        if (q_first0) target += rem;
+      }
+      int quota = in ? idiv_small(target, G) : 0;
+      int extra_g = R - wave_sum(quota);
+      const int share_g = idiv_small(extra_g, q_nonempty), rem_g = extra_g - share_g * q_nonempty;
+      if (q_has) {
+        quota += share_g;
+        if (q_first1) quota += rem_g;
+      }
+      m->target[lane] = target;
+      m->quota[lane] = quota;
+    };
+    auto quota_phase = [&](int served_before) {
+      if (!kTransport && !kDirect && p.phy_draws)
+        for (int i = 0; i < served_before; i++) (void)rng.next();
       if (kTransport) {
-        /* ref: :463-521 */
-        const bool in = lane < S;
-        const bool has = in && (m->seg_begin[lane + 1] > m->seg_begin[lane]);
-        const int nonempty = __popcll(__ballot(has));
-        int target = 0;
-        if (has) target = (int)(nb_rbs * s_w[lane] + s_sstate[lane]);
-        int extra = nb_rbs - wave_sum(target);
-        /* first non-empty slice in the rotation k = (i + rand) % S, i = 0..S-1 */
-        const int r0m = (int)((unsigned)r0 % (unsigned)S), r1m = (int)((unsigned)r1 % (unsigned)S);
-        int pos0 = lane - r0m;
-        pos0 = pos0 < 0 ? pos0 + S : pos0;
-        pos0 = has ? pos0 : 1 << 20;
-        int first0 = wave_min(pos0);
-        const int share = idiv_small(extra, nonempty), rem = extra - share * nonempty; /* C '/' and '%' */
-        if (has) {
-          target += share;
-          if (pos0 == first0) target += rem;
-        }
-        int quota = in ? idiv_small(target, G) : 0;
-        int extra_g = R - wave_sum(quota);
-        int pos1 = lane - r1m;
-        pos1 = pos1 < 0 ? pos1 + S : pos1;
-        pos1 = has ? pos1 : 1 << 20;
-        int first1 = wave_min(pos1);
-        const int share_g = idiv_small(extra_g, nonempty), rem_g = extra_g - share_g * nonempty;
-        if (has) {
-          quota += share_g;
-          if (pos1 == first1) quota += rem_g;
-        }
-        m->target[lane] = target;
-        m->quota[lane] = quota;
+        quota_draws(served_before);
+        quota_targets();
       } else if (SCHED == 7 || SCHED == 11) {
         /* SelectSliceToServe, ref: downlink-nvs-scheduler.cpp:94-142 */
         int pick;
@@ -1021,6 +1061,13 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           my_slice = interslice_maximize_cell<kS, kR>(s_sorted, m, S, R, got);
 #endif
         }
+        if (kSpecSched && spec_next && !p.phy_draws) {
+          /* slice_rbs_offset_ is final as soon as the RBGs are dealt out (ref: :618-620): the quota wave can start TTI t+1's
+           * targets while this wave still looks up the winners and adapts the links */
+          if (lane < S) s_sstate[lane] = (double)(my_target - got * G);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) atomicExch(&fl_cur->greedy_done, 1);
+        }
         if (lane < R && my_slice >= 0) {
           int u = cur_bu[my_slice * R + lane];
           owner = u == 0xFFFF ? -1 : u;
@@ -1085,7 +1132,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
          * second look) and let the quota wave start TTI t+1's quotas (slice offsets and the served count are in place) */
         if (leader) atomicOr(&served_bits[owner >> 5], 1u << (owner & 31));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) atomicExch(&fl_cur->greedy_done, 1);
+        if (lane == 0) atomicExch(&fl_cur->greedy_done, 2); /* 1: slice offsets final, 2: served set published too */
       }
       int tbs = 0, nprb = 0, fcqi = 0, mcs = 0;
       int tbs_bytes_next = 0; /* bytes of this TTI's grant, for the served user's next EWMA update (speculated TTIs) */
@@ -1140,8 +1187,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         /* Exact EWMA of the served users for TTI t+1 (ref: src/flows/radio-bearer.cpp:139-164): the scanning waves left
          * (1 - beta) * avg, unclamped, in s_avg; adding beta * rate gives the reference's sum of the two rounded products.
          * Not before every speculative scan is over: they must all have seen one state, the speculative one. */
+        RS_STAMP(7);
         while (rs_lds_load(&fl_cur->ctr_p3) < nwaves - 1) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        RS_STAMP(6);
         if (leader) {
           const double t_next = t + 0.001;
           const double dt_next = t_next - t; /* Now - m_lastUpdate of the next update: m_lastUpdate is this TTI's time */
@@ -1171,6 +1220,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     if (kSpecSched && spec_next && wave != 0) {
       /* ---------------- the other waves meanwhile: TTI t+1 as if nobody were served in TTI t ---------------- */
       const int nsp = nt - 64, me = tid - 64; /* scanning threads and my index among them */
+#if defined(RS_STAMPS) && defined(RS_STAMPS_W1)
+      stamp1_prev = __builtin_readcyclecounter();
+#endif
+      __builtin_amdgcn_s_setprio(RS_SPEC_PRIO);
       /* P1: avg' = (1 - beta) * avg + beta * 0 = (1 - beta) * avg exactly; the unclamped product stays in s_avg (a served
        * user's exact update adds beta * rate to it), the PF terms use the clamped value */
       for (int u = me; u < U; u += nsp) {
@@ -1181,16 +1234,34 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         s_avg[u] = us;
         pf_terms(u, us < 1 ? 1.0 : us);
       }
+      RS_STAMP1(0);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) atomicAdd(&fl_cur->ctr_p1, 1);
       while (rs_lds_load(&fl_cur->ctr_p1) < nwaves - 1) __builtin_amdgcn_s_sleep(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      RS_STAMP1(1);
       /* P3 on the speculative state */
       const int n_spec = spec_items(n_items);
       for (int it = me; it < n_spec; it += nsp) scan_item(it, nxt_bu, nxt_rec);
+      /* TTI t+1's draws and remainder rotations need nothing of TTI t (unless the error model's draws, one per UE served,
+       * come first on the shared stream) */
+      if (wave == quota_wave && !p.phy_draws) quota_draws(0);
       /* which of my winners were served?  (wave 0 publishes the served set as soon as the allocation is decided) */
-      while (rs_lds_load(&fl_cur->greedy_done) == 0) __builtin_amdgcn_s_sleep(1);
+      RS_STAMP1(2);
+      if (wave == quota_wave) {
+        /* TTI t+1's quotas as soon as TTI t's slice offsets are final (with the error model's draws on the stream: once the
+         * served count is known too); wave 0 will wait for this wave, so it runs at wave 0's priority from here on */
+        __builtin_amdgcn_s_setprio(3);
+        const int need_stage = p.phy_draws ? 2 : 1;
+        while (rs_lds_load(&fl_cur->greedy_done) < need_stage) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (p.phy_draws) quota_draws(rs_lds_load(&m->served));
+        quota_targets();
+        RS_STAMP1(5);
+      }
+      while (rs_lds_load(&fl_cur->greedy_done) < 2) __builtin_amdgcn_s_sleep(RS_SPEC_NAP);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      RS_STAMP1(3);
       for (int it0 = (wave - 1) * 64; it0 < n_spec; it0 += nsp) {
         const int it = it0 + lane;
         bool need = false;
@@ -1209,8 +1280,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) atomicAdd(&fl_cur->ctr_p3, 1);
-      /* TTI t+1's quotas: slice offsets and the served count of TTI t are final since the allocation was decided */
-      if (wave == quota_wave) quota_phase(rs_lds_load(&m->served));
+      RS_STAMP1(4);
     }
     __builtin_amdgcn_s_setprio(0);
     RS_STAMP(7);
@@ -1256,10 +1326,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #ifdef RS_STAMPS
     if (p.stamps) {
       for (int i = 0; i < 12; ++i) p.stamps[(size_t)cell * 20 + i] = stamp_acc[i];
+#ifndef RS_STAMPS_W1
       for (int i = 0; i < 8; ++i) p.stamps[(size_t)cell * 20 + 12 + i] = sort_sub[i];
+#endif
     }
 #endif
   }
+#if defined(RS_STAMPS) && defined(RS_STAMPS_W1)
+  if (tid == RS_STAMPS_W1_TID && p.stamps)
+    for (int i = 0; i < 8; ++i) p.stamps[(size_t)cell * 20 + 12 + i] = sort_sub[i];
+#endif
   if (wave == quota_wave && lane == 0) {
     scal->rng_f = rng.f;
     scal->rng_b = rng.b;

@@ -13,7 +13,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import radiosaber_amd as rs  # noqa: E402
 
 NAMES = ["P0+P1 refresh/EWMA (+barrier)", "P2 quotas (if wave 0)", "P3 best user (+barrier)", "P4a introsort loop",
-         "P4b counting sort", "P4c greedy (wave 0)", "-", "P5 link adapt + counters", "barrier end of TTI",
+         "P4b counting sort", "P4c greedy (wave 0)", "wave 0 waits for the scanning waves", "P5 link adapt + counters", "barrier end of TTI",
          "-", "-", "loop head"]
 
 ap = argparse.ArgumentParser()
@@ -24,9 +24,11 @@ ap.add_argument("--rbg-size", type=int, default=4)
 ap.add_argument("--sched", type=int, default=9)
 ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--ues-per-slice", type=int, default=25)
+ap.add_argument("--w1", action="store_true", help="-DRS_STAMPS_W1 build: the sub-stamp slots hold wave 1's serial-phase clock")
+ap.add_argument("--jit", action="store_true", help="shape-specialised kernel (export RS_JIT_EXTRA=-DRS_STAMPS)")
 a = ap.parse_args()
 sc = rs.SliceConfig([a.ues_per_slice] * 20, weight=[0.05] * 20)
-b = rs.BatchScheduler(sc, a.rbgs, a.rbg_size, a.cells, sched=a.sched, threads_per_cell=a.threads)
+b = rs.BatchScheduler(sc, a.rbgs, a.rbg_size, a.cells, sched=a.sched, threads_per_cell=a.threads, jit=a.jit)
 b.seed(np.arange(a.cells, dtype=np.uint32) + 1)
 b.synthesize_cqi(1, (2 * a.ttis + 39) // 40)
 b.run(a.ttis)
@@ -35,7 +37,10 @@ st = np.stack([b.debug_stamps(c) for c in (0, a.cells // 2, a.cells - 1)]).astyp
 tot = st.sum(1)
 print("greedy: RBGs assigned / TTI", st[:, 9] / a.ttis, " sorted position of the last assignment (mean)", st[:, 10] / a.ttis)
 print(f"launch {ms[0]:.3f} ms, {ms[0] * 1e3 / a.ttis:.2f} us/TTI/cell; cycles/TTI (thread 0): {tot / a.ttis}")
-SUB = ["sort F (pivot+ballots)", "sort barrier 1", "sort R (counts, exchange)", "sort barrier 2", "sort S (receive, descend)", "sort barrier 3", "-", "sort levels (count)"]
+if a.w1:
+    SUB = ["scan: EWMA of every user", "scan: wait for the other scanning waves", "scan: items", "scan: wait for the allocation", "scan: (quotas,) served check, list", "-", "-", "-"]
+else:
+  SUB = ["sort F (pivot+ballots)", "sort barrier 1", "sort R (counts, exchange)", "sort barrier 2", "sort S (receive, descend)", "sort barrier 3", "-", "sort levels (count)"]
 tot = st[:, :12].sum(1)
 for i, n in enumerate(SUB):
     print(f"    {n:26s} " + "  ".join(f"{st[c, 12 + i] / a.ttis:9.1f}" for c in range(3)))
