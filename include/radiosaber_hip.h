@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 3 /* 2: rs_tti_in.rand_draws, schedulers 10 / 11 / 101 / 103, rs_trace_*, rs_hbm_copy_probe, rs_lds_bytes_per_cell;
+#define RS_ABI_VERSION 4 /* 4: finite queues in batches (rs_batch_set_bearers, rs_batch_set_arrivals, rs_batch_read_bearer_state, rs_internet_flow_arrivals);
+                            2: rs_tti_in.rand_draws, schedulers 10 / 11 / 101 / 103, rs_trace_*, rs_hbm_copy_probe, rs_lds_bytes_per_cell;
                             3: rs_get_rbg_size, rs_dl_prbs_for_bandwidth, rs_batch_read_clock, rs_batch_jit_status,
                                rs_batch_synthesize_cqi_at, rs_batch_run_logged_ex */
 
@@ -77,8 +78,9 @@ typedef struct rs_config {
   int32_t sched;                /* RS_SCHED_*                                               */
   int32_t device;               /* HIP device ordinal                                       */
   const double* slice_weight;   /* [S] "weight"                                             */
-  const int32_t* algo_alpha;    /* [S] 0, or 1 = customised slice (ref: :694-711): drop-in mode only, the
-                                   queue state comes in through rs_tti_in.hol_delay / prio_has_data  */
+  const int32_t* algo_alpha;    /* [S] 0, or 1 = customised slice (ref: :694-711): the queue state comes in through
+                                   rs_tti_in.hol_delay / prio_has_data (drop-in mode) or from the batch's own queue model
+                                   (rs_batch_set_bearers / rs_batch_set_arrivals)                       */
   const int32_t* algo_beta;     /* [S] 0 or 1: with alpha = 1, multiply the metric by the HoL delay  */
   const int32_t* algo_epsilon;  /* [S] 0 or 1 (pow(x,0)=1, pow(x,1)=x are exact)            */
   const int32_t* algo_psi;      /* [S] 0 or 1                                               */
@@ -246,6 +248,34 @@ int rs_trace_read_ue_log(const char* path, int32_t n_rows, int32_t nb_rbs, int32
                          uint8_t* out_prb);
 int rs_trace_load_dir(const char* dir, int32_t n_traces, int32_t n_rows, int32_t nb_rbs, int32_t rbg_size,
                       uint8_t* out_rbg);
+
+/* ------------------------------------------------------------------------------------------
+ * Finite queues in a batch: what customised slices (algo_alpha = 1) and rate-limited traffic need.
+ * Replaces, per cell: the bearers' MAC queues and RLC dequeue (ref: src/flows/MacQueue.cpp:86-200,
+ * src/protocolStack/rlc/um-rlc-entity.cpp:126-196), HasPackets / GetQueueSize / GetHeadOfLinePacketDelay
+ * (src/flows/radio-bearer.cpp:263-367), SelectFlowsToSchedule + InsertFlowToUser (downlink-transport-scheduler.cpp:105-150,
+ * packet-scheduler.cpp:305-335: users without queued data are not scheduled, slice_priority_, dataToTransmit) and
+ * DoStopSchedule's split of a grant over the user's bearers from the highest priority down (:170-221).
+ * Schedulers 8, 9, 101, 103.  The applications themselves stay outside: the caller hands in every bearer's arrival bursts.
+ * ------------------------------------------------------------------------------------------ */
+/* bearer_kind [U][2], index = bearer priority (RadioBearer::GetPriority, radio-bearer.cpp:88-97): 0 none, 1 InfiniteBuffer
+ * (always has packets, dataToTransmit 1e8), 2 finite MAC queue.  Every user needs at least one bearer.  Before the first run. */
+int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind);
+/* arrival bursts of every finite-queue bearer: bearer (cell c, user u, priority k) owns bursts offsets[(c*U+u)*2+k] ..
+ * offsets[(c*U+u)*2+k+1] of the three arrays (ascending in time).  At time[i] the application enqueues n_full[i] packets of
+ * 1495 bytes (MAXMTUSIZE 1490 + UDP 8 + IP 20, ROHC 28 -> 3, + PDCP 2) and then, if last_bytes[i] > 0, one of last_bytes[i]
+ * bytes; a burst is visible to the TTI whose time stamp is >= time[i]. */
+int rs_batch_set_arrivals(rs_batch* b, const int64_t* offsets, const double* time, const int32_t* n_full, const int32_t* last_bytes);
+/* per bearer, [n_cells][U][2]: PF average, cumulative bytes / RBs (the `cumu_bytes:` / `cumu_rbs:` of the bearer's log lines),
+ * MAC queue bytes and packets; any pointer may be NULL */
+int rs_batch_read_bearer_state(rs_batch* b, double* avg_rate, int64_t* cum_bytes, int64_t* cum_rbs, int32_t* queue_bytes,
+                               int32_t* queue_packets);
+/* host-side generator (no GPU): the arrival bursts of one InternetFlow application (ref: src/flows/application/
+ * InternetFlow.cpp: exponential inter-arrival times rounded up to ms, heavy-tailed flow sizes, 1490-byte packets) between
+ * start_time and stop_time; flow sizes from a libc-compatible rand() stream seeded with size_seed.  Returns the number of
+ * bursts written (<= max_bursts) or a negative RS_ERR_*. */
+int rs_internet_flow_arrivals(double rate_mbps, double start_time, double stop_time, uint32_t size_seed, int32_t max_bursts,
+                              double* time, int32_t* n_full, int32_t* last_bytes);
 
 /* run n_ttis scheduled TTIs of every cell in ONE kernel launch on the batch's stream and wait */
 int rs_batch_run(rs_batch* b, int32_t n_ttis);

@@ -95,6 +95,14 @@ def lib():
         L.rso_run_synth_many.argtypes = [C.POINTER(_Config), C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int,
                                          C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int)]
+        L.rso_cell_enable_queues.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        L.rso_cell_set_arrivals.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32)]
+        L.rso_cell_step_queues.argtypes = [C.c_void_p, C.c_double, C.POINTER(_Rng), C.POINTER(_TtiOut)]
+        L.rso_run_synth_queues.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_uint, C.c_int,
+                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.rso_cell_get_bearer_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.rso_srand.argtypes = [C.POINTER(_Rng), C.c_uint]
         L.rso_rand.argtypes = [C.POINTER(_Rng)]
         for fn in ("rso_greedy_by_row", "rso_maximize_cell", "rso_vogel", "rso_subopt"):
@@ -264,6 +272,43 @@ class Cell:
         a = np.ascontiguousarray(avg_rate, np.float64)
         d = np.ascontiguousarray(draws, np.int32)
         return lib().rso_cell_allocate_nongreedy(self.h, _p(a, C.c_double), slice_id, _p(d, C.c_int), d.size, C.byref(out.c))
+
+    # ---- finite queues (parity unpinned) ----
+    def enable_queues(self, bearer_kind):
+        """bearer_kind [U][2] (index = priority): 0 none, 1 InfiniteBuffer, 2 finite queue."""
+        k = np.ascontiguousarray(bearer_kind, np.uint8)
+        assert k.shape == (self.U, 2)
+        lib().rso_cell_enable_queues(self.h, _p(k, C.c_uint8))
+
+    def set_arrivals(self, user, prio, time, n_full, last):
+        t = np.ascontiguousarray(time, np.float64)
+        nf = np.ascontiguousarray(n_full, np.int32)
+        la = np.ascontiguousarray(last, np.int32)
+        assert t.shape == nf.shape == la.shape
+        lib().rso_cell_set_arrivals(self.h, user, prio, len(t), _p(t, C.c_double), _p(nf, C.c_int32), _p(la, C.c_int32))
+
+    def step_queues(self, now, rng, out):
+        return lib().rso_cell_step_queues(self.h, now, C.byref(rng.g), C.byref(out.c))
+
+    def run_synth_queues(self, cqi_epochs, seed, n_ttis, refresh=40):
+        e = np.ascontiguousarray(cqi_epochs, np.uint8)
+        assert e.shape[1:] == (self.U, self.R)
+        logs = {"rbg_to_user": np.zeros((n_ttis, self.R), np.int32), "tbs_bits": np.zeros((n_ttis, self.U), np.int32)}
+        rc = lib().rso_run_synth_queues(self.h, _p(e, C.c_uint8), e.shape[0], refresh, seed, n_ttis,
+                                        _p(logs["rbg_to_user"], C.c_int), _p(logs["tbs_bits"], C.c_int))
+        if rc:
+            raise RuntimeError(f"rso_run_synth_queues rc={rc}")
+        return logs
+
+    def bearer_state(self):
+        avg = np.zeros((self.U, 2), np.float64)
+        cb = np.zeros((self.U, 2), np.int64)
+        cr = np.zeros((self.U, 2), np.int64)
+        qb = np.zeros((self.U, 2), np.int32)
+        qp = np.zeros((self.U, 2), np.int32)
+        lib().rso_cell_get_bearer_state(self.h, _p(avg, C.c_double), _p(cb, C.c_int64), _p(cr, C.c_int64), _p(qb, C.c_int32),
+                                        _p(qp, C.c_int32))
+        return {"avg_rate": avg, "cum_bytes": cb, "cum_rbs": cr, "queue_bytes": qb, "queue_packets": qp}
 
     def state(self):
         avg = np.zeros(self.U, np.float64)

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <unordered_map>
 #include <utility>
@@ -284,6 +285,26 @@ struct rso_cell {
   std::vector<uint8_t> prio_has_data; /* [U] m_dataToTransmit[slice_priority_[slice]] != 0 */
   std::vector<double> avg2;     /* [U] average rate of the user's second bearer (MAX_BEARERS = 2), < 0: none */
   double eff_of_cqi[16];
+  /* ---- finite queues (rso_cell_enable_queues): two bearers per user, index = priority ---- */
+  struct Packet { int size; double ts; int frag_off; }; /* MacQueue::QueueElement (flows/MacQueue.h) */
+  struct Bearer {
+    int kind = 0;            /* 0 none, 1 InfiniteBuffer, 2 finite queue (InternetFlow / TraceBased) */
+    std::deque<Packet> q;    /* MacQueue::m_queue */
+    int queue_size = 0;      /* MacQueue::m_queueSize  */
+    int n_packets = 0;       /* MacQueue::m_nbDataPackets */
+    double avg = 100000;     /* RadioBearer::m_averageTransmissionRate */
+    int tx_bytes = 0;        /* m_transmittedBytes */
+    double last_update = 0.1;
+    int64_t cum_bytes = 0, cum_rbs = 0;
+    std::vector<double> arr_time; /* arrival bursts: enqueue instants ... */
+    std::vector<int> arr_nfull, arr_last; /* ... full packets of RSO_FULL_PACKET bytes, then one of arr_last bytes (0: none) */
+    size_t next_arr = 0;
+  };
+  std::vector<Bearer> bearers; /* [U][2]; empty: backlogged mode */
+  std::vector<uint8_t> active; /* [U] user is in UsersToSchedule this TTI */
+  std::vector<double> avgsum;  /* [U] 1 + averages of the bearers in the user's record (summed in index order) */
+  std::vector<int> data_tx;    /* [U][2] m_dataToTransmit */
+  std::vector<long> required_rbs; /* [U] m_requiredRBs (sched 7) */
   /* scratch of allocate_transport, kept between TTIs (no per-TTI heap traffic when many cells run on many threads) */
   std::vector<double> scratch_metrics, scratch_slice_eff, scratch_max_rank;
   std::vector<int> scratch_user_index;
@@ -378,8 +399,12 @@ void update_average_rate(rso_cell* c, double now) {
  * averageRate += its average` (:681-686), i.e. (1 + a) + a2 with two bearers. */
 double slice_metric(const rso_cell* c, int slice, double se, double avg_rate, int user = -1) {
   double average = 1;
-  average += avg_rate;
-  if (user >= 0 && !c->avg2.empty() && c->avg2[user] >= 0) average += c->avg2[user];
+  if (user >= 0 && !c->avgsum.empty()) {
+    average = c->avgsum[user]; /* queue mode: 1 + every bearer of the record, summed when the record was built */
+  } else {
+    average += avg_rate;
+    if (user >= 0 && !c->avg2.empty() && c->avg2[user] >= 0) average += c->avg2[user];
+  }
   se = se * 180000 / 1000;
   average /= 1000.0;
   if (c->alpha[slice] == 0) return pow(se, c->eps[slice]) / pow(average, c->psi[slice]);
@@ -445,7 +470,9 @@ int allocate_transport(rso_cell* c, const double* avg, int rand0, int rand1, rso
   std::vector<char> with_data(S, 0);
   std::vector<int> target(S, 0);
   int nonempty = 0, extra_rbs = nb_rbs;
+  const bool listed = !c->active.empty(); /* queue mode: only the users with queued data are in UsersToSchedule */
   for (int u = 0; u < U; u++) {
+    if (listed && !c->active[u]) continue;
     int s = c->u2s[u];
     if (with_data[s]) continue;
     nonempty += 1;
@@ -481,7 +508,8 @@ int allocate_transport(rso_cell* c, const double* avg, int rand0, int rand1, rso
   metrics.resize((size_t)R * U);
   for (int i = 0; i < R; i++)
     for (int j = 0; j < U; j++)
-      metrics[(size_t)i * U + j] = slice_metric(c, c->u2s[j], c->eff_of_cqi[c->cqi[(size_t)j * R + i]], avg[j], j);
+      if (!listed || c->active[j])
+        metrics[(size_t)i * U + j] = slice_metric(c, c->u2s[j], c->eff_of_cqi[c->cqi[(size_t)j * R + i]], avg[j], j);
   /* :545-567 best user of every slice in every RBG, strict '>' from -1: first max wins */
   std::vector<int>& user_index = c->scratch_user_index;
   std::vector<double>& slice_eff = c->scratch_slice_eff;
@@ -491,6 +519,7 @@ int allocate_transport(rso_cell* c, const double* avg, int rand0, int rand1, rso
   for (int i = 0; i < R; i++) {
     max_rank.assign(S, -1);
     for (int j = 0; j < U; j++) {
+      if (listed && !c->active[j]) continue;
       int s = c->u2s[j];
       if (metrics[(size_t)i * U + j] > max_rank[s]) {
         max_rank[s] = metrics[(size_t)i * U + j];
@@ -596,7 +625,16 @@ int allocate_pf(rso_cell* c, const double* avg, rso_tti_out* out) {
 int nvs_select_slice(rso_cell* c) {
   const int S = c->S;
   std::vector<char> with_queue(S, 0);
-  for (int u = 0; u < c->U; u++) with_queue[c->u2s[u]] = 1;
+  if (c->bearers.empty()) {
+    for (int u = 0; u < c->U; u++) with_queue[c->u2s[u]] = 1;
+  } else {
+    /* :101-121: a slice counts when one of its bearers has packets and dataToTransmit > 0 */
+    for (int u = 0; u < c->U; u++)
+      for (int b = 0; b < 2; b++) {
+        const rso_cell::Bearer& br = c->bearers[(size_t)u * 2 + b];
+        if (br.kind == 1 || (br.kind == 2 && !br.q.empty() && br.queue_size + br.n_packets * 8 > 0)) with_queue[c->u2s[u]] = 1;
+      }
+  }
   int slice_id = 0;
   double max_score = 0;
   for (int i = 0; i < S; i++) {
@@ -623,18 +661,23 @@ int allocate_nvs(rso_cell* c, const double* avg, int slice, rso_tti_out* out) {
   std::vector<long> required(U, 0);
   std::vector<int> got(U, 0);
   std::vector<uint8_t> all(R * G);
+  const bool listed = !c->active.empty(); /* queue mode: only the users of the slice that have queued data */
   for (int u = 0; u < U; u++) {
-    if (c->u2s[u] != slice) continue;
+    if (c->u2s[u] != slice || (listed && !c->active[u])) continue;
     for (int r = 0; r < R; r++)
       for (int k = 0; k < G; k++) all[r * G + k] = prb_cqi(c, u, r, k);
     int wide = rso_final_cqi(all.data(), R * G);
-    required[u] = (100000000 * 8) / kTbs[0][kMcsToItbs[kCqiToMcs[wide - 1]]];
+    /* InsertFlowToUser adds to m_requiredRBs only when it creates the user's record, i.e. for the first bearer seen */
+    int first_data = 100000000;
+    if (listed) first_data = c->data_tx[(size_t)u * 2] > 0 ? c->data_tx[(size_t)u * 2] : c->data_tx[(size_t)u * 2 + 1];
+    required[u] = (first_data * 8) / kTbs[0][kMcsToItbs[kCqiToMcs[wide - 1]]];
+    if (listed) c->required_rbs[u] = required[u];
   }
   for (int r = 0; r < R; r++) {
     double target = std::numeric_limits<double>::lowest();
     int pick = -1;
     for (int u = 0; u < U; u++) {
-      if (c->u2s[u] != slice) continue;
+      if (c->u2s[u] != slice || (listed && !c->active[u])) continue;
       double m = slice_metric(c, slice, c->eff_of_cqi[c->cqi[(size_t)u * R + r]], avg[u], u);
       if (m > target && (long)got[u] < required[u]) { target = m; pick = u; }
     }
@@ -879,6 +922,190 @@ int rso_run_synth_many(const rso_config* cfg, int n_cells, const uint8_t* cqi_ep
   if (total_bytes) *total_bytes = bytes;
   if (threads_used) *threads_used = used;
   return rc_all;
+}
+
+
+/* =====================================================================================
+ * Finite queues: bearers with MAC queues, arrivals handed in as bursts.
+ * Restated from flows/MacQueue.cpp (Enqueue :106-121, GetQueueSizeWithMACHoverhead :86-99, GetPacketToTramsit :123-200),
+ * protocolStack/rlc/um-rlc-entity.cpp:126-196 (TransmissionProcedure of a queued bearer), flows/radio-bearer.cpp:281-308
+ * (GetHeadOfLinePacketDelay), :344-367 (HasPackets), downlink-transport-scheduler.cpp:105-221 (SelectFlowsToSchedule,
+ * DoSchedule, DoStopSchedule), packet-scheduler.cpp:305-335 (InsertFlowToUser), downlink-nvs-scheduler.cpp:94-273.
+ * PARITY UNPINNED: no reference output exists for these paths in this image.
+ * ===================================================================================== */
+
+void rso_cell_enable_queues(rso_cell* c, const uint8_t* bearer_kind /* [U][2] */) {
+  c->bearers.assign((size_t)c->U * 2, rso_cell::Bearer());
+  for (size_t i = 0; i < c->bearers.size(); i++) c->bearers[i].kind = bearer_kind[i];
+  c->active.assign(c->U, 0);
+  c->avgsum.assign(c->U, 1);
+  c->data_tx.assign((size_t)c->U * 2, 0);
+  c->required_rbs.assign(c->U, 0);
+  c->hol.assign(c->U, 0);
+  c->prio_has_data.assign(c->U, 0);
+}
+
+void rso_cell_set_arrivals(rso_cell* c, int user, int prio, int n, const double* time, const int32_t* n_full, const int32_t* last) {
+  rso_cell::Bearer& b = c->bearers[(size_t)user * 2 + prio];
+  b.arr_time.assign(time, time + n);
+  b.arr_nfull.assign(n_full, n_full + n);
+  b.arr_last.assign(last, last + n);
+  b.next_arr = 0;
+}
+
+void rso_cell_get_bearer_state(const rso_cell* c, double* avg, int64_t* cum_bytes, int64_t* cum_rbs, int32_t* queue_bytes,
+                               int32_t* queue_packets) {
+  for (size_t i = 0; i < c->bearers.size(); i++) {
+    if (avg) avg[i] = c->bearers[i].avg;
+    if (cum_bytes) cum_bytes[i] = c->bearers[i].cum_bytes;
+    if (cum_rbs) cum_rbs[i] = c->bearers[i].cum_rbs;
+    if (queue_bytes) queue_bytes[i] = c->bearers[i].queue_size;
+    if (queue_packets) queue_packets[i] = c->bearers[i].n_packets;
+  }
+}
+
+static void queue_dequeue(rso_cell::Bearer& b, int available) {
+  /* UmRlcEntity::TransmissionProcedure, queued bearer (um-rlc-entity.cpp:126-196): packets leave the MAC queue one by one,
+   * each costing its data + 8 bytes of RLC/MAC/CRC overhead; the last one may be a fragment */
+  while (available > 0 && !b.q.empty()) {
+    const int overhead = 8;
+    if (overhead >= available) break; /* GetPacketToTramsit returns NULL: availableBytes = 0 */
+    rso_cell::Packet& head = b.q.front();
+    const int data = head.size - head.frag_off; /* a fragment continues at its offset; a fresh packet has offset 0 */
+    if (data + overhead > available) {
+      const int frag = available - overhead;
+      head.frag_off += frag;
+      b.queue_size -= frag;
+      available -= frag + overhead;
+    } else {
+      b.queue_size -= data;
+      b.n_packets -= 1;
+      b.q.pop_front();
+      available -= data + overhead;
+    }
+  }
+}
+
+int rso_cell_step_queues(rso_cell* c, double now, rso_rng* g, rso_tti_out* out) {
+  if (c->bearers.empty()) return -20;
+  if (c->sched == RSO_SCHED_PF || c->sched == RSO_SCHED_NVS_NONGREEDY) return -21; /* per-flow PF / sampler: not restated with queues */
+  const int U = c->U, S = c->S;
+  /* events with a time stamp before this TTI's: the applications' Send() calls (MacQueue::Enqueue per packet) */
+  for (rso_cell::Bearer& b : c->bearers)
+    while (b.kind == 2 && b.next_arr < b.arr_time.size() && b.arr_time[b.next_arr] <= now) {
+      const double ts = b.arr_time[b.next_arr];
+      for (int k = 0; k < b.arr_nfull[b.next_arr]; k++) { b.q.push_back({RSO_FULL_PACKET, ts, 0}); b.queue_size += RSO_FULL_PACKET; b.n_packets++; }
+      if (b.arr_last[b.next_arr] > 0) { b.q.push_back({b.arr_last[b.next_arr], ts, 0}); b.queue_size += b.arr_last[b.next_arr]; b.n_packets++; }
+      b.next_arr++;
+    }
+  /* UpdateAverageTransmissionRate: every bearer of the RRC container (radio-bearer.cpp:139-164) */
+  for (rso_cell::Bearer& b : c->bearers) {
+    if (b.kind == 0 || now == b.last_update) continue;
+    double rate = (b.tx_bytes * 8) / (now - b.last_update);
+    double beta = 0.02;
+    b.avg = ((1 - beta) * b.avg) + (beta * rate);
+    if (b.avg < 1) b.avg = 1;
+    b.tx_bytes = 0;
+    b.last_update = now;
+  }
+  /* SelectFlowsToSchedule + InsertFlowToUser: the users' records */
+  std::vector<int> slice_priority(S, 0);
+  int n_active = 0;
+  for (int u = 0; u < U; u++) {
+    c->active[u] = 0;
+    double sum = 1;
+    for (int b = 0; b < 2; b++) {
+      rso_cell::Bearer& br = c->bearers[(size_t)u * 2 + b];
+      const bool has = br.kind == 1 || (br.kind == 2 && !br.q.empty());
+      int data = 0;
+      if (has) {
+        data = br.kind == 1 ? 100000000 : br.queue_size + br.n_packets * 8; /* GetQueueSizeWithMACHoverhead */
+        c->active[u] = 1;
+        sum += br.avg;
+        if (b > slice_priority[c->u2s[u]]) slice_priority[c->u2s[u]] = b;
+      }
+      c->data_tx[(size_t)u * 2 + b] = data;
+    }
+    c->avgsum[u] = sum;
+    n_active += c->active[u];
+  }
+  for (int u = 0; u < U; u++) {
+    const int p = slice_priority[c->u2s[u]];
+    const rso_cell::Bearer& br = c->bearers[(size_t)u * 2 + p];
+    c->prio_has_data[u] = c->data_tx[(size_t)u * 2 + p] != 0;
+    /* GetHeadOfLinePacketDelay (radio-bearer.cpp:281-308): 0 with an empty MAC queue, else now - head time stamp, >= 1e-5 */
+    double HOL = 0.;
+    if (br.kind != 0 && br.queue_size != 0) {
+      HOL = now - br.q.front().ts;
+      if (HOL < 0.00001) HOL = 0.00001;
+    }
+    c->hol[u] = HOL;
+  }
+  for (int s = 0; s < S; s++) { out->target_rbs[s] = 0; out->quota_rbgs[s] = 0; }
+  for (int r = 0; r < c->R; r++) out->rbg_to_user[r] = -1;
+  for (int u = 0; u < U; u++) { out->user_nprb[u] = 0; out->user_final_cqi[u] = 0; out->user_mcs[u] = 0; out->user_tbs_bits[u] = 0; }
+  out->served_slice = -1;
+  int rc = 0;
+  if (c->sched == RSO_SCHED_NVS) {
+    /* downlink-nvs-scheduler.cpp:196-218: the slice is chosen before anything else; users = the slice's bearers with packets */
+    const int slice = nvs_select_slice(c);
+    int in_slice = 0;
+    for (int u = 0; u < U; u++) {
+      if (c->u2s[u] != slice) c->active[u] = 0;
+      in_slice += c->active[u];
+    }
+    if (in_slice) rc = allocate_nvs(c, c->avg.data(), slice, out);
+    out->served_slice = slice;
+  } else if (n_active) {
+    /* RBsAllocation runs -- and draws its two rand() values -- only when some user has queued data (:160-165) */
+    const int rand0 = rso_rand(g), rand1 = rso_rand(g);
+    rc = allocate_transport(c, c->avg.data(), rand0, rand1, out, true);
+  }
+  if (rc) return rc;
+  /* DoStopSchedule (:170-221 / nvs :220-273): the grant goes to the user's bearers from the highest priority down */
+  for (int u = 0; u < U; u++) {
+    if (!c->active[u]) continue;
+    int available = out->user_tbs_bits[u] / 8;
+    for (int i = 1; i >= 0; i--) {
+      if (available <= 0) break;
+      const int data = c->data_tx[(size_t)u * 2 + i];
+      if (data > 0) {
+        rso_cell::Bearer& br = c->bearers[(size_t)u * 2 + i];
+        const int sent = std::min(available, data);
+        available -= sent;
+        br.tx_bytes += sent;
+        br.cum_bytes += sent;
+        br.cum_rbs += out->user_nprb[u];
+        if (br.kind == 2) queue_dequeue(br, sent);
+      }
+    }
+  }
+  return 0;
+}
+
+/* queue-mode run on synthetic grids: the clock, the CQI refresh and the rand() coupling of rso_run_synth */
+int rso_run_synth_queues(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed, int n_ttis,
+                         int* log_rbg_to_user, int* log_tbs_bits) {
+  const int S = c->S, U = c->U, R = c->R;
+  rso_rng g;
+  rso_srand(&g, seed);
+  std::vector<int> target(S), quota(S), map(R), nprb(U), fcqi(U), mcs(U), tbs(U);
+  rso_tti_out out = {target.data(), quota.data(), map.data(), nprb.data(), fcqi.data(), mcs.data(), tbs.data(), -1, nullptr, nullptr, nullptr, nullptr};
+  double t = 0;
+  for (int k = 0; k < 100; k++) t = clock_advance(t);
+  for (int n = 0; n < n_ttis; n++) {
+    if (n % refresh == 0) {
+      int e = n / refresh;
+      if (e >= n_epochs) return -10;
+      rso_cell_set_cqi(c, cqi_epochs + (size_t)e * U * R);
+    }
+    int rc = rso_cell_step_queues(c, t, &g, &out);
+    if (rc) return rc;
+    if (log_rbg_to_user) memcpy(log_rbg_to_user + (size_t)n * R, map.data(), sizeof(int) * R);
+    if (log_tbs_bits) memcpy(log_tbs_bits + (size_t)n * U, tbs.data(), sizeof(int) * U);
+    t = clock_advance(t);
+  }
+  return 0;
 }
 
 }  // extern "C"

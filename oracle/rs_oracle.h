@@ -164,6 +164,23 @@ int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_rbg_to_user, i
 int rso_run_synth(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed,
                   int phy_error_draws, int n_ttis, int* log_rbg_to_user, int* log_tbs_bits);
 
+/* ---- finite queues.  PARITY UNPINNED (restated from flows/MacQueue.cpp, protocolStack/rlc/um-rlc-entity.cpp,
+ *      flows/radio-bearer.cpp:281-367, downlink-transport-scheduler.cpp:105-221, packet-scheduler.cpp:305-335). ----
+ * bearer_kind [U][2], index = bearer priority: 0 none, 1 InfiniteBuffer, 2 finite queue fed by arrival bursts */
+#define RSO_FULL_PACKET 1495 /* MAXMTUSIZE 1490 + UDP 8 + IP 20, ROHC 28 -> 3, PDCP 2 (protocolStack/packet/Packet.cpp:84-118) */
+void rso_cell_enable_queues(rso_cell* c, const uint8_t* bearer_kind);
+/* arrival bursts of one bearer, ascending in time: at time[i] the application enqueues n_full[i] packets of RSO_FULL_PACKET
+ * bytes and then, if last[i] > 0, one packet of last[i] bytes */
+void rso_cell_set_arrivals(rso_cell* c, int user, int prio, int n, const double* time, const int32_t* n_full, const int32_t* last);
+/* one DoSchedule() with queues: arrivals up to `now`, EWMA of every bearer, the users' records, RBsAllocation (transport
+ * schedulers and sched 7), DoStopSchedule incl. the RLC dequeue */
+int rso_cell_step_queues(rso_cell* c, double now, rso_rng* g, rso_tti_out* out); /* draws 2 values when it allocates */
+int rso_run_synth_queues(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed, int n_ttis,
+                         int* log_rbg_to_user, int* log_tbs_bits);
+/* per bearer [U][2]: PF average, cumulative bytes / RBs, MAC queue bytes and packets; any pointer may be NULL */
+void rso_cell_get_bearer_state(const rso_cell* c, double* avg, int64_t* cum_bytes, int64_t* cum_rbs, int32_t* queue_bytes,
+                               int32_t* queue_packets);
+
 /* the simulated clock at the start of scheduled TTI first_tti + k, k = 0..n-1 (simulator.cc:117-126) */
 void rso_clock_ticks(int first_tti, int n, double* out);
 

@@ -85,6 +85,7 @@ ABI_SYMBOLS = [
     "rs_trace_read_mapping", "rs_trace_read_ue_log", "rs_trace_load_dir", "rs_hbm_copy_probe", "rs_lds_bytes_per_cell",
     "rs_get_rbg_size", "rs_dl_prbs_for_bandwidth", "rs_batch_synthesize_cqi_at", "rs_batch_run_logged_ex",
     "rs_batch_read_clock", "rs_batch_jit_status",
+    "rs_batch_set_bearers", "rs_batch_set_arrivals", "rs_batch_read_bearer_state", "rs_internet_flow_arrivals",
 ]
 
 _lib = None
@@ -117,6 +118,13 @@ def lib():
     L.rs_batch_run_logged_ex.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_BatchLog)]
     L.rs_batch_read_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rs_batch_jit_status.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.rs_batch_set_bearers.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+    L.rs_batch_set_arrivals.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32)]
+    L.rs_batch_read_bearer_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.rs_internet_flow_arrivals.argtypes = [C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_int32, C.POINTER(C.c_double),
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rs_get_rbg_size.argtypes = [C.c_int]
     L.rs_dl_prbs_for_bandwidth.argtypes = [C.c_double]
     L.rs_batch_download_cqi_epochs.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint8)]
@@ -189,6 +197,30 @@ def dl_prbs_for_bandwidth(bw_mhz):
     return lib().rs_dl_prbs_for_bandwidth(float(bw_mhz))
 
 
+BEARER_NONE, BEARER_BACKLOG, BEARER_QUEUE = 0, 1, 2
+FULL_PACKET = 1495  # MAXMTUSIZE 1490 + UDP 8 + IP 20, ROHC 28 -> 3, PDCP 2 (ref: src/protocolStack/packet/Packet.cpp:84-118)
+
+
+def internet_flow_arrivals(rate_mbps, start_time, stop_time, size_seed, max_bursts=1 << 16):
+    """Arrival bursts of one InternetFlow application (ref: src/flows/application/InternetFlow.cpp): (time f64[n], n_full i32[n],
+    last_bytes i32[n]); no GPU needed."""
+    t = np.zeros(max_bursts, np.float64)
+    nf = np.zeros(max_bursts, np.int32)
+    la = np.zeros(max_bursts, np.int32)
+    n = _count(lib().rs_internet_flow_arrivals(rate_mbps, start_time, stop_time, size_seed, max_bursts, _p(t, C.c_double),
+                                               _p(nf, C.c_int32), _p(la, C.c_int32)))
+    return t[:n].copy(), nf[:n].copy(), la[:n].copy()
+
+
+def frames_to_bursts(times, frame_bytes, mtu=1490):
+    """Frames of a video trace as arrival bursts (ref: src/flows/application/TraceBased.cpp:155-224): size/1490 packets of
+    1490 + 5 bytes and, for a remainder, one of remainder + 5 bytes (this application adds the headers to the last packet too)."""
+    fb = np.asarray(frame_bytes, np.int64)
+    rem = fb % mtu
+    return (np.ascontiguousarray(times, np.float64), (fb // mtu).astype(np.int32),
+            np.where(rem > 0, rem + (FULL_PACKET - mtu), 0).astype(np.int32))
+
+
 def lds_bytes_per_cell(n_slices, n_users, n_rbgs, sched=RS_SCHED_MAXCELL, threads=512):
     """LDS bytes of one cell of this shape (<= 40 960: four cells per CU, <= 81 920: two)."""
     return _count(lib().rs_lds_bytes_per_cell(n_slices, n_users, n_rbgs, sched, threads))
@@ -249,6 +281,10 @@ class SliceConfig:
     algo_beta: List[int] = field(default_factory=list)
     algo_epsilon: List[int] = field(default_factory=list)
     algo_psi: List[int] = field(default_factory=list)
+    # per slice, what every UE of the slice runs (single-cell-with-interference.h:226-248, 300-440): {"backlog_flow": n,
+    # "internet_flow": n, "if_bitrate": [Mbps per slice, ...], "video_app": n, "video_bitrate": [kbps, ...]}; empty = one
+    # InfiniteBuffer flow per UE
+    traffic: List[dict] = field(default_factory=list)
 
     def __post_init__(self):
         S = len(self.ues_per_slice)
@@ -265,7 +301,7 @@ class SliceConfig:
     def from_json(cls, path_or_dict):
         obj = path_or_dict if isinstance(path_or_dict, dict) else json.loads(Path(path_or_dict).read_text())
         ues = [int(x) for x in obj["ues_per_slice"]]
-        w, a, b, e, p = [], [], [], [], []
+        w, a, b, e, p, tr = [], [], [], [], [], []
         for grp in obj["slices"]:
             for _ in range(int(grp["n_slices"])):
                 w.append(float(grp["weight"]))
@@ -273,7 +309,27 @@ class SliceConfig:
                 b.append(int(grp.get("algo_beta", 0)))
                 e.append(int(grp.get("algo_epsilon", 0)))
                 p.append(int(grp.get("algo_psi", 0)))
-        return cls(ues, w, a, b, e, p)
+                tr.append({k: grp[k] for k in ("backlog_flow", "internet_flow", "if_bitrate", "video_app", "video_bitrate")
+                           if k in grp})
+        return cls(ues, w, a, b, e, p, tr if any(tr) else [])
+
+    def bearer_kinds(self):
+        """[U][2] bearer kinds (index = priority) from `traffic`: InternetFlow j has priority j, every other application
+        priority 0 (RadioBearer::GetPriority, src/flows/radio-bearer.cpp:88-97)."""
+        k = np.zeros((self.n_users, 2), np.uint8)
+        u2s = self.user_to_slice
+        for u in range(self.n_users):
+            t = self.traffic[u2s[u]] if self.traffic else {}
+            nif = int(t.get("internet_flow", 0))
+            if nif > 2:
+                raise ValueError("more than MAX_BEARERS = 2 internet flows per UE")
+            for j in range(nif):
+                k[u, j] = BEARER_QUEUE
+            if int(t.get("video_app", 0)) and not nif:
+                k[u, 0] = BEARER_QUEUE
+            if (int(t.get("backlog_flow", 0)) or not t) and not k[u, 0]:
+                k[u, 0] = BEARER_BACKLOG
+        return k
 
     @property
     def n_slices(self):
@@ -485,6 +541,40 @@ class BatchScheduler:
         _check(lib().rs_batch_read_state(self._h, _p(avg, C.c_double), _p(cb, C.c_int64), _p(cr, C.c_int64),
                                          _p(sl, C.c_double)))
         return {"avg_rate": avg, "cum_bytes": cb, "cum_rbs": cr, "slice_state": sl}
+
+    # ---- finite queues ----
+    def set_bearers(self, bearer_kind):
+        """bearer_kind [U][2] (index = bearer priority): BEARER_NONE / BEARER_BACKLOG / BEARER_QUEUE."""
+        k = np.ascontiguousarray(bearer_kind, np.uint8)
+        assert k.shape == (self.U, 2)
+        _check(lib().rs_batch_set_bearers(self._h, _p(k, C.c_uint8)))
+        self.bearer_kind = k
+
+    def set_arrivals(self, bursts):
+        """bursts[(cell, user, prio)] = (time f64[n], n_full i32[n], last_bytes i32[n]) for every finite-queue bearer that
+        receives traffic (missing keys: no arrivals)."""
+        nb = self.n_cells * self.U * 2
+        off = np.zeros(nb + 1, np.int64)
+        for (c, u, k), (t, _, _) in bursts.items():
+            off[(c * self.U + u) * 2 + k + 1] = len(t)
+        off = np.cumsum(off)
+        total = int(off[-1])
+        t_all = np.zeros(max(total, 1), np.float64)
+        nf_all = np.zeros(max(total, 1), np.int32)
+        la_all = np.zeros(max(total, 1), np.int32)
+        for (c, u, k), (t, nf, la) in bursts.items():
+            i = int(off[(c * self.U + u) * 2 + k])
+            t_all[i:i + len(t)], nf_all[i:i + len(t)], la_all[i:i + len(t)] = t, nf, la
+        _check(lib().rs_batch_set_arrivals(self._h, _p(off, C.c_int64), _p(t_all, C.c_double), _p(nf_all, C.c_int32),
+                                           _p(la_all, C.c_int32)))
+
+    def bearer_state(self):
+        shp = (self.n_cells, self.U, 2)
+        avg, cb, cr = np.zeros(shp, np.float64), np.zeros(shp, np.int64), np.zeros(shp, np.int64)
+        qb, qp = np.zeros(shp, np.int32), np.zeros(shp, np.int32)
+        _check(lib().rs_batch_read_bearer_state(self._h, _p(avg, C.c_double), _p(cb, C.c_int64), _p(cr, C.c_int64),
+                                                _p(qb, C.c_int32), _p(qp, C.c_int32)))
+        return {"avg_rate": avg, "cum_bytes": cb, "cum_rbs": cr, "queue_bytes": qb, "queue_packets": qp}
 
     def clock(self):
         """(t, last_update): the simulated time of the next TTI and RadioBearer::m_lastUpdate, per cell."""

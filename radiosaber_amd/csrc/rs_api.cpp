@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <random>
 #include <fstream>
 #include <vector>
 
@@ -27,7 +28,7 @@
 extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_t stream);
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes);
 struct RsJitKernel;
-extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, char* err, size_t errlen);
+extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, int queue, char* err, size_t errlen);
 extern "C" hipError_t rs_jit_launch(RsJitKernel* k, const RsLaunch* p, hipStream_t stream);
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,
                                       uint64_t seed, int64_t first_cell, const uint32_t* cdf16, hipStream_t stream);
@@ -238,6 +239,17 @@ struct rs_batch {
   int32_t* d_err = nullptr;
   unsigned long long* d_slice_bytes = nullptr;
   unsigned long long* d_stamps = nullptr;
+  /* finite queues (rs_batch_set_bearers / rs_batch_set_arrivals) */
+  bool queues = false;
+  uint8_t* d_bearer_kind = nullptr;
+  int64_t* d_arr_off = nullptr;
+  double* d_arr_time = nullptr;
+  int32_t *d_arr_nfull = nullptr, *d_arr_last = nullptr;
+  int32_t* d_qi = nullptr;   /* 7 arrays [cells][2][U]: head, tail, pk, frag, bytes, pkts, tx */
+  double* d_bavg = nullptr;  /* [cells][2][U] */
+  int64_t* d_bcum = nullptr; /* 2 arrays [cells][2][U]: bytes, rbs */
+  uint8_t* d_qflags = nullptr;
+  double* d_qhol = nullptr;
   RsJitKernel* jit = nullptr; /* shape-specialised kernel (owned by the process-wide cache) */
   bool jit_wanted = false;
   char jit_msg[512] = ""; /* why the shape-specialised kernel is not in use (empty: it is, or it was not asked for) */
@@ -260,8 +272,6 @@ int validate(const rs_config* c, bool direct) {
   if (!c->slice_weight || !c->algo_alpha || !c->algo_epsilon || !c->algo_psi || !c->user_to_slice)
     return fail(RS_ERR_INVALID, "null slice/user array");
   for (int s = 0; s < c->n_slices; s++) {
-    if (c->algo_alpha[s] != 0 && !direct)
-      return fail(RS_ERR_INVALID, "slice %d: algo_alpha != 0 needs per-TTI queue state: drop-in mode (rs_create) only", s);
     if ((c->algo_alpha[s] | 1) != 1 || (c->algo_alpha[s] && (!c->algo_beta || (c->algo_beta[s] | 1) != 1)))
       return fail(RS_ERR_INVALID, "slice %d: algo_alpha/algo_beta must be 0 or 1", s);
     if ((c->algo_epsilon[s] | 1) != 1 || (c->algo_psi[s] | 1) != 1)
@@ -462,7 +472,7 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
     /* failure is not an error of this call: the built-in kernels stay in use and the batch keeps the reason
      * (rs_batch_jit_status); rs_last_error() is left alone */
     b->jit_wanted = true;
-    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, b->jit_msg, sizeof b->jit_msg);
+    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, b->jit_msg, sizeof b->jit_msg);
     if (b->jit) b->jit_msg[0] = 0;
     else if (!b->jit_msg[0]) snprintf(b->jit_msg, sizeof b->jit_msg, "hiprtc build failed");
   }
@@ -484,6 +494,9 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
            uint32_t* d_keys = nullptr) {
   if (n_ttis < 1) return fail(RS_ERR_INVALID, "n_ttis %d < 1", n_ttis);
   if (b->cqi_mode == RS_CQI_NONE) return fail(RS_ERR_STATE, "no CQI source set");
+  if (b->any_alpha && !b->direct && !b->queues)
+    return fail(RS_ERR_STATE, "customised slices (algo_alpha = 1) read queue state: call rs_batch_set_bearers / rs_batch_set_arrivals first");
+  if (b->queues && !b->d_arr_off) return fail(RS_ERR_STATE, "rs_batch_set_arrivals has not been called");
   if (n_ttis > RS_MAX_TTIS_PER_LAUNCH) {
     /* longer runs go out as several launches (state carries over; the per-launch counters of the kernel are 32-bit) */
     if (d_map || d_tbs || d_uinfo || d_keys) return fail(RS_ERR_INVALID, "logged runs are limited to %d TTIs per call", RS_MAX_TTIS_PER_LAUNCH);
@@ -504,6 +517,15 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
   L.user_trace = b->d_user_trace;
   L.log_map = d_map; L.log_quota = d_quota; L.log_target = d_target; L.log_tbs = d_tbs; L.log_uinfo = d_uinfo;
   L.log_keys = d_keys;
+  if (b->queues) {
+    const size_t n = (size_t)b->n_cells * 2 * b->U;
+    L.bearer_kind = b->d_bearer_kind; L.arr_off = b->d_arr_off; L.arr_time = b->d_arr_time;
+    L.arr_nfull = b->d_arr_nfull; L.arr_last = b->d_arr_last;
+    L.q_head = b->d_qi; L.q_tail = b->d_qi + n; L.q_pk = b->d_qi + 2 * n; L.q_frag = b->d_qi + 3 * n;
+    L.q_bytes = b->d_qi + 4 * n; L.q_pkts = b->d_qi + 5 * n; L.b_tx = b->d_qi + 6 * n;
+    L.b_avg = b->d_bavg; L.b_cumb = b->d_bcum; L.b_cumr = b->d_bcum + n;
+    L.q_flags = b->d_qflags; L.q_hol = b->d_qhol;
+  }
   if (b->jit) HIP_TRY(rs_jit_launch(b->jit, &L, b->stream));
   else HIP_TRY(rs_launch_cells(&L, b->threads, b->stream));
   b->ttis_done += n_ttis;
@@ -520,7 +542,9 @@ void rs_batch_destroy(rs_batch* b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   void* ptrs[] = {b->d_tab, b->d_weight, b->d_eps, b->d_psi, b->d_alpha, b->d_beta, b->d_user_slice, b->d_tbs_eff, b->d_avg, b->d_tx, b->d_cumb, b->d_cumr,
-                  b->d_sstate, b->d_scal, b->d_epochs, b->d_trace, b->d_user_trace, b->d_err, b->d_slice_bytes, b->d_stamps};
+                  b->d_sstate, b->d_scal, b->d_epochs, b->d_trace, b->d_user_trace, b->d_err, b->d_slice_bytes, b->d_stamps,
+                  b->d_bearer_kind, b->d_arr_off, b->d_arr_time, b->d_arr_nfull, b->d_arr_last, b->d_qi, b->d_bavg, b->d_bcum,
+                  b->d_qflags, b->d_qhol};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -708,6 +732,147 @@ int rs_batch_read_state(rs_batch* b, double* avg, int64_t* cum_bytes, int64_t* c
   if (cum_rbs) HIP_TRY(hipMemcpy(cum_rbs, b->d_cumr, 8 * n, hipMemcpyDeviceToHost));
   if (slice_state) HIP_TRY(hipMemcpy(slice_state, b->d_sstate, 8 * (size_t)b->n_cells * b->S, hipMemcpyDeviceToHost));
   return RS_OK;
+}
+
+/* ---- finite queues ---- */
+int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
+  if (!b || !bearer_kind) return fail(RS_ERR_INVALID, "null argument");
+  if (b->direct) return fail(RS_ERR_INVALID, "drop-in contexts take the queue state per TTI (rs_tti_in.hol_delay / prio_has_data)");
+  if (b->ttis_done) return fail(RS_ERR_STATE, "rs_batch_set_bearers after TTIs were run");
+  if (b->sched != RS_SCHED_SEQUENTIAL && b->sched != RS_SCHED_MAXCELL && b->sched != RS_SCHED_SUBOPT && b->sched != RS_SCHED_VOGEL)
+    return fail(RS_ERR_INVALID, "finite queues: schedulers 8, 9, 101 and 103 only (sched %d)", b->sched);
+  const size_t U = b->U;
+  for (size_t u = 0; u < U; u++) {
+    for (int k = 0; k < 2; k++)
+      if (bearer_kind[u * 2 + k] > 2) return fail(RS_ERR_INVALID, "bearer kind %d of user %zu", bearer_kind[u * 2 + k], u);
+    if (!bearer_kind[u * 2] && !bearer_kind[u * 2 + 1]) return fail(RS_ERR_INVALID, "user %zu has no bearer", u);
+  }
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  const size_t n = (size_t)b->n_cells * 2 * U;
+  if (!b->d_bearer_kind) {
+    HIP_TRY(hipMalloc(&b->d_bearer_kind, 2 * U));
+    HIP_TRY(hipMalloc(&b->d_qi, 4 * 7 * n));
+    HIP_TRY(hipMalloc(&b->d_bavg, 8 * n));
+    HIP_TRY(hipMalloc(&b->d_bcum, 8 * 2 * n));
+    HIP_TRY(hipMalloc(&b->d_qflags, (size_t)b->n_cells * U));
+    HIP_TRY(hipMalloc(&b->d_qhol, 8 * (size_t)b->n_cells * U));
+  }
+  HIP_TRY(hipMemcpy(b->d_bearer_kind, bearer_kind, 2 * U, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(b->d_qi, 0, 4 * 7 * n));
+  HIP_TRY(hipMemset(b->d_bcum, 0, 8 * 2 * n));
+  HIP_TRY(hipMemset(b->d_qflags, 0, (size_t)b->n_cells * U));
+  HIP_TRY(hipMemset(b->d_qhol, 0, 8 * (size_t)b->n_cells * U));
+  std::vector<double> avg(n, 100000.0); /* radio-bearer.cpp:54 */
+  HIP_TRY(hipMemcpy(b->d_bavg, avg.data(), 8 * n, hipMemcpyHostToDevice));
+  b->queues = true;
+  if (b->jit_wanted) { /* the shape-specialised kernel of the queue model is a different code object */
+    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 1, b->jit_msg, sizeof b->jit_msg);
+    if (b->jit) b->jit_msg[0] = 0;
+  }
+  return RS_OK;
+}
+
+int rs_batch_set_arrivals(rs_batch* b, const int64_t* offsets, const double* time, const int32_t* n_full, const int32_t* last_bytes) {
+  if (!b || !offsets) return fail(RS_ERR_INVALID, "null argument");
+  if (!b->queues) return fail(RS_ERR_STATE, "rs_batch_set_bearers first");
+  if (b->ttis_done) return fail(RS_ERR_STATE, "rs_batch_set_arrivals after TTIs were run");
+  const size_t nb = (size_t)b->n_cells * b->U * 2;
+  if (offsets[0] != 0) return fail(RS_ERR_INVALID, "offsets[0] must be 0");
+  for (size_t i = 0; i < nb; i++) {
+    if (offsets[i + 1] < offsets[i]) return fail(RS_ERR_INVALID, "offsets must not decrease (bearer %zu)", i);
+    for (int64_t k = offsets[i]; k < offsets[i + 1]; k++) {
+      if (k > offsets[i] && !(time[k] >= time[k - 1])) return fail(RS_ERR_INVALID, "arrival times of bearer %zu are not ascending", i);
+      if (n_full[k] < 0 || last_bytes[k] < 0 || last_bytes[k] > RS_FULL_PACKET || n_full[k] + last_bytes[k] == 0)
+        return fail(RS_ERR_INVALID, "burst %lld of bearer %zu: n_full %d, last %d", (long long)k, i, n_full[k], last_bytes[k]);
+    }
+  }
+  const size_t total = (size_t)offsets[nb];
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  void* old[] = {b->d_arr_off, b->d_arr_time, b->d_arr_nfull, b->d_arr_last};
+  for (void* q : old)
+    if (q) HIP_TRY(hipFree(q));
+  b->d_arr_off = nullptr; b->d_arr_time = nullptr; b->d_arr_nfull = nullptr; b->d_arr_last = nullptr;
+  HIP_TRY(hipMalloc(&b->d_arr_off, 8 * (nb + 1)));
+  HIP_TRY(hipMalloc(&b->d_arr_time, 8 * (total ? total : 1)));
+  HIP_TRY(hipMalloc(&b->d_arr_nfull, 4 * (total ? total : 1)));
+  HIP_TRY(hipMalloc(&b->d_arr_last, 4 * (total ? total : 1)));
+  HIP_TRY(hipMemcpy(b->d_arr_off, offsets, 8 * (nb + 1), hipMemcpyHostToDevice));
+  if (total) {
+    HIP_TRY(hipMemcpy(b->d_arr_time, time, 8 * total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_arr_nfull, n_full, 4 * total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_arr_last, last_bytes, 4 * total, hipMemcpyHostToDevice));
+  }
+  return RS_OK;
+}
+
+int rs_batch_read_bearer_state(rs_batch* b, double* avg, int64_t* cum_bytes, int64_t* cum_rbs, int32_t* queue_bytes,
+                               int32_t* queue_packets) {
+  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  if (!b->queues) return fail(RS_ERR_STATE, "the batch has no bearers (rs_batch_set_bearers)");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const size_t U = b->U, n = (size_t)b->n_cells * 2 * U;
+  /* device layout [cells][2][U] -> [cells][U][2] */
+  auto gather = [&](auto* dst, const auto* src_dev, auto zero) -> int {
+    std::vector<decltype(zero)> tmp(n);
+    HIP_TRY(hipMemcpy(tmp.data(), src_dev, sizeof(zero) * n, hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < (size_t)b->n_cells; c++)
+      for (size_t k = 0; k < 2; k++)
+        for (size_t u = 0; u < U; u++) dst[(c * U + u) * 2 + k] = tmp[(c * 2 + k) * U + u];
+    return RS_OK;
+  };
+  int rc = RS_OK;
+  if (avg && !rc) rc = gather(avg, b->d_bavg, 0.0);
+  if (cum_bytes && !rc) rc = gather(cum_bytes, b->d_bcum, (int64_t)0);
+  if (cum_rbs && !rc) rc = gather(cum_rbs, b->d_bcum + n, (int64_t)0);
+  if (queue_bytes && !rc) rc = gather(queue_bytes, b->d_qi + 4 * n, (int32_t)0);
+  if (queue_packets && !rc) rc = gather(queue_packets, b->d_qi + 5 * n, (int32_t)0);
+  return rc;
+}
+
+/* InternetFlow's arrival process (ref: src/flows/application/InternetFlow.cpp:41-58, 83-90, 155-200): exponential
+ * inter-arrival times from libstdc++'s std::exponential_distribution over a default-constructed std::default_random_engine
+ * (every InternetFlow object owns one, so every flow of a rate sees the same intervals), rounded up to whole
+ * milliseconds; heavy-tailed flow sizes from the table's CDF with one rand() per flow.  The reference draws the sizes from the
+ * process-wide libc stream it shares with the scheduler; a batch has no such global event order, so each bearer gets its
+ * own libc-compatible stream seeded with size_seed (documented deviation of the batched traffic model). */
+int rs_internet_flow_arrivals(double rate_mbps, double start_time, double stop_time, uint32_t size_seed, int32_t max_bursts,
+                              double* time, int32_t* n_full, int32_t* last_bytes) {
+  if (!(rate_mbps > 0) || !(stop_time > start_time) || max_bursts < 1 || !time || !n_full || !last_bytes)
+    return fail(RS_ERR_INVALID, "bad argument");
+  static const int kFlowSize[11] = {1460, 2920, 4380, 7300, 10220, 58400, 105120, 200020, 389820, 1733020, 3076220};
+  static const double kFlowCdf[11] = {0.5, 0.6, 0.7, 0.75, 0.8, 0.8125, 0.825, 0.85, 0.9, 0.95, 1};
+  double avg_flowsize = 0;
+  for (int i = 0; i < 11; i++) avg_flowsize += (i == 0 ? kFlowCdf[0] : kFlowCdf[i] - kFlowCdf[i - 1]) * kFlowSize[i];
+  const int avg_size = (int)avg_flowsize;
+  const double interval_mean = avg_size / rate_mbps * 8 / 1000000;
+  const double lambda = 1 / interval_mean;
+  std::exponential_distribution<double> distribute(lambda);
+  std::default_random_engine generator;
+  HostRng sizes;
+  sizes.seed(size_seed);
+  double now = start_time; /* DoStart schedules the first Send at +0.0 from the application's start */
+  int n = 0;
+  for (;;) {
+    /* Send(): one flow */
+    const double cdf = (double)sizes.next() / 2147483647; /* rand() / RAND_MAX */
+    int flow_size = kFlowSize[10];
+    for (int i = 0; i < 11; i++)
+      if (kFlowCdf[i] >= cdf) { flow_size = kFlowSize[i]; break; }
+    const int last_pkt = flow_size % 1490;
+    const int n_pkts = (int)std::ceil(flow_size / (double)1490);
+    if (n >= max_bursts) return fail(RS_ERR_INVALID, "more than max_bursts = %d flows before stop_time", max_bursts);
+    time[n] = now;
+    /* every packet gets its headers, then the last one is SET to the remainder (no headers on top): :133-136 */
+    n_full[n] = last_pkt != 0 ? n_pkts - 1 : n_pkts;
+    last_bytes[n] = last_pkt;
+    n++;
+    /* ScheduleTransmit(GetInterval()) */
+    const double interval = std::ceil(distribute(generator) * 1000) / 1000.0;
+    if (!((now + interval) < stop_time)) break;
+    now = interval + now; /* Simulator::DoSchedule: timeStamp = time + Now() */
+  }
+  return n;
 }
 
 int rs_batch_read_clock(rs_batch* b, double* t, double* last_update) {

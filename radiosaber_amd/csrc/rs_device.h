@@ -27,6 +27,7 @@ typedef unsigned long size_t;
 #define RS_TX_NPRB_MASK 0x3FF
 #define RS_TX_COUNTED (1 << 30)
 /* a shape-specialised kernel counts a launch's bytes per user in 32 bits: 32 768 TTIs x < 2^16 bytes per TTI */
+#define RS_FULL_PACKET 1495 /* MAXMTUSIZE 1490 + UDP 8 + IP 20, ROHC 28 -> 3, PDCP 2 (ref: src/protocolStack/packet/Packet.cpp:84-118) */
 #define RS_MAX_TTIS_PER_LAUNCH 32768
 #define RS_MAX_BYTES_PER_TTI 65535
 #define RS_PF_SEG 32 /* sched 1: users are scanned in segments of this many for the per-RBG argmax */
@@ -184,6 +185,17 @@ struct RsLaunch {
   const int32_t* beta;       /* [S] */
   const double* hol;         /* [U] head-of-line delay of the slice-priority bearer */
   const uint8_t* prio;       /* [U] prioritized bearer has data (NULL = all) */
+  /* finite queues (batched mode, rs_batch_set_bearers / rs_batch_set_arrivals): two bearers per user, index = priority */
+  const uint8_t* bearer_kind; /* [U][2] 0 none, 1 InfiniteBuffer, 2 finite queue */
+  const int64_t* arr_off;     /* [n_cells*U*2 + 1] first arrival burst of every bearer in the arrays below */
+  const double* arr_time;     /* burst time stamps (ascending per bearer) */
+  const int32_t* arr_nfull;   /* full packets (RS_FULL_PACKET bytes) of the burst */
+  const int32_t* arr_last;    /* bytes of the burst's last packet (0: none) */
+  int32_t *q_head, *q_tail, *q_pk, *q_frag, *q_bytes, *q_pkts, *b_tx; /* [cells][2][U] queue window / progress / totals, bytes since the last EWMA */
+  double* b_avg;              /* [cells][2][U] RadioBearer::m_averageTransmissionRate */
+  int64_t *b_cumb, *b_cumr;   /* [cells][2][U] m_cumulativeBytes / m_cumulativeRBs */
+  uint8_t* q_flags;           /* [cells][U] bit 0: prioritized bearer has data, bit 1: user has queued data */
+  double* q_hol;              /* [cells][U] head-of-line delay of the slice-priority bearer */
   int32_t* log_upper;        /* sched 10, drop-in mode: [S][R] (rbg | user << 8), -1 padded; NULL = off */
   const uint8_t* draws;      /* sched 11, drop-in mode: rand() % 4 of the RS_NVS_SAMPLES x U draws, in draw order */
   const int32_t* tbs_eff;    /* [R+1][27] TBS bits of n RBGs (n*G PRBs) at itbs, incl. the >110-PRB rule */

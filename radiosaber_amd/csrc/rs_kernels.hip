@@ -101,14 +101,20 @@ namespace {
 #define RS_JIT_SCHED 8
 #endif
 
-template <int SCHED, int EPT, bool FIXED, bool DIRECT>
+template <int SCHED, int EPT, bool FIXED, bool DIRECT, bool QUEUE = false>
 __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* lds) {
+  static_assert(!QUEUE || (!DIRECT && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103)),
+                "finite queues: batched transport schedulers only");
   const int cell = blockIdx.x;
   /* only the drop-in entry point (DIRECT: one TTI on caller-provided state) uses these; batches never do, and their
    * kernels carry neither the code nor the registers */
   constexpr bool kDirect = DIRECT;
   const uint8_t* const prb_cqi_in = DIRECT ? p.prb_cqi : nullptr;
-  const int queue_mode_in = DIRECT ? p.queue_mode : 0;
+  const int queue_mode_in = DIRECT ? p.queue_mode : (QUEUE ? 1 : 0);
+  /* customised-slice inputs per user: the caller's arrays (drop-in mode) or this cell's rows of the queue model's
+   * (bit 0: the prioritized bearer has data; queue model only, bit 1: the user has any queued data = is in UsersToSchedule) */
+  const uint8_t* const prio_in = QUEUE ? p.q_flags + (size_t)blockIdx.x * (FIXED ? RS_JIT_U : p.U) : (DIRECT ? p.prio : nullptr);
+  const double* const hol_in = QUEUE ? p.q_hol + (size_t)blockIdx.x * (FIXED ? RS_JIT_U : p.U) : (DIRECT ? p.hol : nullptr);
   const int tid = threadIdx.x;
   const int nt = FIXED ? RS_JIT_NT : (int)blockDim.x;
   const int lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
@@ -128,7 +134,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * user ((1 - beta) * avg, no bytes) and the best user of every (RBG, slice).  Serving a user can only LOWER its metric, so
    * an item whose speculative winner was not served keeps that winner exactly (first-maximum rule included); the few items
    * whose winner was served (~13 %) are listed and rescanned with the true averages after the TTI's closing barrier. */
-  constexpr bool kSpecSched = !DIRECT && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
+  constexpr bool kSpecSched = !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
 #ifdef RS_NO_SPEC
   const bool spec_enabled = false;
 #else
@@ -162,7 +168,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * s_tx[u], the owner unpacks it when the next EWMA update consumes it, and the totals go to HBM once per launch (the
    * built-in kernels, whose users-per-thread count is a run-time value, add to HBM with fire-and-forget atomics instead).
    * Bit 30 of the stored tx word: "already in the HBM totals" (the last TTI's service, flushed with the launch). */
-  constexpr bool kCumRegs = FIXED && !DIRECT;
+  constexpr bool kCumRegs = FIXED && !DIRECT && !QUEUE;
   constexpr int kKU = kCumRegs ? (RS_JIT_U + RS_JIT_NT - 1) / RS_JIT_NT : 1;
   /* 32-bit per launch: the host splits runs so that n_ttis * (largest transport block in bytes) < 2^31 (RS_MAX_TTIS_PER_LAUNCH) */
   int cum_b[kKU], cum_r[kKU];
@@ -285,6 +291,80 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     for (int k = 1; k <= 13; ++k)
       xthr_k[k - 1] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xl), k), __builtin_amdgcn_readlane(__double2loint(xl), k));
   }
+  /* queue model scratch in LDS: m->hist is free outside the counting sort (and the speculation, which the queue model does not use) */
+  int32_t* const q_slice_prio = (int32_t*)m->hist;      /* [64] highest bearer priority with packets, per slice */
+  int32_t* const q_slice_act = (int32_t*)m->hist + 64;  /* [64] the slice has a user with queued data */
+  int32_t* const q_any = &m->nvs_slice; /* slices with data this TTI (0: RBsAllocation does not run); read in the serial phase,
+                                         * i.e. after the counting sort reused m->hist: its own word (unused by these schedulers) */
+    /* ---------------- finite queues: the bearers' MAC queues, one thread per user ----------------
+   * ref: src/flows/MacQueue.cpp:86-200, src/protocolStack/rlc/um-rlc-entity.cpp:126-196, src/flows/radio-bearer.cpp:281-367,
+   * downlink-transport-scheduler.cpp:105-221, packet-scheduler.cpp:305-335.  Per bearer (index = priority) the queue is a
+   * window [head, tail) of its uploaded arrival bursts plus the progress inside the head burst; a burst = n_full packets of
+   * RS_FULL_PACKET bytes and one last packet.  Order per TTI: DoStopSchedule of the previous TTI (grant split from the highest
+   * priority down, RLC dequeue with 8 bytes of overhead per packet, fragmenting the last), EWMA of every bearer, the arrivals
+   * up to now, then the user's record (bearers with packets, dataToTransmit, slice priority, head-of-line delay). */
+  auto bearer_index = [&](int u, int b) -> size_t { return ((size_t)cell * 2 + b) * U + u; };
+  auto queue_data = [&](int kind, size_t bi) -> int { /* m_dataToTransmit of a bearer with packets, else 0 */
+    if (kind == 1) return 100000000;
+    if (kind != 2) return 0;
+    const int pk = p.q_pkts[bi];
+    return pk > 0 ? p.q_bytes[bi] + 8 * pk : 0; /* GetQueueSizeWithMACHoverhead */
+  };
+  auto stop_schedule_user = [&](int u) {
+    const int grant = s_tx[u];
+    if (grant == 0) return;
+    s_tx[u] = 0;
+    int avail = grant & RS_TX_BYTES_MASK;
+    const int nprb = (grant >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK;
+    long long user_bytes = 0;
+    for (int b = 1; b >= 0 && avail > 0; --b) {
+      const int kind = p.bearer_kind[u * 2 + b];
+      const size_t bi = bearer_index(u, b);
+      const int data = queue_data(kind, bi);
+      if (data <= 0) continue;
+      const int sent = avail < data ? avail : data;
+      avail -= sent;
+      p.b_tx[bi] += sent;
+      p.b_cumb[bi] += sent;
+      p.b_cumr[bi] += nprb;
+      user_bytes += sent;
+      if (kind == 2) {
+        /* TransmissionProcedure(sent): whole packets cost their data + 8 bytes, the last one may leave as a fragment */
+        int left = sent, head = p.q_head[bi], pk = p.q_pk[bi], frag = p.q_frag[bi], qb = p.q_bytes[bi], qp = p.q_pkts[bi];
+        const size_t a0 = (size_t)p.arr_off[(size_t)(cell * U + u) * 2 + b];
+        while (left > 8 && qp > 0) {
+          const int nfull = p.arr_nfull[a0 + head], last = p.arr_last[a0 + head];
+          const int size_cur = pk < nfull ? RS_FULL_PACKET : last;
+          const int data_cur = size_cur - frag;
+          if (data_cur + 8 > left) { /* fragment */
+            frag += left - 8;
+            qb -= left - 8;
+            left = 0;
+            break;
+          }
+          left -= data_cur + 8;
+          qb -= data_cur;
+          qp -= 1;
+          frag = 0;
+          pk += 1;
+          if (pk < nfull) { /* a run of untouched full packets leaves in one step */
+            int k = left / (RS_FULL_PACKET + 8);
+            k = k < nfull - pk ? k : nfull - pk;
+            left -= k * (RS_FULL_PACKET + 8);
+            qb -= k * RS_FULL_PACKET;
+            qp -= k;
+            pk += k;
+          }
+          if (pk >= nfull + (last > 0 ? 1 : 0)) { head += 1; pk = 0; }
+        }
+        p.q_head[bi] = head; p.q_pk[bi] = pk; p.q_frag[bi] = frag; p.q_bytes[bi] = qb; p.q_pkts[bi] = qp;
+      }
+    }
+    if (user_bytes) {
+      p.cum_bytes[(size_t)cell * U + u] += user_bytes; /* per-user totals for rs_batch_slice_bytes / read_state */
+      p.cum_rbs[(size_t)cell * U + u] += nprb;
+    }
+  };
   bool have_spec = false; /* this TTI's EWMA, metric scan and quotas were prepared during the previous TTI's serial phase */
   for (int tti = 0; tti < p.n_ttis; ++tti) {
     RS_STAMP(11);
@@ -365,6 +445,91 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       s_rcp32[u + (uo & ~7)] = (uo & 1) ? __builtin_amdgcn_rcpf((float)k) : 1.0f; /* v_rcp_f32, 1 ulp */
     };
     /* ---------------- P1: PF EWMA (ref: src/flows/radio-bearer.cpp:139-164) ---------------- */
+    if constexpr (QUEUE) {
+      if (tid < 64) { q_slice_prio[tid] = 0; q_slice_act[tid] = 0; }
+      __syncthreads();
+      const bool do_ewma = !(t == last_update);
+      const double dt = t - last_update;
+      for (int u = tid; u < U; u += nt) {
+        stop_schedule_user(u);
+        bool has[2] = {false, false};
+        double bavg[2] = {0, 0};
+        for (int b = 0; b < 2; ++b) {
+          const int kind = p.bearer_kind[u * 2 + b];
+          if (kind == 0) continue;
+          const size_t bi = bearer_index(u, b);
+          /* RadioBearer::UpdateAverageTransmissionRate: every bearer, scheduled or not */
+          double a = p.b_avg[bi];
+          if (do_ewma) {
+            const double rate = (double)(p.b_tx[bi] * 8) / dt;
+            const double beta = 0.02;
+            a = ((1 - beta) * a) + (beta * rate);
+            if (a < 1) a = 1;
+            p.b_avg[bi] = a;
+            p.b_tx[bi] = 0;
+          }
+          bavg[b] = a;
+          if (kind == 2) {
+            /* the applications' Send() events with a time stamp up to now (MacQueue::Enqueue per packet) */
+            const size_t a0 = (size_t)p.arr_off[(size_t)(cell * U + u) * 2 + b];
+            const int n_arr = (int)((size_t)p.arr_off[(size_t)(cell * U + u) * 2 + b + 1] - a0);
+            int tail = p.q_tail[bi], qb = p.q_bytes[bi], qp = p.q_pkts[bi];
+            const int tail0 = tail;
+            while (tail < n_arr && p.arr_time[a0 + tail] <= t) {
+              const int nfull = p.arr_nfull[a0 + tail], last = p.arr_last[a0 + tail];
+              qb += nfull * RS_FULL_PACKET + last;
+              qp += nfull + (last > 0 ? 1 : 0);
+              tail += 1;
+            }
+            if (tail != tail0) { p.q_tail[bi] = tail; p.q_bytes[bi] = qb; p.q_pkts[bi] = qp; }
+            has[b] = qp > 0;
+          } else {
+            has[b] = true; /* InfiniteBuffer: HasPackets() is always true */
+          }
+        }
+        const bool active = has[0] || has[1];
+        double k = 1; /* averageRate = 1; += every bearer of the record, in index order (:681-686) */
+        if (has[0]) k += bavg[0];
+        if (has[1]) k += bavg[1];
+        k /= 1000.0;
+        s_avgk[u] = k;
+        if (active) {
+          const int sl = p.user_slice[u];
+          atomicMax(&q_slice_prio[sl], has[1] ? 1 : 0);
+          q_slice_act[sl] = 1;
+        }
+        p.q_flags[(size_t)cell * U + u] = active ? 2 : 0;
+      }
+      last_update = t;
+      __syncthreads();
+      for (int u = tid; u < U; u += nt) {
+        const int flags = p.q_flags[(size_t)cell * U + u];
+        const int sl = p.user_slice[u];
+        const int uo = s_uoff[u];
+        float r32 = 0.0f;
+        if (flags & 2) {
+          r32 = (uo & 1) ? __builtin_amdgcn_rcpf((float)s_avgk[u]) : 1.0f;
+          if (p.alpha[sl]) {
+            /* customised slice (ref: :694-711): the slice's priority = the highest bearer priority with packets in the slice */
+            const int pb = q_slice_prio[sl];
+            const int kind = p.bearer_kind[u * 2 + pb];
+            const size_t bi = bearer_index(u, pb);
+            const bool has_data = queue_data(kind, bi) != 0;
+            double hol = 0.0; /* GetHeadOfLinePacketDelay: 0 with an empty MAC queue (an InfiniteBuffer bearer has none) */
+            if (kind == 2 && p.q_bytes[bi] != 0) {
+              const size_t a0 = (size_t)p.arr_off[(size_t)(cell * U + u) * 2 + pb];
+              hol = t - p.arr_time[a0 + p.q_head[bi]];
+              if (hol < 0.00001) hol = 0.00001;
+            }
+            p.q_hol[(size_t)cell * U + u] = hol;
+            p.q_flags[(size_t)cell * U + u] = 2 | (has_data ? 1 : 0);
+            r32 = !has_data ? 0.0f : (p.beta[sl] != 0 ? r32 * (float)hol : r32);
+          }
+        }
+        s_rcp32[u + (uo & ~7)] = r32;
+      }
+      __syncthreads();
+    } else
     if (!have_spec) {
       const bool do_ewma = !kDirect && !(t == last_update);
       const double dt = t - last_update;
@@ -400,9 +565,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
              * head-of-line delay when beta (sched 7: always) -- folded into the stage-1 factor */
             const int sl = p.user_slice[u];
             if (p.alpha[sl]) {
-              const bool has = p.prio ? p.prio[u] != 0 : true;
+              const bool has = prio_in ? (prio_in[u] & 1) != 0 : true;
               const bool use_hol = SCHED == 7 || SCHED == 11 || p.beta[sl] != 0;
-              r32 = !has ? 0.0f : (use_hol ? r32 * (float)p.hol[u] : r32);
+              r32 = !has ? 0.0f : (use_hol ? r32 * (float)hol_in[u] : r32);
             }
             s_rcp32[u + (uo & ~7)] = r32;
           }
@@ -448,17 +613,18 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     int q_nonempty = 0;
     bool q_first0 = false, q_first1 = false; /* my slice receives the remainder of the PRBs / of the RBGs */
     auto quota_draws = [&](int served_before) {
+      /* ref: :463-521 */
+      const bool in = lane < S;
+      q_has = in && (QUEUE ? q_slice_act[lane] != 0 : (m->seg_begin[lane + 1] > m->seg_begin[lane]));
+      q_nonempty = __popcll(__ballot(q_has));
+      if (QUEUE && lane == 0) *q_any = q_nonempty;
       int r0 = p.rand0, r1 = p.rand1;
-      if (!kDirect) {
+      if (!kDirect && !(QUEUE && q_nonempty == 0)) { /* (no user with queued data: RBsAllocation does not run, :160-165) */
         if (p.phy_draws)
           for (int i = 0; i < served_before; i++) (void)rng.next();
         r0 = rng.next();
         r1 = rng.next();
       }
-      /* ref: :463-521 */
-      const bool in = lane < S;
-      q_has = in && (m->seg_begin[lane + 1] > m->seg_begin[lane]);
-      q_nonempty = __popcll(__ballot(q_has));
       /* first non-empty slice in the rotation k = (i + rand) % S, i = 0..S-1 */
       const int r0m = (int)((unsigned)r0 % (unsigned)S), r1m = (int)((unsigned)r1 % (unsigned)S);
       int pos0 = lane - r0m;
@@ -475,6 +641,11 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       int target = 0;
       if (q_has) target = (int)(nb_rbs * s_w[lane] + s_sstate[lane]);
       int extra = nb_rbs - wave_sum(target);
+      if (QUEUE && q_nonempty == 0) { /* nothing to schedule this TTI */
+        m->target[lane] = 0;
+        m->quota[lane] = 0;
+        return;
+      }
       const int share = idiv_small(extra, q_nonempty), rem = extra - share * q_nonempty; /* C '/' and '%' */
       if (q_has) {
         target += share;
@@ -741,8 +912,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           /* both table reads are issued whatever the slice's exponents are (no branch around an LDS read) */
           const double num_c = s_num[c], den_u = s_avgk[u];
           const double num = sl_eps ? num_c : 1.0, den = sl_psi ? den_u : 1.0;
-          if (sl_custom && p.prio && p.prio[u] == 0) return 0.0;
-          if (sl_custom == 2) return p.hol[u] * num / den; /* HoL * pow(se) / pow(avg), left to right */
+          if (QUEUE && (prio_in[u] & 2) == 0) return -2.0; /* not in UsersToSchedule: below the scan's start value of -1 */
+          if (sl_custom && prio_in && (prio_in[u] & 1) == 0) return 0.0;
+          if (sl_custom == 2) return hol_in[u] * num / den; /* HoL * pow(se) / pow(avg), left to right */
           return num / den;
         };
 #ifdef RS_EXP_P3_SKIP
@@ -826,7 +998,14 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             for (int k = 0; k < kP3Block; ++k) cand |= av[k] >= thr ? (1u << k) : 0u;
             /* customised slices can rank every user at 0 (no prioritized data): the reference's scan then
              * keeps the first user (0 > -1), so that user goes to stage 2 */
-            if (!cand) cand = 1u << ((ub > blk ? ub : blk) - blk);
+            if (!cand) {
+              if (QUEUE) { /* users without queued data are not in the list: every slot of the slice, the first listed one wins */
+#pragma unroll
+                for (int k = 0; k < kP3Block; ++k) cand |= (blk + k >= ub && blk + k < ue) ? (1u << k) : 0u;
+              } else {
+                cand = 1u << ((ub > blk ? ub : blk) - blk);
+              }
+            }
             while (cand) {
               const int j = __ffs((int)cand) - 1;
               cand &= cand - 1;
@@ -1125,7 +1304,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       const unsigned long long lead_mask = __ballot(leader);
       served_prev = __popcll(lead_mask);
       /* ref: :618-620 slice_rbs_offset_ = target - final_rbgs*rbg_size */
-      if (kTransport && lane < S) s_sstate[lane] = (double)((kSpecSched ? my_target : m->target[lane]) - got * G);
+      if (kTransport && lane < S && !(QUEUE && *q_any == 0))
+        s_sstate[lane] = (double)((kSpecSched ? my_target : m->target[lane]) - got * G);
       if (lane == 0) m->served = served_prev;
       if (kSpecSched && spec_next) {
         /* the allocation is decided: tell the scanning waves who was served (their speculative winners among these need a
@@ -1170,8 +1350,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           int bytes = tbs / 8;
           if (bytes > 100000000) bytes = 100000000;
           if (bytes > 0) {
-            if (kCumRegs) {
-              s_tx[owner] += bytes | (nprb << RS_TX_NPRB_SHIFT); /* the owner thread of P1 counts it (registers) */
+            if (kCumRegs || QUEUE) {
+              /* the owner thread of P1 counts it (registers) / splits it over the user's bearers and dequeues (queue model) */
+              s_tx[owner] += bytes | (nprb << RS_TX_NPRB_SHIFT);
             } else {
               /* the next EWMA update consumes the bytes: in a speculated TTI that happens right below, on this lane */
               if (!(kSpecSched && spec_next)) s_tx[owner] += bytes;
@@ -1293,6 +1474,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     if (!kDirect) t += 0.001; /* ref: src/core/eventScheduler/simulator.cc:117-126 */
   }
 
+  if constexpr (QUEUE) {
+    /* DoStopSchedule of the launch's last TTI, so that the bearers' counters and queues the host reads are complete */
+    for (int u = tid; u < U; u += nt) stop_schedule_user(u);
+  }
   /* ---------------- store the cell ---------------- */
 #pragma unroll
   for (int ku = 0; ku < (kCumRegs ? kKU : 1); ++ku) {
@@ -1345,18 +1530,21 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 }  // namespace
 
 #ifndef RS_JIT_BUILD
-template <int SCHED, int EPT, bool DIRECT>
+template <int SCHED, int EPT, bool DIRECT, bool QUEUE = false>
 __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
   extern __shared__ __align__(16) unsigned char lds[];
-  rs_cell_body<SCHED, EPT, false, DIRECT>(p, lds);
+  rs_cell_body<SCHED, EPT, false, DIRECT, QUEUE>(p, lds);
 }
 #else
+#ifndef RS_JIT_QUEUE
+#define RS_JIT_QUEUE 0
+#endif
 /* shape-specialised entry point compiled at run time (rs_jit.cpp): static LDS of exactly the carve's size */
 extern "C" __global__ void __launch_bounds__(RS_JIT_NT, 4) rs_cell_kernel_jit(RsLaunch p) {
   constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT);
   __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
   constexpr int kEpt = (RS_JIT_SCHED != 9 && RS_JIT_SCHED != 10) ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);
-  rs_cell_body<RS_JIT_SCHED, kEpt, true, false>(p, lds);
+  rs_cell_body<RS_JIT_SCHED, kEpt, true, false, RS_JIT_QUEUE != 0>(p, lds);
 }
 #endif
 
@@ -1439,6 +1627,24 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
     if (p->direct) hipLaunchKernelGGL((rs_cell_kernel<SCHED_, EPT_, true>), grid, block, p->lds_bytes, stream, *p); \
     else hipLaunchKernelGGL((rs_cell_kernel<SCHED_, EPT_, false>), grid, block, p->lds_bytes, stream, *p);         \
   } while (0)
+#define RS_LAUNCH_QUEUE(SCHED_, EPT_) \
+  hipLaunchKernelGGL((rs_cell_kernel<SCHED_, EPT_, false, true>), grid, block, p->lds_bytes, stream, *p)
+  if (p->bearer_kind != nullptr) { /* finite queues (batches of the transport schedulers only; the host has checked) */
+    switch (p->sched) {
+      case 8: RS_LAUNCH_QUEUE(8, 0); break;
+      case 101: RS_LAUNCH_QUEUE(101, 0); break;
+      case 103: RS_LAUNCH_QUEUE(103, 0); break;
+      case 9:
+        if (ept <= 1) RS_LAUNCH_QUEUE(9, 1);
+        else if (ept <= 2) RS_LAUNCH_QUEUE(9, 2);
+        else if (ept <= 3) RS_LAUNCH_QUEUE(9, 3);
+        else if (ept <= 4) RS_LAUNCH_QUEUE(9, 4);
+        else RS_LAUNCH_QUEUE(9, 0);
+        break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (p->sched) {
     case 1: RS_LAUNCH_CELL(1, 0); break;
     case 7: RS_LAUNCH_CELL(7, 0); break;
@@ -1469,7 +1675,11 @@ extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes) {
 #define RS_BOTH(SCHED_, EPT_) (const void*)rs_cell_kernel<SCHED_, EPT_, false>, (const void*)rs_cell_kernel<SCHED_, EPT_, true>
   const void* fns[] = {RS_BOTH(1, 0),  RS_BOTH(7, 0),  RS_BOTH(8, 0),  RS_BOTH(101, 0), RS_BOTH(103, 0), RS_BOTH(11, 0),
                        RS_BOTH(10, 1), RS_BOTH(10, 2), RS_BOTH(10, 3), RS_BOTH(10, 4),
-                       RS_BOTH(9, 0),  RS_BOTH(9, 1),  RS_BOTH(9, 2),  RS_BOTH(9, 3),  RS_BOTH(9, 4)};
+                       RS_BOTH(9, 0),  RS_BOTH(9, 1),  RS_BOTH(9, 2),  RS_BOTH(9, 3),  RS_BOTH(9, 4),
+                       (const void*)rs_cell_kernel<8, 0, false, true>, (const void*)rs_cell_kernel<101, 0, false, true>,
+                       (const void*)rs_cell_kernel<103, 0, false, true>, (const void*)rs_cell_kernel<9, 0, false, true>,
+                       (const void*)rs_cell_kernel<9, 1, false, true>, (const void*)rs_cell_kernel<9, 2, false, true>,
+                       (const void*)rs_cell_kernel<9, 3, false, true>, (const void*)rs_cell_kernel<9, 4, false, true>};
 #undef RS_BOTH
 
   for (const void* f : fns) {

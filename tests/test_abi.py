@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(rs):
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/radiosaber_hip.h but not exported"
     assert sorted(api.ABI_SYMBOLS) == declared
-    assert L.rs_abi_version() == 3
+    assert L.rs_abi_version() == 4
 
 
 def test_code_object_is_gfx950(rs):
@@ -75,7 +75,7 @@ def test_no_cpu_fallback(rs):
 
 def test_config_validation_messages(rs):
     L = rs.lib()
-    for kw, frag in ((dict(algo_alpha=[1, 0]), "algo_alpha"), (dict(algo_epsilon=[2, 1]), "algo_epsilon")):
+    for kw, frag in ((dict(algo_alpha=[2, 0]), "algo_alpha"), (dict(algo_epsilon=[2, 1]), "algo_epsilon")):
         sc = rs.SliceConfig([2, 2], **kw)
         with pytest.raises(rs.RadioSaberError) as e:
             rs.BatchScheduler(sc, 12, 2, 1)

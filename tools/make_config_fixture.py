@@ -24,6 +24,7 @@ for f in sorted(glob.glob(str(REF / "**" / "*.json"), recursive=True)):
         scheds |= {int(x) for x in re.findall(r"SingleCellWithI\s+\d+\s+(\d+)", Path(sh).read_text())}
     out[rel] = {"ues_per_slice": list(sc.ues_per_slice), "weight": list(sc.weight), "algo_alpha": list(sc.algo_alpha),
                 "algo_beta": list(sc.algo_beta), "algo_epsilon": list(sc.algo_epsilon), "algo_psi": list(sc.algo_psi),
+                "traffic": list(sc.traffic),
                 "schedulers_in_run_scripts": sorted(scheds)}
 (ROOT / "tests" / "golden" / "experiment_configs.json").write_text(json.dumps(out, indent=0))
 print(len(out), "configurations")
