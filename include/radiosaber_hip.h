@@ -256,7 +256,12 @@ int rs_trace_load_dir(const char* dir, int32_t n_traces, int32_t n_rows, int32_t
  * (src/flows/radio-bearer.cpp:263-367), SelectFlowsToSchedule + InsertFlowToUser (downlink-transport-scheduler.cpp:105-150,
  * packet-scheduler.cpp:305-335: users without queued data are not scheduled, slice_priority_, dataToTransmit) and
  * DoStopSchedule's split of a grant over the user's bearers from the highest priority down (:170-221).
- * Schedulers 8, 9, 101, 103.  The applications themselves stay outside: the caller hands in every bearer's arrival bursts.
+ * Schedulers 8, 9, 101, 103 and, RBG by RBG on one wave because their gates bind with finite queues, 7 (a user leaves the race
+ * once its PRBs reach m_requiredRBs, downlink-nvs-scheduler.cpp:299-300 with packet-scheduler.cpp:319-334) and 1 (every bearer
+ * with packets is a flow with its own PF average; a flow leaves once the transport block of its PRBs so far carries its queue,
+ * downlink-packet-scheduler.cpp:221-265; rbg_to_user then holds flow ids 2 * user + bearer and DoStopSchedule credits whole
+ * transport blocks, dl-pf-packet-scheduler.cpp:60-125).  The applications themselves stay outside: the caller hands in every
+ * bearer's arrival bursts.
  * ------------------------------------------------------------------------------------------ */
 /* bearer_kind [U][2], index = bearer priority (RadioBearer::GetPriority, radio-bearer.cpp:88-97): 0 none, 1 InfiniteBuffer
  * (always has packets, dataToTransmit 1e8), 2 finite MAC queue.  Every user needs at least one bearer.  Before the first run. */

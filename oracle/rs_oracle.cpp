@@ -986,9 +986,65 @@ static void queue_dequeue(rso_cell::Bearer& b, int available) {
   }
 }
 
+/* DownlinkPacketScheduler::RBsAllocation on FLOWS (sched 1 with finite queues; downlink-packet-scheduler.cpp:179-331,
+ * dl-pf-packet-scheduler.cpp:60-140): a flow = a bearer with packets, in RRC container order (user ascending, bearer index
+ * ascending); metric (se * 180000.) / the bearer's own average; a flow leaves the competition once the transport block of
+ * its PRBs so far carries its whole queue (:253-265).  DoStopSchedule credits the whole block to the flow and hands it to
+ * the RLC.  rbg_to_user reports the flow id 2 * user + bearer. */
+static int step_pf_flows(rso_cell* c, rso_tti_out* out) {
+  const int U = c->U, R = c->R, G = c->rbg_size;
+  std::vector<int> flows;
+  for (int u = 0; u < U; u++)
+    for (int b = 0; b < 2; b++)
+      if (c->data_tx[(size_t)u * 2 + b] > 0) flows.push_back(u * 2 + b);
+  const int F = (int)flows.size();
+  if (F == 0) return 0;
+  std::vector<char> done(F, 0);
+  std::vector<std::vector<uint8_t>> prbs(F);
+  int n_done = 0;
+  for (int r = 0; r < R; r++) {
+    if (n_done == F) break;
+    double target = 0;
+    int pick = -1;
+    for (int k = 0; k < F; k++) {
+      const int u = flows[k] >> 1;
+      double se = c->eff_of_cqi[c->cqi[(size_t)u * R + r]];
+      double metric = (se * 180000.) / c->bearers[flows[k]].avg;
+      if (metric > target && !done[k]) { target = metric; pick = k; }
+    }
+    if (pick < 0) continue;
+    out->rbg_to_user[r] = flows[pick];
+    for (int k = 0; k < G; k++) prbs[pick].push_back(prb_cqi(c, flows[pick] >> 1, r, k));
+    int fc = rso_final_cqi(prbs[pick].data(), (int)prbs[pick].size());
+    int tbs = rso_tbs_bits(kCqiToMcs[fc - 1], (int)prbs[pick].size());
+    if (tbs >= c->data_tx[flows[pick]] * 8) { done[pick] = 1; n_done++; }
+  }
+  for (int k = 0; k < F; k++) {
+    if (prbs[k].empty()) continue;
+    const int u = flows[k] >> 1;
+    int fc = rso_final_cqi(prbs[k].data(), (int)prbs[k].size());
+    int mcs = kCqiToMcs[fc - 1];
+    int tbs = rso_tbs_bits(mcs, (int)prbs[k].size());
+    out->user_nprb[u] += (int)prbs[k].size();
+    out->user_final_cqi[u] = fc;
+    out->user_mcs[u] = mcs;
+    out->user_tbs_bits[u] += tbs;
+    /* DL_PF_PacketScheduler::DoStopSchedule (dl-pf-packet-scheduler.cpp:60-125) */
+    int available = tbs / 8;
+    if (available > 0) {
+      rso_cell::Bearer& br = c->bearers[flows[k]];
+      br.tx_bytes += available;
+      br.cum_bytes += available;
+      br.cum_rbs += (int)prbs[k].size();
+      if (br.kind == 2) queue_dequeue(br, available);
+    }
+  }
+  return 0;
+}
+
 int rso_cell_step_queues(rso_cell* c, double now, rso_rng* g, rso_tti_out* out) {
   if (c->bearers.empty()) return -20;
-  if (c->sched == RSO_SCHED_PF || c->sched == RSO_SCHED_NVS_NONGREEDY) return -21; /* per-flow PF / sampler: not restated with queues */
+  if (c->sched == RSO_SCHED_NVS_NONGREEDY || c->sched == RSO_SCHED_UPPERBOUND) return -21; /* not restated with queues */
   const int U = c->U, S = c->S;
   /* events with a time stamp before this TTI's: the applications' Send() calls (MacQueue::Enqueue per packet) */
   for (rso_cell::Bearer& b : c->bearers)
@@ -1046,6 +1102,7 @@ int rso_cell_step_queues(rso_cell* c, double now, rso_rng* g, rso_tti_out* out) 
   for (int u = 0; u < U; u++) { out->user_nprb[u] = 0; out->user_final_cqi[u] = 0; out->user_mcs[u] = 0; out->user_tbs_bits[u] = 0; }
   out->served_slice = -1;
   int rc = 0;
+  if (c->sched == RSO_SCHED_PF) return step_pf_flows(c, out); /* incl. its own DoStopSchedule */
   if (c->sched == RSO_SCHED_NVS) {
     /* downlink-nvs-scheduler.cpp:196-218: the slice is chosen before anything else; users = the slice's bearers with packets */
     const int slice = nvs_select_slice(c);

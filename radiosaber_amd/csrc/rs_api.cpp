@@ -288,12 +288,13 @@ int validate(const rs_config* c, bool direct) {
 int upad_of(int U) { return rs_upad_of(U); }
 
 void carve_lds(rs_batch* b, RsLaunch* L) {
-  const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads);
+  const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads, b->queues ? 1 : 0);
   L->Upad = c.Upad;
   L->nvs_seg = c.nvs_seg;
   L->off_avgk = c.off_avgk; L->off_rcp = c.off_rcp; L->off_tab = c.off_tab; L->off_slice = c.off_slice;
   L->off_tx = c.off_tx; L->off_misc = c.off_misc; L->off_tbs = c.off_tbs; L->off_elems = c.off_elems;
   L->off_sorted = c.off_sorted; L->off_items = c.off_items; L->off_sortx = c.off_sortx; L->off_cqi = c.off_cqi;
+  L->off_queue = c.off_queue;
   L->lds_bytes = c.lds_bytes;
   L->n_seg = c.n_seg;
   L->n_items = c.n_items;
@@ -339,6 +340,7 @@ int batch_alloc(rs_batch* b) {
     t.eff[c] = eff[c];
     t.mcs_of_cqi[c] = kCqiToMcs[c - 1];
     t.itbs_of_cqi[c] = kMcsToItbs[kCqiToMcs[c - 1]];
+    t.tbs1_of_cqi[c] = kTbs[0][kMcsToItbs[kCqiToMcs[c - 1]]];
   }
   /* AMCModule.cpp:313-315 reads TransportBlockSizeTable[-1][itbs] when nbRBs > 110 and nbRBs % 5 == 0.
    * In the as-shipped -O0 build McsToItbs[29] sits 128 bytes in front of the table, so
@@ -739,8 +741,9 @@ int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
   if (!b || !bearer_kind) return fail(RS_ERR_INVALID, "null argument");
   if (b->direct) return fail(RS_ERR_INVALID, "drop-in contexts take the queue state per TTI (rs_tti_in.hol_delay / prio_has_data)");
   if (b->ttis_done) return fail(RS_ERR_STATE, "rs_batch_set_bearers after TTIs were run");
-  if (b->sched != RS_SCHED_SEQUENTIAL && b->sched != RS_SCHED_MAXCELL && b->sched != RS_SCHED_SUBOPT && b->sched != RS_SCHED_VOGEL)
-    return fail(RS_ERR_INVALID, "finite queues: schedulers 8, 9, 101 and 103 only (sched %d)", b->sched);
+  if (b->sched != RS_SCHED_SEQUENTIAL && b->sched != RS_SCHED_MAXCELL && b->sched != RS_SCHED_SUBOPT && b->sched != RS_SCHED_VOGEL &&
+      b->sched != RS_SCHED_PF && b->sched != RS_SCHED_NVS)
+    return fail(RS_ERR_INVALID, "finite queues: schedulers 1, 7, 8, 9, 101 and 103 only (sched %d)", b->sched);
   const size_t U = b->U;
   for (size_t u = 0; u < U; u++) {
     for (int k = 0; k < 2; k++)
@@ -765,6 +768,8 @@ int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
   std::vector<double> avg(n, 100000.0); /* radio-bearer.cpp:54 */
   HIP_TRY(hipMemcpy(b->d_bavg, avg.data(), 8 * n, hipMemcpyHostToDevice));
   b->queues = true;
+  carve_lds(b, &b->base); /* schedulers 1 and 7 keep per-bearer scratch in LDS in this mode */
+  if (b->base.lds_bytes > 160 * 1024) return fail(RS_ERR_INVALID, "cell needs %d B of LDS (> 160 KiB)", b->base.lds_bytes);
   if (b->jit_wanted) { /* the shape-specialised kernel of the queue model is a different code object */
     b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 1, b->jit_msg, sizeof b->jit_msg);
     if (b->jit) b->jit_msg[0] = 0;

@@ -67,7 +67,7 @@ struct RsMisc {
 struct RsCarve {
   int Upad, n_seg, n_items, ept, nvs_seg;
   int off_avgk, off_rcp, off_tab, off_slice, off_tx, off_misc, off_tbs, off_elems, off_sorted, off_items,
-      off_sortx, off_cqi, lds_bytes;
+      off_sortx, off_cqi, off_queue, lds_bytes;
 };
 constexpr int rs_round_up(int x, int a) { return (x + a - 1) / a * a; }
 constexpr int rs_upad_of(int U) {
@@ -90,7 +90,10 @@ constexpr int rs_nvs_scratch_bytes(int U, int R) {
  * (user u16 + metric f64 per RBG) are reduced per RBG in ascending order afterwards.  With slices of more than 32 users on
  * average rs_carve picks the smallest run length in {8, 16, 32} that keeps the cell at or under 80 KB of LDS (two cells per
  * CU); otherwise nvs_seg = 0: one work item per RBG scans the whole slice (measured on 25-user slices: runs cost 8-10 %). */
-constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int nvs_seg) {
+/* queue = 1: the batch runs the queue model (finite MAC queues, two bearers per user); schedulers 1 and 7 then allocate RBG by
+ * RBG on one wave (the per-flow "satisfied" break / the m_requiredRBs gate) and keep per-bearer scratch in LDS:
+ * grant1 i32[U] | data0 i32[U] | data1 i32[U] | need i32[U] | flags u8[2U] */
+constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int nvs_seg, int queue = 0) {
   RsCarve c{};
   c.Upad = rs_upad_of(U);
   c.nvs_seg = nvs_seg;
@@ -119,10 +122,12 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
   c.off_sortx = off; off += (sched == 9 || sched == 10) ? rs_round_up(c.ept <= 4 ? 4 * (R * S / 16 + 2) : 8 * R * S, 16)
                                                            : (sched == 11 ? rs_round_up(rs_nvs_scratch_bytes(U, R), 16) : (sched == 101 ? RS_UMAP_SCRATCH_BYTES : 0));
   c.off_cqi = off; off += rs_round_up(c.Upad * R, 16);
+  c.off_queue = off; off += (queue && (sched == 1 || sched == 7)) ? rs_round_up(18 * U, 16) : 0;
   c.lds_bytes = off;
   return c;
 }
-constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads) {
+constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads, int queue = 0) {
+  if (queue) return rs_carve_with(S, U, R, sched, threads, 0, queue); /* (sched 7 with queues: no split runs, no metric scan) */
   if (sched == 7 && U > 32 * S) { /* slices of more than 32 users on average: one run per work item is too long */
     for (int seg = 8; seg <= 16; seg *= 2) {
       const RsCarve c = rs_carve_with(S, U, R, sched, threads, seg);
@@ -143,6 +148,7 @@ struct RsTables {
   int32_t mcs_of_cqi[16];
   int32_t itbs_of_cqi[16];
   int32_t tbs_row_m1[28]; /* the reference's T[-1][itbs] at -O0 (see rs_kernels.hip)  */
+  int32_t tbs1_of_cqi[16]; /* TBS bits of one PRB at a CQI (GetTBSizeFromMCS(mcs), AMCModule.cpp:299-303): m_requiredRBs */
 };
 
 /* per-cell scalar state that survives between launches */
@@ -225,7 +231,7 @@ struct RsLaunch {
   unsigned long long* stamps; /* diagnostic build (-DRS_STAMPS): [cells][20] phase cycles, else unused */
   /* LDS carve (byte offsets from the dynamic LDS base) */
   int32_t off_avgk, off_rcp, off_tx, off_tab, off_slice, off_items, off_elems,
-      off_sorted, off_sortx, off_misc, off_tbs, off_cqi, lds_bytes;
+      off_sorted, off_sortx, off_misc, off_tbs, off_cqi, off_queue, lds_bytes;
   int32_t n_seg, n_items;    /* segments per RBG scan, R*n_seg */
 };
 

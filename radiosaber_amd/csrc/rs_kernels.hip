@@ -103,8 +103,10 @@ namespace {
 
 template <int SCHED, int EPT, bool FIXED, bool DIRECT, bool QUEUE = false>
 __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* lds) {
-  static_assert(!QUEUE || (!DIRECT && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103)),
-                "finite queues: batched transport schedulers only");
+  static_assert(!QUEUE || (!DIRECT && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103 || SCHED == 1 || SCHED == 7)),
+                "finite queues: batches of schedulers 1, 7, 8, 9, 101, 103");
+  /* schedulers 1 and 7 with queues allocate RBG by RBG on wave 0 (the satisfied-flow break / the m_requiredRBs gate bind) */
+  constexpr bool kQSerial = QUEUE && (SCHED == 1 || SCHED == 7);
   const int cell = blockIdx.x;
   /* only the drop-in entry point (DIRECT: one TTI on caller-provided state) uses these; batches never do, and their
    * kernels carry neither the code nor the registers */
@@ -119,14 +121,14 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   const int nt = FIXED ? RS_JIT_NT : (int)blockDim.x;
   const int lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
   const int S = FIXED ? RS_JIT_S : p.S, U = FIXED ? RS_JIT_U : p.U, R = FIXED ? RS_JIT_R : p.R, G = FIXED ? RS_JIT_G : p.G;
-  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT);
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, QUEUE ? 1 : 0);
   /* byte offsets of the LDS arrays: constants in a shape-specialised build */
-  struct Offs { int avgk, rcp, tab, slice, tx, misc, tbs, elems, sorted, items, sortx, cqi, Upad, n_seg, n_items; };
+  struct Offs { int avgk, rcp, tab, slice, tx, misc, tbs, elems, sorted, items, sortx, cqi, queue, Upad, n_seg, n_items; };
   const Offs o = FIXED ? Offs{kCv.off_avgk, kCv.off_rcp, kCv.off_tab, kCv.off_slice, kCv.off_tx, kCv.off_misc, kCv.off_tbs,
-                              kCv.off_elems, kCv.off_sorted, kCv.off_items, kCv.off_sortx, kCv.off_cqi, kCv.Upad,
+                              kCv.off_elems, kCv.off_sorted, kCv.off_items, kCv.off_sortx, kCv.off_cqi, kCv.off_queue, kCv.Upad,
                               kCv.n_seg, kCv.n_items}
                        : Offs{p.off_avgk, p.off_rcp, p.off_tab, p.off_slice, p.off_tx, p.off_misc, p.off_tbs, p.off_elems,
-                              p.off_sorted, p.off_items, p.off_sortx, p.off_cqi, p.Upad, p.n_seg, p.n_items};
+                              p.off_sorted, p.off_items, p.off_sortx, p.off_cqi, p.off_queue, p.Upad, p.n_seg, p.n_items};
   constexpr bool kTransport = (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103 || SCHED == 10);
   const int quota_wave = nwaves - 1; /* P2 runs on the last wave, beside the other waves' P3 */
   /* Speculative next-TTI metric scan.  In the schedulers whose inter-slice step and link adaptation run on
@@ -292,6 +294,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       xthr_k[k - 1] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xl), k), __builtin_amdgcn_readlane(__double2loint(xl), k));
   }
   /* queue model scratch in LDS: m->hist is free outside the counting sort (and the speculation, which the queue model does not use) */
+  /* schedulers 1 and 7: per-bearer scratch (rs_carve_with) */
+  int32_t* const q_grant1 = (int32_t*)(lds + o.queue);   /* [U] sched 1: this TTI's grant of the user's second flow (the first: s_tx) */
+  int32_t* const q_data0 = q_grant1 + U;                 /* [U] m_dataToTransmit of bearer 0 (0: no packets) */
+  int32_t* const q_data1 = q_data0 + U;                  /* [U] ... of bearer 1 */
+  int32_t* const q_need = q_data1 + U;                   /* [U] sched 7: m_requiredRBs minus the PRBs allocated so far */
+  uint8_t* const q_done = (uint8_t*)(q_need + U);        /* [2U] sched 1: the flow is satisfied */
+  if constexpr (kQSerial) {
+    for (int u = tid; u < U; u += nt) q_grant1[u] = 0; /* (a launch ends with every grant consumed) */
+    __syncthreads();
+  }
   int32_t* const q_slice_prio = (int32_t*)m->hist;      /* [64] highest bearer priority with packets, per slice */
   int32_t* const q_slice_act = (int32_t*)m->hist + 64;  /* [64] the slice has a user with queued data */
   int32_t* const q_any = &m->nvs_slice; /* slices with data this TTI (0: RBsAllocation does not run); read in the serial phase,
@@ -310,7 +322,63 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     const int pk = p.q_pkts[bi];
     return pk > 0 ? p.q_bytes[bi] + 8 * pk : 0; /* GetQueueSizeWithMACHoverhead */
   };
+  /* one bearer's RLC dequeue of `sent` bytes (TransmissionProcedure): whole packets cost their data + 8 bytes, the last one may
+   * leave as a fragment */
+  auto rlc_dequeue = [&](int u, int b, size_t bi, int sent) {
+    int left = sent, head = p.q_head[bi], pk = p.q_pk[bi], frag = p.q_frag[bi], qb = p.q_bytes[bi], qp = p.q_pkts[bi];
+    const size_t a0 = (size_t)p.arr_off[(size_t)(cell * U + u) * 2 + b];
+    while (left > 8 && qp > 0) {
+      const int nfull = p.arr_nfull[a0 + head], last = p.arr_last[a0 + head];
+      const int size_cur = pk < nfull ? RS_FULL_PACKET : last;
+      const int data_cur = size_cur - frag;
+      if (data_cur + 8 > left) { /* fragment */
+        frag += left - 8;
+        qb -= left - 8;
+        left = 0;
+        break;
+      }
+      left -= data_cur + 8;
+      qb -= data_cur;
+      qp -= 1;
+      frag = 0;
+      pk += 1;
+      if (pk < nfull) { /* a run of untouched full packets leaves in one step */
+        int k = left / (RS_FULL_PACKET + 8);
+        k = k < nfull - pk ? k : nfull - pk;
+        left -= k * (RS_FULL_PACKET + 8);
+        qb -= k * RS_FULL_PACKET;
+        qp -= k;
+        pk += k;
+      }
+      if (pk >= nfull + (last > 0 ? 1 : 0)) { head += 1; pk = 0; }
+    }
+    p.q_head[bi] = head; p.q_pk[bi] = pk; p.q_frag[bi] = frag; p.q_bytes[bi] = qb; p.q_pkts[bi] = qp;
+  };
   auto stop_schedule_user = [&](int u) {
+    if constexpr (SCHED == 1) {
+      /* DL_PF_PacketScheduler::DoStopSchedule (dl-pf-packet-scheduler.cpp:60-125): every flow is credited its own transport
+       * block in full and hands it to its RLC */
+      long long user_bytes = 0, user_rbs = 0;
+      for (int b = 0; b < 2; ++b) {
+        int32_t* slot = b == 0 ? &s_tx[u] : &q_grant1[u];
+        const int grant = *slot;
+        if (grant == 0) continue;
+        *slot = 0;
+        const int bytes = grant & RS_TX_BYTES_MASK, nprb = (grant >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK;
+        const size_t bi = bearer_index(u, b);
+        p.b_tx[bi] += bytes;
+        p.b_cumb[bi] += bytes;
+        p.b_cumr[bi] += nprb;
+        user_bytes += bytes;
+        user_rbs += nprb;
+        if (p.bearer_kind[u * 2 + b] == 2) rlc_dequeue(u, b, bi, bytes);
+      }
+      if (user_bytes) {
+        p.cum_bytes[(size_t)cell * U + u] += user_bytes;
+        p.cum_rbs[(size_t)cell * U + u] += user_rbs;
+      }
+      return;
+    }
     const int grant = s_tx[u];
     if (grant == 0) return;
     s_tx[u] = 0;
@@ -328,37 +396,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       p.b_cumb[bi] += sent;
       p.b_cumr[bi] += nprb;
       user_bytes += sent;
-      if (kind == 2) {
-        /* TransmissionProcedure(sent): whole packets cost their data + 8 bytes, the last one may leave as a fragment */
-        int left = sent, head = p.q_head[bi], pk = p.q_pk[bi], frag = p.q_frag[bi], qb = p.q_bytes[bi], qp = p.q_pkts[bi];
-        const size_t a0 = (size_t)p.arr_off[(size_t)(cell * U + u) * 2 + b];
-        while (left > 8 && qp > 0) {
-          const int nfull = p.arr_nfull[a0 + head], last = p.arr_last[a0 + head];
-          const int size_cur = pk < nfull ? RS_FULL_PACKET : last;
-          const int data_cur = size_cur - frag;
-          if (data_cur + 8 > left) { /* fragment */
-            frag += left - 8;
-            qb -= left - 8;
-            left = 0;
-            break;
-          }
-          left -= data_cur + 8;
-          qb -= data_cur;
-          qp -= 1;
-          frag = 0;
-          pk += 1;
-          if (pk < nfull) { /* a run of untouched full packets leaves in one step */
-            int k = left / (RS_FULL_PACKET + 8);
-            k = k < nfull - pk ? k : nfull - pk;
-            left -= k * (RS_FULL_PACKET + 8);
-            qb -= k * RS_FULL_PACKET;
-            qp -= k;
-            pk += k;
-          }
-          if (pk >= nfull + (last > 0 ? 1 : 0)) { head += 1; pk = 0; }
-        }
-        p.q_head[bi] = head; p.q_pk[bi] = pk; p.q_frag[bi] = frag; p.q_bytes[bi] = qb; p.q_pkts[bi] = qp;
-      }
+      if (kind == 2) rlc_dequeue(u, b, bi, sent);
     }
     if (user_bytes) {
       p.cum_bytes[(size_t)cell * U + u] += user_bytes; /* per-user totals for rs_batch_slice_bytes / read_state */
@@ -488,6 +526,18 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           }
         }
         const bool active = has[0] || has[1];
+        if constexpr (kQSerial) {
+          q_data0[u] = has[0] ? queue_data(p.bearer_kind[u * 2], bearer_index(u, 0)) : 0;
+          q_data1[u] = has[1] ? queue_data(p.bearer_kind[u * 2 + 1], bearer_index(u, 1)) : 0;
+          q_done[2 * u] = 0;
+          q_done[2 * u + 1] = 0;
+        }
+        if constexpr (SCHED == 1) {
+          /* flows, not users: each bearer competes with its own average (dl-pf-packet-scheduler.cpp:128-140) */
+          s_avg[u] = bavg[0];
+          s_avgk[u] = bavg[1];
+          continue;
+        }
         double k = 1; /* averageRate = 1; += every bearer of the record, in index order (:681-686) */
         if (has[0]) k += bavg[0];
         if (has[1]) k += bavg[1];
@@ -502,7 +552,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       }
       last_update = t;
       __syncthreads();
-      for (int u = tid; u < U; u += nt) {
+      for (int u = tid; u < U && SCHED != 1; u += nt) {
         const int flags = p.q_flags[(size_t)cell * U + u];
         const int sl = p.user_slice[u];
         const int uo = s_uoff[u];
@@ -523,7 +573,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             }
             p.q_hol[(size_t)cell * U + u] = hol;
             p.q_flags[(size_t)cell * U + u] = 2 | (has_data ? 1 : 0);
-            r32 = !has_data ? 0.0f : (p.beta[sl] != 0 ? r32 * (float)hol : r32);
+            r32 = !has_data ? 0.0f : ((SCHED == 7 || p.beta[sl] != 0) ? r32 * (float)hol : r32);
           }
         }
         s_rcp32[u + (uo & ~7)] = r32;
@@ -674,7 +724,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           pick = 0; /* the caller passes only the served slice's users */
         } else {
           const bool in = lane < S;
-          const bool has = in && (m->seg_begin[lane + 1] > m->seg_begin[lane]);
+          /* slices with queued data (ref: :101-121; with queues: a bearer with packets and dataToTransmit > 0) */
+          const bool has = in && (QUEUE ? q_slice_act[lane] != 0 : (m->seg_begin[lane + 1] > m->seg_begin[lane]));
           double ew = in ? s_sstate[lane] : 1.0;
           unsigned long long zero = __ballot(has && ew == 0);
           unsigned long long hasm = __ballot(has);
@@ -913,6 +964,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           const double num_c = s_num[c], den_u = s_avgk[u];
           const double num = sl_eps ? num_c : 1.0, den = sl_psi ? den_u : 1.0;
           if (QUEUE && (prio_in[u] & 2) == 0) return -2.0; /* not in UsersToSchedule: below the scan's start value of -1 */
+          /* (schedulers 1 and 7 with queues do not come here: serial allocator below) */
           if (sl_custom && prio_in && (prio_in[u] & 1) == 0) return 0.0;
           if (sl_custom == 2) return hol_in[u] * num / den; /* HoL * pow(se) / pow(avg), left to right */
           return num / den;
@@ -1030,7 +1082,32 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
       }
     };
-    if constexpr (SCHED != 11) {
+    if constexpr (kQSerial && SCHED == 7) {
+      /* m_requiredRBs (packet-scheduler.cpp:319-334): the data of the bearer that created the user's record, in PRBs of the
+       * wideband MCS -- EESM over every PRB of the band in order, G identical terms per RBG */
+      const int ub = m->seg_begin[seg_lo], ue = m->seg_begin[seg_lo + 1];
+      for (int u = ub + tid; u < ue; u += nt) {
+        int need = 0;
+        if (prio_in[u] & 2) {
+          double sum = 0;
+          for (int r = 0; r < R; ++r) {
+            const double ev = s_e[s_cqi[r * Upad + u]];
+            for (int k = 0; k < G; ++k) sum += ev;
+          }
+          const double x = sum / (double)(R * G);
+          int wide = 15;
+          if (!(x == 0)) {
+            wide = 1;
+#pragma unroll
+            for (int k = 1; k <= 13; ++k) wide += (x <= xthr_k[k - 1]) ? 1 : 0;
+          }
+          const int first = q_data0[u] > 0 ? q_data0[u] : q_data1[u];
+          need = (first * 8) / tab->tbs1_of_cqi[wide];
+        }
+        q_need[u] = need;
+      }
+    }
+    if constexpr (SCHED != 11 && !kQSerial) {
       /* fix-up of a speculated TTI: only the items whose speculative winner was served in the previous TTI (listed by the
        * scanning waves) are scanned again, now with the true averages; a list that overflowed means all of them.  One loop
        * for both cases: the scan is inlined once here and once in the serial phase. */
@@ -1226,7 +1303,87 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         if (lane == 0) { fl_prev->ctr_p1 = 0; fl_prev->ctr_p3 = 0; fl_prev->greedy_done = 0; fl_prev->n_fix = 0; }
         if (spec_next && lane < 32) served_bits[lane] = 0u;
       }
-      if constexpr (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103) {
+      if constexpr (kQSerial) {
+        /* Schedulers 1 and 7 with finite queues: RBG by RBG, the first maximum among the candidates still in the race --
+         * flows whose transport block does not yet carry their queue (downlink-packet-scheduler.cpp:221-265) / users of the
+         * served slice below their m_requiredRBs (downlink-nvs-scheduler.cpp:283-308).  Lanes = candidates, 64 at a time;
+         * metrics are >= 0, so their bit patterns order like (high word signed, low word unsigned): two DPP max reductions
+         * and the lowest lane among the equals; a later chunk only wins with a strictly larger metric. */
+        int c_lo = 0, c_hi = 2 * U; /* sched 1: flow ids 2 * user + bearer */
+        int sl_eps = 1, sl_psi = 1, sl_custom = 0;
+        if (SCHED == 7) {
+          c_lo = m->seg_begin[seg_lo];
+          c_hi = m->seg_begin[seg_lo + 1];
+          sl_eps = m->eps_psi[seg_lo] & 1;
+          sl_psi = (m->eps_psi[seg_lo] >> 1) & 1;
+          sl_custom = p.alpha[seg_lo] != 0;
+        }
+        for (int r = 0; r < R; ++r) {
+          int bhi = -1, blo = (int)0x80000000, bpick = -1;
+          for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+            const int cnd = c0 + lane;
+            const int u = SCHED == 1 ? cnd >> 1 : cnd;
+            bool valid = cnd < c_hi;
+            double metric = 0.0;
+            if (valid) {
+              const int cq = s_cqi[r * Upad + u];
+              if (SCHED == 1) {
+                const int data = (cnd & 1) ? q_data1[u] : q_data0[u];
+                valid = data > 0 && q_done[cnd] == 0;
+                metric = s_num[cq] / ((cnd & 1) ? s_avgk[u] : s_avg[u]); /* (se * 180000.) / the flow's own average */
+                valid = valid && metric > 0; /* the scan starts from 0 with '>' */
+              } else {
+                valid = (prio_in[u] & 2) != 0 && q_need[u] > 0;
+                const double num = sl_eps ? s_num[cq] : 1.0, den = sl_psi ? s_avgk[u] : 1.0;
+                if (!sl_custom) metric = num / den;
+                else metric = (prio_in[u] & 1) == 0 ? 0.0 : hol_in[u] * num / den; /* ref: nvs :375-387 */
+              }
+            }
+            const int hi = valid ? __double2hiint(metric) : -1;
+            const int lo = (int)((unsigned)__double2loint(metric) ^ 0x80000000u);
+            const int mhi = wave_max(hi);
+            const int mlo = wave_max(hi == mhi ? lo : (int)0x80000000);
+            if (mhi >= 0 && (mhi > bhi || (mhi == bhi && mlo > blo))) {
+              bhi = mhi;
+              blo = mlo;
+              bpick = c0 + __ffsll((long long)__ballot(valid && hi == mhi && lo == mlo)) - 1;
+            }
+          }
+          if (lane == r) owner = bpick;
+          if (bpick >= 0) {
+            if (SCHED == 7) {
+              if (lane == 0) q_need[bpick] -= G;
+            } else {
+              /* the flow's transport block so far (its PRBs in RBG order): satisfied once it carries the whole queue */
+              const unsigned long long mine = __ballot(owner == bpick && lane <= r);
+              if (lane == r) {
+                const int u = bpick >> 1;
+                unsigned long long mm = mine;
+                double sum = 0;
+                int nprb = 0;
+                while (mm) {
+                  const int r2 = __ffsll((long long)mm) - 1;
+                  mm &= mm - 1;
+                  const double ev = s_e[s_cqi[r2 * Upad + u]];
+                  for (int k = 0; k < G; ++k) sum += ev;
+                  nprb += G;
+                }
+                const double x = sum / (double)nprb;
+                int fq = 15;
+                if (!(x == 0)) {
+                  fq = 1;
+#pragma unroll
+                  for (int k = 1; k <= 13; ++k) fq += (x <= xthr_k[k - 1]) ? 1 : 0;
+                }
+                const int data = (bpick & 1) ? q_data1[u] : q_data0[u];
+                if (s_tbs[(nprb / G) * 16 + fq] >= data * 8) q_done[bpick] = 1;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      } else if constexpr (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103) {
         /* DownlinkTransportScheduler's inter-slice policies (rs_interslice.h): lane r learns the slice of RBG r */
         int my_slice;
         constexpr int kS = FIXED ? RS_JIT_S : 0, kR = FIXED ? RS_JIT_R : 0;
@@ -1295,8 +1452,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       /* ---------------- P5: link adaptation + DoStopSchedule counters (lanes = RBGs) ---------------- */
       /* lanes holding the same user; the lowest one (leader) handles the user */
       /* owner + 1 <= U <= 2047; a shape-specialised build knows how many bits that takes */
-      constexpr int kOwnerBits = !FIXED ? 11 : RS_JIT_U < 63 ? 6 : RS_JIT_U < 127 ? 7 : RS_JIT_U < 255 ? 8
-                                 : RS_JIT_U < 511 ? 9 : RS_JIT_U < 1023 ? 10 : 11;
+      constexpr bool kFlows = kQSerial && SCHED == 1; /* owner = flow id 2 * user + bearer */
+      constexpr int kOwnerMax = FIXED ? (kFlows ? 2 * RS_JIT_U : RS_JIT_U) : 0;
+      constexpr int kOwnerBits = !FIXED ? (kFlows ? 12 : 11) : kOwnerMax < 63 ? 6 : kOwnerMax < 127 ? 7 : kOwnerMax < 255 ? 8
+                                 : kOwnerMax < 511 ? 9 : kOwnerMax < 1023 ? 10 : kOwnerMax < 2047 ? 11 : 12;
       BitBallots<kOwnerBits> ob;
       ob.gather(owner + 1, lane < R && owner >= 0);
       const unsigned long long same = owner >= 0 ? ob.lanes_with(owner + 1) : 0ull;
@@ -1321,7 +1480,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
          * (src/utility/eesm-effective-sinr.h:33-46 with the exp() values tabulated by the host) */
         unsigned long long mm = leader ? same : 0ull;
         double sum = 0;
-        const uint8_t* col = s_cqi + (owner < 0 ? 0 : owner);
+        const uint8_t* col = s_cqi + (owner < 0 ? 0 : (kFlows ? owner >> 1 : owner));
         while (mm) {
           const int r2 = __ffsll((long long)mm) - 1;
           mm &= mm - 1;
@@ -1350,7 +1509,11 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           int bytes = tbs / 8;
           if (bytes > 100000000) bytes = 100000000;
           if (bytes > 0) {
-            if (kCumRegs || QUEUE) {
+            if (kFlows) {
+              /* this flow's transport block: credited to its own bearer by the owner thread (stop_schedule_user) */
+              if (owner & 1) q_grant1[owner >> 1] = bytes | (nprb << RS_TX_NPRB_SHIFT);
+              else s_tx[owner >> 1] = bytes | (nprb << RS_TX_NPRB_SHIFT);
+            } else if (kCumRegs || QUEUE) {
               /* the owner thread of P1 counts it (registers) / splits it over the user's bearers and dequeues (queue model) */
               s_tx[owner] += bytes | (nprb << RS_TX_NPRB_SHIFT);
             } else {
@@ -1393,8 +1556,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           if (p.log_target) p.log_target[row * S + lane] = (int16_t)(kSpecSched ? my_target : m->target[lane]);
         }
         if (leader) {
-          if (p.log_tbs) p.log_tbs[row * U + owner] = tbs;
-          if (p.log_uinfo) p.log_uinfo[row * U + owner] = nprb | (fcqi << 16) | (mcs << 24);
+          if (kFlows) { /* two flows of one user may both hold RBGs: the user's row shows their sum */
+            if (p.log_tbs) atomicAdd(&p.log_tbs[row * U + (owner >> 1)], tbs);
+          } else {
+            if (p.log_tbs) p.log_tbs[row * U + owner] = tbs;
+            if (p.log_uinfo) p.log_uinfo[row * U + owner] = nprb | (fcqi << 16) | (mcs << 24);
+          }
         }
       }
     }
@@ -1541,7 +1708,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
 #endif
 /* shape-specialised entry point compiled at run time (rs_jit.cpp): static LDS of exactly the carve's size */
 extern "C" __global__ void __launch_bounds__(RS_JIT_NT, 4) rs_cell_kernel_jit(RsLaunch p) {
-  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT);
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_QUEUE != 0 ? 1 : 0);
   __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
   constexpr int kEpt = (RS_JIT_SCHED != 9 && RS_JIT_SCHED != 10) ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);
   rs_cell_body<RS_JIT_SCHED, kEpt, true, false, RS_JIT_QUEUE != 0>(p, lds);
@@ -1631,6 +1798,8 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
   hipLaunchKernelGGL((rs_cell_kernel<SCHED_, EPT_, false, true>), grid, block, p->lds_bytes, stream, *p)
   if (p->bearer_kind != nullptr) { /* finite queues (batches of the transport schedulers only; the host has checked) */
     switch (p->sched) {
+      case 1: RS_LAUNCH_QUEUE(1, 0); break;
+      case 7: RS_LAUNCH_QUEUE(7, 0); break;
       case 8: RS_LAUNCH_QUEUE(8, 0); break;
       case 101: RS_LAUNCH_QUEUE(101, 0); break;
       case 103: RS_LAUNCH_QUEUE(103, 0); break;
@@ -1676,6 +1845,7 @@ extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes) {
   const void* fns[] = {RS_BOTH(1, 0),  RS_BOTH(7, 0),  RS_BOTH(8, 0),  RS_BOTH(101, 0), RS_BOTH(103, 0), RS_BOTH(11, 0),
                        RS_BOTH(10, 1), RS_BOTH(10, 2), RS_BOTH(10, 3), RS_BOTH(10, 4),
                        RS_BOTH(9, 0),  RS_BOTH(9, 1),  RS_BOTH(9, 2),  RS_BOTH(9, 3),  RS_BOTH(9, 4),
+                       (const void*)rs_cell_kernel<1, 0, false, true>, (const void*)rs_cell_kernel<7, 0, false, true>,
                        (const void*)rs_cell_kernel<8, 0, false, true>, (const void*)rs_cell_kernel<101, 0, false, true>,
                        (const void*)rs_cell_kernel<103, 0, false, true>, (const void*)rs_cell_kernel<9, 0, false, true>,
                        (const void*)rs_cell_kernel<9, 1, false, true>, (const void*)rs_cell_kernel<9, 2, false, true>,

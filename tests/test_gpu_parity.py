@@ -564,8 +564,9 @@ def _experiment_cases():
     cases = []
     for name, c in sorted(cfgs.items()):
         if any(c["algo_alpha"]):
-            # customised slices read queue state: the batch's queue model runs this configuration with its own traffic
-            # (tests/test_gpu_queues.py::test_customize_20slices_experiment_runs_as_a_batch); here every flow is backlogged
+            # customised slices read queue state: the batch's queue model runs this configuration with its own traffic and all
+            # three schedulers of its run script (tests/test_gpu_queues.py::test_customize_20slices_experiment_runs_as_a_batch);
+            # this test keeps every flow backlogged
             continue
         for sched in c["schedulers_in_run_scripts"]:
             cases.append((name, sched))

@@ -134,8 +134,10 @@ def test_fragmentation_and_overhead_accounting(rs, oracle):
               mean_gap_ms=40, mean_bytes=90000)
 
 
-def test_customize_20slices_experiment_runs_as_a_batch(rs, oracle):
-    """exp-customization/exp-customize-20slices/config.json (the reference's customised-slice experiment, sched 9): backlogged,
+@pytest.mark.parametrize("sched", [9, 7, 1])
+def test_customize_20slices_experiment_runs_as_a_batch(rs, oracle, sched):
+    """exp-customization/exp-customize-20slices/config.json with the three scheduler numbers its run script passes (1, 7, 9;
+    run_customize.sh): backlogged,
     one / two InternetFlow bearers and video slices as ONE batch.  Traffic: rs_internet_flow_arrivals with the config's rates
     and the reference's 1 280 kbit/s video trace (tests/golden/video_foreman_1280k.json); 64 RBGs of 8 PRBs like the run script."""
     cfg = json.loads((GOLDEN / "experiment_configs.json").read_text())["exp-customization/exp-customize-20slices/config.json"]
@@ -165,7 +167,7 @@ def test_customize_20slices_experiment_runs_as_a_batch(rs, oracle):
                 bursts[(c, u, 0)] = rs.frames_to_bursts(ts, video["bytes"][:len(ts)])
     grids = synth_cqi(77, (n_cells, (n_ttis + 39) // 40, U, R), HIST)
     seeds = np.array([5, 6], np.uint32)
-    b = rs.BatchScheduler(sc, R, G, n_cells, sched=9, jit=True)
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=True)
     b.set_bearers(kinds)
     b.set_arrivals(bursts)
     b.seed(seeds)
@@ -174,7 +176,7 @@ def test_customize_20slices_experiment_runs_as_a_batch(rs, oracle):
     bst = b.bearer_state()
     b.close()
     for c in range(n_cells):
-        cell = oracle.Cell(cfg["ues_per_slice"], R, G, 9, weights=cfg["weight"], alpha=cfg["algo_alpha"], beta=cfg["algo_beta"],
+        cell = oracle.Cell(cfg["ues_per_slice"], R, G, sched, weights=cfg["weight"], alpha=cfg["algo_alpha"], beta=cfg["algo_beta"],
                            epsilon=cfg["algo_epsilon"], psi=cfg["algo_psi"])
         cell.enable_queues(kinds)
         for (cc, u, k), (t, nf, la) in bursts.items():
@@ -191,6 +193,32 @@ def test_customize_20slices_experiment_runs_as_a_batch(rs, oracle):
     assert bst["cum_bytes"][:, vid, 0].sum() > 0
     two = np.flatnonzero(kinds[:, 1] == rs.BEARER_QUEUE)
     assert bst["cum_bytes"][:, two, 1].sum() > 0
+
+
+@pytest.mark.parametrize("jit", [False, True])
+def test_nvs_with_queues_and_the_required_rbs_gate(rs, oracle, jit):
+    """Sched 7 with finite queues: SelectSliceToServe over the slices that have queued data, the customised metric (always
+    HoL-weighted here), and the m_requiredRBs gate -- with a few thousand bytes queued a user needs only a few RBGs and drops
+    out of the race for the rest of the TTI (downlink-nvs-scheduler.cpp:299-300)."""
+    _, maps = _run_case(rs, oracle, 7, [4, 5, 3, 6], ["B-", "Q-", "QQ", "Q-"], [0, 1, 1, 0], [0, 0, 1, 0], 25, 4, n_cells=3,
+                        launches=[1, 59, 90], jit=jit, seed=31, mean_gap_ms=20, mean_bytes=400)
+    # the gate binds: TTIs in which the served slice's users are satisfied before the RBGs run out leave RBGs unallocated
+    partial = ((maps >= 0).any(2) & (maps < 0).any(2)).sum()
+    assert partial > 0, "no TTI with unallocated RBGs: the m_requiredRBs gate never bound"
+    _run_case(rs, oracle, 7, [25] * 4, ["Q-", "QQ", "B-", "Q-"], [1, 1, 0, 0], [1, 0, 0, 0], 64, 8, n_cells=1, launches=[100],
+              jit=jit, seed=32, mean_gap_ms=8, mean_bytes=9000)
+
+
+@pytest.mark.parametrize("jit", [False, True])
+def test_per_flow_pf_with_queues_and_the_satisfied_flow_break(rs, oracle, jit):
+    """Sched 1 with finite queues: every bearer with packets is a flow with its own PF average; a flow leaves the TTI's
+    competition once the transport block of its PRBs so far carries its queue (downlink-packet-scheduler.cpp:253-265); the
+    RBG map holds flow ids 2 * user + bearer."""
+    _, maps = _run_case(rs, oracle, 1, [4, 5, 3, 6], ["B-", "Q-", "QQ", "Q-"], [0, 0, 0, 0], [0, 0, 0, 0], 25, 4, n_cells=3,
+                        launches=[1, 59, 90], jit=jit, seed=41, mean_gap_ms=5, mean_bytes=1500)
+    assert (maps % 2 == 1).any(), "no RBG went to a second bearer"
+    _run_case(rs, oracle, 1, [20] * 3, ["Q-", "QQ", "Q-"], [0, 0, 0], [0, 0, 0], 64, 8, n_cells=1, launches=[120], jit=jit, seed=42,
+              mean_gap_ms=10, mean_bytes=4000)
 
 
 def test_queue_mode_is_required_for_customised_batches_and_validated(rs):
@@ -211,7 +239,7 @@ def test_queue_mode_is_required_for_customised_batches_and_validated(rs):
     bs = b.bearer_state()
     assert bs["cum_bytes"][0, :3, 0].sum() > 0 and bs["cum_bytes"][0, 3:].sum() == 0
     b.close()
-    b7 = rs.BatchScheduler(rs.SliceConfig([3, 3]), 12, 2, 1, sched=7)
+    b10 = rs.BatchScheduler(rs.SliceConfig([3, 3]), 12, 2, 1, sched=10)
     with pytest.raises(rs.RadioSaberError):
-        b7.set_bearers(kinds)
-    b7.close()
+        b10.set_bearers(kinds)
+    b10.close()
