@@ -45,6 +45,10 @@
 
 namespace {
 
+#ifndef RS_P3_BLOCK_TOP
+#define RS_P3_BLOCK_TOP 0 /* users per stage-1 block of the scan at the top of the TTI (0: the same as in the serial phase) */
+#endif
+template <int N> struct RsInt { static constexpr int v = N; };
 #ifndef RS_SPEC_NAP
 #define RS_SPEC_NAP 2 /* s_sleep argument (x 64 cycles) while the scanning waves wait for the allocation */
 #endif
@@ -136,12 +140,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * user ((1 - beta) * avg, no bytes) and the best user of every (RBG, slice).  Serving a user can only LOWER its metric, so
    * an item whose speculative winner was not served keeps that winner exactly (first-maximum rule included); the few items
    * whose winner was served (~13 %) are listed and rescanned with the true averages after the TTI's closing barrier. */
-  constexpr bool kSpecSched = !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
+  /* Measured on MI355X (profiles/r02_spec_notes.md): it pays while a slice's scan is short -- +1 % (sched 9) ... +7 % (sched 8) at
+   * 25 UEs per slice, -4 ... -7 % at 50, where the rescans after the barrier cost more than the scan they replace: on up to
+   * 32 UEs per slice on average; a shape-specialised build for a larger shape does not carry the code at all. */
 #ifdef RS_NO_SPEC
-  const bool spec_enabled = false;
+  constexpr bool kSpecSched = false;
 #else
-  const bool spec_enabled = kSpecSched && nwaves >= 2;
+  constexpr bool kSpecSched = !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103) &&
+                              (!FIXED || RS_JIT_U <= 32 * RS_JIT_S);
 #endif
+  const bool spec_enabled = kSpecSched && nwaves >= 2 && U <= 32 * S;
 
   double* s_avg = (double*)lds;
   double* s_avgk = (double*)(lds + o.avgk);
@@ -912,7 +920,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
     const int n_items = nvs_split ? R * nvs_runs : o.n_items;
     /* one work item = (segment, RBG): winner to bu_out[it], its record (transport schedulers) to rec_out */
-    auto scan_item = [&](int it, uint16_t* bu_out, uint32_t* rec_out) {
+    auto scan_item = [&](int it, uint16_t* bu_out, uint32_t* rec_out, auto blk_tag) {
       {
         int sg = it / R, r = it - sg * R; /* r fastest: neighbouring lanes read neighbouring CQI bytes */
         int seg = SCHED == 7 ? seg_lo : sg;
@@ -947,7 +955,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         const float kTol = 0x1.ffffcp-1f; /* 1 - 2^-19 */
         /* sched 7 scans runs of 8..32 users: a shape-specialised build ranks exactly one run per block */
         /* (the speculating schedulers carry this scan twice, here and in the serial phase: 32 products per block would spill) */
-        constexpr int kP3Block = (SCHED == 7 && FIXED && kCv.nvs_seg != 0) ? kCv.nvs_seg
+        constexpr int kP3Block = decltype(blk_tag)::v != 0 ? decltype(blk_tag)::v
+                                 : (SCHED == 7 && FIXED && kCv.nvs_seg != 0) ? kCv.nvs_seg
                                  : ((kSpecSched && RS_P3_BLOCK > 16) ? 16 : RS_P3_BLOCK);
         const bool one_num = SCHED != 1 && !sl_eps;
         const float* numtab = one_num ? m->ones16 : s_num32; /* a table either way: no branch per user */
@@ -1119,7 +1128,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       const int n_spec = spec_items(n_items); /* items the serial phase speculated: [0, n_spec) */
       const int n_scan = listed ? n_fix + (n_items - n_spec) : n_items;
       for (int j = tid; j < n_scan; j += nt)
-        scan_item(listed ? (j < n_fix ? (int)fix_list[j] : n_spec + (j - n_fix)) : j, cur_bu, cur_rec);
+        scan_item(listed ? (j < n_fix ? (int)fix_list[j] : n_spec + (j - n_fix)) : j, cur_bu, cur_rec, RsInt<RS_P3_BLOCK_TOP>{});
     }
     __syncthreads();
     if (kTransport && p.log_keys) {
@@ -1590,7 +1599,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       RS_STAMP1(1);
       /* P3 on the speculative state */
       const int n_spec = spec_items(n_items);
-      for (int it = me; it < n_spec; it += nsp) scan_item(it, nxt_bu, nxt_rec);
+      for (int it = me; it < n_spec; it += nsp) scan_item(it, nxt_bu, nxt_rec, RsInt<0>{});
       /* TTI t+1's draws and remainder rotations need nothing of TTI t (unless the error model's draws, one per UE served,
        * come first on the shared stream) */
       if (wave == quota_wave && !p.phy_draws) quota_draws(0);
