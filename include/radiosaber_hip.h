@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 4 /* 4: finite queues in batches (rs_batch_set_bearers, rs_batch_set_arrivals, rs_batch_read_bearer_state, rs_internet_flow_arrivals);
+#define RS_ABI_VERSION 5 /* 5: per-PRB batch sources (rs_batch_upload_cqi_epochs_prb, rs_batch_set_trace_prb);
+                            4: finite queues in batches (rs_batch_set_bearers, rs_batch_set_arrivals, rs_batch_read_bearer_state, rs_internet_flow_arrivals);
                             2: rs_tti_in.rand_draws, schedulers 10 / 11 / 101 / 103, rs_trace_*, rs_hbm_copy_probe, rs_lds_bytes_per_cell;
                             3: rs_get_rbg_size, rs_dl_prbs_for_bandwidth, rs_batch_read_clock, rs_batch_jit_status,
                                rs_batch_synthesize_cqi_at, rs_batch_run_logged_ex */
@@ -207,6 +208,10 @@ int rs_batch_seed(rs_batch* b, const uint32_t* seed /* [n_cells] */, const int64
 /* CQI source A: explicit grids. h_cqi = [n_cells][n_epochs][U][R] (host); epoch e serves scheduled
  * TTIs [e*cqi_refresh, (e+1)*cqi_refresh).  Copied to HBM once. */
 int rs_batch_upload_cqi_epochs(rs_batch* b, const uint8_t* h_cqi, int32_t n_epochs);
+/* CQI source A, per PRB: h_cqi_prb = [n_cells][n_epochs][U][R*rbg_size], reports that may differ inside an RBG (what
+ * enb-mac-entity.cc:173-186 stores: all PRBs).  The metric reads PRB rbg*rbg_size (ref: downlink-transport-scheduler.cpp:536), link
+ * adaptation every allocated PRB (ref: :643-646). */
+int rs_batch_upload_cqi_epochs_prb(rs_batch* b, const uint8_t* h_cqi_prb, int32_t n_epochs);
 /* CQI source B: i.i.d. grids drawn on the device from a CQI histogram (weights of CQI 1..15),
  * counter-based generator keyed by (seed, cell, epoch, user, rbg).  Stays in HBM. */
 int rs_batch_synthesize_cqi(rs_batch* b, uint64_t seed, const double* cqi_weights /* [15] */, int32_t n_epochs);
@@ -221,6 +226,10 @@ int rs_batch_download_cqi_epochs(rs_batch* b, int32_t cell, uint8_t* h_cqi);
  * cqi-manager.cpp:105-123 / enb-mac-entity.cc:189-191 ((int)(Now*1000/40) % row_modulus). */
 int rs_batch_set_trace(rs_batch* b, const uint8_t* h_trace, int32_t n_traces, int32_t n_rows,
                        int32_t row_modulus, const int32_t* h_user_trace /* [n_cells][U] */);
+
+/* CQI source C, per PRB: h_trace_prb = [n_traces][n_rows][R*rbg_size] (rs_trace_read_ue_log's out_prb rows); same replay rule */
+int rs_batch_set_trace_prb(rs_batch* b, const uint8_t* h_trace_prb, int32_t n_traces, int32_t n_rows, int32_t row_modulus,
+                           const int32_t* h_user_trace /* [n_cells][U] */);
 
 /* ---- the reference's CQI trace files (host side of source C; no GPU involved) ----------------------
  * mapping<i>.config: lines "<user id> <trace id>"; user u replays trace map[u % n_entries]

@@ -103,6 +103,8 @@ def lib():
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.rso_cell_get_bearer_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.rso_run_synth_prb.argtypes = L.rso_run_synth.argtypes
+        L.rso_run_trace_prb.argtypes = L.rso_run_trace.argtypes
         L.rso_srand.argtypes = [C.POINTER(_Rng), C.c_uint]
         L.rso_rand.argtypes = [C.POINTER(_Rng)]
         for fn in ("rso_greedy_by_row", "rso_maximize_cell", "rso_vogel", "rso_subopt"):
@@ -320,11 +322,11 @@ class Cell:
         return {"avg_rate": avg, "cum_bytes": cb, "cum_rbs": cr, "slice_state": sl}
 
     def run_trace(self, trace, mapping, seed, rand_skip, n_ttis, phy_error_draws=1, first_tti=100,
-                  row_modulus=475, log=True):
+                  row_modulus=475, log=True, per_prb=False):
         trace = np.ascontiguousarray(trace, np.uint8)
         mapping = np.ascontiguousarray(mapping, np.int32)
         n_tr, n_rows, R = trace.shape
-        assert R == self.R
+        assert R == self.R * (self.rbg_size if per_prb else 1)
         run = _TraceRun(_p(trace, C.c_uint8), n_tr, n_rows, _p(mapping, C.c_int), len(mapping),
                         row_modulus, seed, rand_skip, phy_error_draws, first_tti, n_ttis)
         logs = None
@@ -334,7 +336,7 @@ class Cell:
                     "quota": np.zeros((n_ttis, self.S), np.int32),
                     "target": np.zeros((n_ttis, self.S), np.int32),
                     "tbs_bits": np.zeros((n_ttis, self.U), np.int32)}
-        rc = lib().rso_run_trace(self.h, C.byref(run),
+        rc = (lib().rso_run_trace_prb if per_prb else lib().rso_run_trace)(self.h, C.byref(run),
                                  _optp(logs and logs["rbg_to_user"], C.c_int),
                                  _optp(logs and logs["final_cqi"], C.c_int),
                                  _optp(logs and logs["quota"], C.c_int),
@@ -344,16 +346,18 @@ class Cell:
             raise RuntimeError(f"rso_run_trace rc={rc}")
         return logs
 
-    def run_synth(self, cqi_epochs, seed, n_ttis, refresh=40, phy_error_draws=0, log=True):
+    def run_synth(self, cqi_epochs, seed, n_ttis, refresh=40, phy_error_draws=0, log=True, per_prb=False):
+        """per_prb=True: cqi_epochs [n_epochs][U][R*rbg_size]."""
         e = np.ascontiguousarray(cqi_epochs, np.uint8)
-        assert e.shape[1:] == (self.U, self.R)
+        assert e.shape[1:] == (self.U, self.R * (self.rbg_size if per_prb else 1))
         logs = None
         if log:
             logs = {"rbg_to_user": np.zeros((n_ttis, self.R), np.int32),
                     "tbs_bits": np.zeros((n_ttis, self.U), np.int32)}
-        rc = lib().rso_run_synth(self.h, _p(e, C.c_uint8), e.shape[0], refresh, seed, phy_error_draws,
-                                 n_ttis, _optp(logs and logs["rbg_to_user"], C.c_int),
-                                 _optp(logs and logs["tbs_bits"], C.c_int))
+        fn = lib().rso_run_synth_prb if per_prb else lib().rso_run_synth
+        rc = fn(self.h, _p(e, C.c_uint8), e.shape[0], refresh, seed, phy_error_draws,
+                n_ttis, _optp(logs and logs["rbg_to_user"], C.c_int),
+                _optp(logs and logs["tbs_bits"], C.c_int))
         if rc:
             raise RuntimeError(f"rso_run_synth rc={rc}")
         return logs

@@ -817,6 +817,15 @@ static bool uses_rand(int sched) {
          sched == RSO_SCHED_SUBOPT;
 }
 
+static thread_local bool g_trace_per_prb = false;
+/* rso_run_trace with run->trace = [n_traces][n_rows][R*rbg_size] */
+int rso_run_trace_prb(rso_cell* c, const rso_trace_run* run, int* log_map, int* log_fcqi, int* log_quota,
+                      int* log_target, int* log_tbs) {
+  g_trace_per_prb = true;
+  int rc = rso_run_trace(c, run, log_map, log_fcqi, log_quota, log_target, log_tbs);
+  g_trace_per_prb = false;
+  return rc;
+}
 int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_map, int* log_fcqi, int* log_quota,
                   int* log_target, int* log_tbs) {
   const int S = c->S, U = c->U, R = c->R;
@@ -847,7 +856,16 @@ int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_map, int* log_
       if (row >= run->n_rows) return -10;
       for (int u = 0; u < U; u++) {
         int tr = run->mapping[u % run->n_map];
-        rso_cell_set_user_cqi(c, u, run->trace + ((size_t)tr * run->n_rows + row) * R);
+        if (g_trace_per_prb) {
+          /* the full report of enb-mac-entity.cc:173-186: every PRB; the metric reads PRB rbg*rbg_size */
+          const int n = R * c->rbg_size;
+          if (c->cqi_prb.empty()) c->cqi_prb.assign((size_t)U * n, 10);
+          const uint8_t* rowp = run->trace + ((size_t)tr * run->n_rows + row) * n;
+          memcpy(&c->cqi_prb[(size_t)u * n], rowp, n);
+          for (int r = 0; r < R; r++) c->cqi[(size_t)u * R + r] = rowp[r * c->rbg_size];
+        } else {
+          rso_cell_set_user_cqi(c, u, run->trace + ((size_t)tr * run->n_rows + row) * R);
+        }
       }
     }
     int r0 = 0, r1 = 0;
@@ -866,8 +884,19 @@ int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_map, int* log_
   return 0;
 }
 
+static int run_synth_impl(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed,
+                          int phy_error_draws, int n_ttis, int* log_map, int* log_tbs, bool per_prb);
 int rso_run_synth(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed,
-                  int phy_error_draws, int n_ttis, int* log_map, int* log_tbs) {
+                  int phy_error_draws, int n_ttis, int* log_rbg_to_user, int* log_tbs_bits) {
+  return run_synth_impl(c, cqi_epochs, n_epochs, refresh, seed, phy_error_draws, n_ttis, log_rbg_to_user, log_tbs_bits, false);
+}
+/* the same with per-PRB grids [n_epochs][U][R*rbg_size] (reports that differ inside an RBG) */
+int rso_run_synth_prb(rso_cell* c, const uint8_t* cqi_prb_epochs, int n_epochs, int refresh, unsigned seed,
+                      int phy_error_draws, int n_ttis, int* log_rbg_to_user, int* log_tbs_bits) {
+  return run_synth_impl(c, cqi_prb_epochs, n_epochs, refresh, seed, phy_error_draws, n_ttis, log_rbg_to_user, log_tbs_bits, true);
+}
+static int run_synth_impl(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed,
+                          int phy_error_draws, int n_ttis, int* log_map, int* log_tbs, bool per_prb) {
   const int S = c->S, U = c->U, R = c->R;
   rso_rng g;
   rso_srand(&g, seed);
@@ -883,7 +912,8 @@ int rso_run_synth(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refr
     if (n % refresh == 0) {
       int e = n / refresh;
       if (e >= n_epochs) return -10;
-      rso_cell_set_cqi(c, cqi_epochs + (size_t)e * U * R);
+      if (per_prb) rso_cell_set_cqi_prb(c, cqi_epochs + (size_t)e * U * R * c->rbg_size);
+      else rso_cell_set_cqi(c, cqi_epochs + (size_t)e * U * R);
     }
     int r0 = 0, r1 = 0;
     if (uses_rand(c->sched)) { r0 = rso_rand(&g); r1 = rso_rand(&g); }

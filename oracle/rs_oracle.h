@@ -164,6 +164,12 @@ int rso_run_trace(rso_cell* c, const rso_trace_run* run, int* log_rbg_to_user, i
 int rso_run_synth(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed,
                   int phy_error_draws, int n_ttis, int* log_rbg_to_user, int* log_tbs_bits);
 
+/* the two runs with per-PRB sources: cqi_prb_epochs [n_epochs][U][R*rbg_size]; run->trace [n_traces][n_rows][R*rbg_size] */
+int rso_run_synth_prb(rso_cell* c, const uint8_t* cqi_prb_epochs, int n_epochs, int refresh, unsigned seed,
+                      int phy_error_draws, int n_ttis, int* log_rbg_to_user, int* log_tbs_bits);
+int rso_run_trace_prb(rso_cell* c, const rso_trace_run* run, int* log_rbg_to_user, int* log_final_cqi,
+                      int* log_quota, int* log_target, int* log_tbs_bits);
+
 /* ---- finite queues.  PARITY UNPINNED (restated from flows/MacQueue.cpp, protocolStack/rlc/um-rlc-entity.cpp,
  *      flows/radio-bearer.cpp:281-367, downlink-transport-scheduler.cpp:105-221, packet-scheduler.cpp:305-335). ----
  * bearer_kind [U][2], index = bearer priority: 0 none, 1 InfiniteBuffer, 2 finite queue fed by arrival bursts */

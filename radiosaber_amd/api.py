@@ -85,6 +85,7 @@ ABI_SYMBOLS = [
     "rs_trace_read_mapping", "rs_trace_read_ue_log", "rs_trace_load_dir", "rs_hbm_copy_probe", "rs_lds_bytes_per_cell",
     "rs_get_rbg_size", "rs_dl_prbs_for_bandwidth", "rs_batch_synthesize_cqi_at", "rs_batch_run_logged_ex",
     "rs_batch_read_clock", "rs_batch_jit_status",
+    "rs_batch_upload_cqi_epochs_prb", "rs_batch_set_trace_prb",
     "rs_batch_set_bearers", "rs_batch_set_arrivals", "rs_batch_read_bearer_state", "rs_internet_flow_arrivals",
 ]
 
@@ -118,6 +119,8 @@ def lib():
     L.rs_batch_run_logged_ex.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_BatchLog)]
     L.rs_batch_read_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rs_batch_jit_status.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.rs_batch_upload_cqi_epochs_prb.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32]
+    L.rs_batch_set_trace_prb.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     L.rs_batch_set_bearers.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
     L.rs_batch_set_arrivals.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32)]
@@ -479,6 +482,20 @@ class BatchScheduler:
         assert a.ndim == 4 and a.shape[0] == self.n_cells and a.shape[2:] == (self.U, self.R), a.shape
         _check(lib().rs_batch_upload_cqi_epochs(self._h, _p(a, C.c_uint8), a.shape[1]))
         self.n_epochs = a.shape[1]
+
+    def upload_cqi_epochs_prb(self, cqi_prb):
+        """[n_cells][n_epochs][U][R*rbg_size]: per-PRB reports (the metric reads each RBG's first PRB, link adaptation all)."""
+        a = np.ascontiguousarray(cqi_prb, np.uint8)
+        assert a.ndim == 4 and a.shape[0] == self.n_cells and a.shape[2:] == (self.U, self.R * self.rbg_size), a.shape
+        _check(lib().rs_batch_upload_cqi_epochs_prb(self._h, _p(a, C.c_uint8), a.shape[1]))
+        self.n_epochs = a.shape[1]
+
+    def set_trace_prb(self, trace_prb, user_trace, row_modulus=475):
+        t = np.ascontiguousarray(trace_prb, np.uint8)
+        assert t.ndim == 3 and t.shape[2] == self.R * self.rbg_size
+        ut = np.ascontiguousarray(user_trace, np.int32)
+        assert ut.shape == (self.n_cells, self.U)
+        _check(lib().rs_batch_set_trace_prb(self._h, _p(t, C.c_uint8), t.shape[0], t.shape[1], row_modulus, _p(ut, C.c_int32)))
 
     def synthesize_cqi(self, seed, n_epochs, weights=TRACE_CQI_HISTOGRAM, first_cell=0):
         """Grids drawn on the device, keyed by (seed, first_cell + local cell, epoch, user, rbg)."""

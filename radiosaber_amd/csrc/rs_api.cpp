@@ -235,6 +235,8 @@ struct rs_batch {
   uint8_t* d_trace = nullptr;
   int32_t n_traces = 0, n_rows = 0, row_mod = 0;
   int32_t* d_user_trace = nullptr;
+  uint8_t *d_epochs_prb = nullptr, *d_trace_prb = nullptr; /* per-PRB twins (link adaptation) */
+  int64_t grid_stride_prb = 0;
   int32_t cqi_mode = RS_CQI_NONE;
   int32_t* d_err = nullptr;
   unsigned long long* d_slice_bytes = nullptr;
@@ -517,6 +519,10 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
   L.epochs = b->d_epochs; L.grid_stride = b->grid_stride; L.n_epochs = b->n_epochs;
   L.trace = b->d_trace; L.n_traces = b->n_traces; L.n_rows = b->n_rows; L.row_mod = b->row_mod;
   L.user_trace = b->d_user_trace;
+  L.epochs_prb = b->cqi_mode == RS_CQI_EPOCHS ? b->d_epochs_prb : nullptr; L.grid_stride_prb = b->grid_stride_prb;
+  L.trace_prb = b->cqi_mode == RS_CQI_TRACE ? b->d_trace_prb : nullptr;
+  if (b->queues && b->sched == RS_SCHED_NVS && (L.epochs_prb || L.trace_prb))
+    return fail(RS_ERR_INVALID, "sched 7 with queues computes m_requiredRBs from the per-RBG grid: per-PRB sources are not supported there");
   L.log_map = d_map; L.log_quota = d_quota; L.log_target = d_target; L.log_tbs = d_tbs; L.log_uinfo = d_uinfo;
   L.log_keys = d_keys;
   if (b->queues) {
@@ -546,7 +552,7 @@ void rs_batch_destroy(rs_batch* b) {
   void* ptrs[] = {b->d_tab, b->d_weight, b->d_eps, b->d_psi, b->d_alpha, b->d_beta, b->d_user_slice, b->d_tbs_eff, b->d_avg, b->d_tx, b->d_cumb, b->d_cumr,
                   b->d_sstate, b->d_scal, b->d_epochs, b->d_trace, b->d_user_trace, b->d_err, b->d_slice_bytes, b->d_stamps,
                   b->d_bearer_kind, b->d_arr_off, b->d_arr_time, b->d_arr_nfull, b->d_arr_last, b->d_qi, b->d_bavg, b->d_bcum,
-                  b->d_qflags, b->d_qhol};
+                  b->d_qflags, b->d_qhol, b->d_epochs_prb, b->d_trace_prb};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -576,6 +582,28 @@ int rs_batch_upload_cqi_epochs(rs_batch* b, const uint8_t* h_cqi, int32_t n_epoc
   b->grid_stride = (int64_t)stride;
   b->n_epochs = n_epochs;
   b->cqi_mode = RS_CQI_EPOCHS;
+  if (b->d_epochs_prb) { HIP_TRY(hipFree(b->d_epochs_prb)); b->d_epochs_prb = nullptr; }
+  return RS_OK;
+}
+
+int rs_batch_upload_cqi_epochs_prb(rs_batch* b, const uint8_t* h_cqi_prb, int32_t n_epochs) {
+  if (!b || !h_cqi_prb || n_epochs < 1) return fail(RS_ERR_INVALID, "bad argument");
+  const size_t per_user = (size_t)b->R * b->G, grid = (size_t)b->U * per_user, total = (size_t)b->n_cells * n_epochs;
+  /* the metric reads the first PRB of every RBG (ref: downlink-transport-scheduler.cpp:536): the per-RBG grids the kernels keep in LDS */
+  std::vector<uint8_t> rbg(total * b->U * b->R);
+  for (size_t g = 0; g < total; g++)
+    for (size_t u = 0; u < (size_t)b->U; u++)
+      for (size_t r = 0; r < (size_t)b->R; r++) rbg[(g * b->U + u) * b->R + r] = h_cqi_prb[g * grid + u * per_user + r * b->G];
+  for (size_t i = 0; i < total * grid; i++)
+    if (h_cqi_prb[i] < 1 || h_cqi_prb[i] > 15) return fail(RS_ERR_INVALID, "CQI %d at byte %zu outside 1..15", h_cqi_prb[i], i);
+  int rc = rs_batch_upload_cqi_epochs(b, rbg.data(), n_epochs);
+  if (rc) return rc;
+  const size_t stride = round_up((int)grid, 16);
+  std::vector<uint8_t> packed(total * stride, 0);
+  for (size_t g = 0; g < total; g++) memcpy(&packed[g * stride], h_cqi_prb + g * grid, grid);
+  HIP_TRY(hipMalloc(&b->d_epochs_prb, packed.size()));
+  HIP_TRY(hipMemcpy(b->d_epochs_prb, packed.data(), packed.size(), hipMemcpyHostToDevice));
+  b->grid_stride_prb = (int64_t)stride;
   return RS_OK;
 }
 
@@ -644,6 +672,23 @@ int rs_batch_set_trace(rs_batch* b, const uint8_t* h_trace, int32_t n_traces, in
   HIP_TRY(hipMemcpy(b->d_user_trace, h_user_trace, 4 * nu, hipMemcpyHostToDevice));
   b->n_traces = n_traces; b->n_rows = n_rows; b->row_mod = row_modulus;
   b->cqi_mode = RS_CQI_TRACE;
+  if (b->d_trace_prb) { HIP_TRY(hipFree(b->d_trace_prb)); b->d_trace_prb = nullptr; }
+  return RS_OK;
+}
+
+int rs_batch_set_trace_prb(rs_batch* b, const uint8_t* h_trace_prb, int32_t n_traces, int32_t n_rows, int32_t row_modulus,
+                           const int32_t* h_user_trace) {
+  if (!b || !h_trace_prb || n_traces < 1 || n_rows < 1) return fail(RS_ERR_INVALID, "bad argument");
+  const size_t per_row = (size_t)b->R * b->G, rows = (size_t)n_traces * n_rows;
+  for (size_t i = 0; i < rows * per_row; i++)
+    if (h_trace_prb[i] < 1 || h_trace_prb[i] > 15) return fail(RS_ERR_INVALID, "trace CQI %d outside 1..15", h_trace_prb[i]);
+  std::vector<uint8_t> rbg(rows * b->R);
+  for (size_t q = 0; q < rows; q++)
+    for (size_t r = 0; r < (size_t)b->R; r++) rbg[q * b->R + r] = h_trace_prb[q * per_row + r * b->G];
+  int rc = rs_batch_set_trace(b, rbg.data(), n_traces, n_rows, row_modulus, h_user_trace);
+  if (rc) return rc;
+  HIP_TRY(hipMalloc(&b->d_trace_prb, rows * per_row));
+  HIP_TRY(hipMemcpy(b->d_trace_prb, h_trace_prb, rows * per_row, hipMemcpyHostToDevice));
   return RS_OK;
 }
 

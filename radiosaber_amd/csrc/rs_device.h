@@ -220,6 +220,10 @@ struct RsLaunch {
   const uint8_t* trace;      /* [n_traces][n_rows][R] */
   int32_t n_traces, n_rows, row_mod;
   const int32_t* user_trace; /* [cells][U] */
+  /* optional per-PRB twins of the two sources (link adaptation reads them; the metric reads the per-RBG arrays above) */
+  const uint8_t* epochs_prb; /* [cells][n_epochs][grid_stride_prb]: [U][R*G] */
+  int64_t grid_stride_prb;
+  const uint8_t* trace_prb;  /* [n_traces][n_rows][R*G] */
   /* optional per-TTI log */
   int16_t* log_map;          /* [cells][n_ttis][R] */
   int16_t* log_quota;        /* [cells][n_ttis][S] */

@@ -115,7 +115,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   /* only the drop-in entry point (DIRECT: one TTI on caller-provided state) uses these; batches never do, and their
    * kernels carry neither the code nor the registers */
   constexpr bool kDirect = DIRECT;
-  const uint8_t* const prb_cqi_in = DIRECT ? p.prb_cqi : nullptr;
+  /* per-PRB CQI for the link adaptation (reports that differ inside an RBG): the caller's block (drop-in mode) or the batch's
+   * per-PRB epoch grids / trace rows; the metric always reads the RBG's first PRB, which is what the LDS grid holds */
+  const bool per_prb = DIRECT ? p.prb_cqi != nullptr : (p.epochs_prb != nullptr || p.trace_prb != nullptr);
   const int queue_mode_in = DIRECT ? p.queue_mode : (QUEUE ? 1 : 0);
   /* customised-slice inputs per user: the caller's arrays (drop-in mode) or this cell's rows of the queue model's
    * (bit 0: the prioritized bearer has data; queue model only, bit 1: the user has any queued data = is in UsersToSchedule) */
@@ -414,6 +416,14 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   bool have_spec = false; /* this TTI's EWMA, metric scan and quotas were prepared during the previous TTI's serial phase */
   for (int tti = 0; tti < p.n_ttis; ++tti) {
     RS_STAMP(11);
+    auto prb_ptr = [&](int user, int r2) -> const uint8_t* { /* the G PRBs of RBG r2 as `user` reported them */
+      if (DIRECT) return p.prb_cqi + ((size_t)user * R + r2) * G;
+      if (p.cqi_mode == RS_CQI_EPOCHS) {
+        const long long e = epoch < p.n_epochs ? epoch : (long long)p.n_epochs - 1;
+        return p.epochs_prb + ((size_t)cell * p.n_epochs + (size_t)e) * p.grid_stride_prb + ((size_t)user * R + r2) * G;
+      }
+      return p.trace_prb + (((size_t)p.user_trace[(size_t)cell * U + user] * p.n_rows + cqi_row) * R + r2) * G;
+    };
     /* ---------------- P0: CQI refresh ---------------- */
     if (p.cqi_mode == RS_CQI_EPOCHS) {
       /* a launch that starts inside an epoch loads that epoch's grid first: LDS does not survive between launches */
@@ -1234,8 +1244,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         for (int y = x; y < f + q; ++y) {
           if (ent_user[y] != u) continue;
           const int r2 = (int)((s_sorted[y] >> 8) & 63u);
-          if (prb_cqi_in) {
-            const uint8_t* pr = prb_cqi_in + ((size_t)u * R + r2) * G;
+          if (per_prb) {
+            const uint8_t* pr = prb_ptr(u, r2);
             for (int g = 0; g < G; ++g) sum += s_e[pr[g]];
           } else {
             const double ev = s_e[s_cqi[r2 * Upad + u]];
@@ -1493,9 +1503,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         while (mm) {
           const int r2 = __ffsll((long long)mm) - 1;
           mm &= mm - 1;
-          if (prb_cqi_in) {
-            /* per-PRB reports (drop-in mode with the simulated channel): read the RBG's PRBs from HBM */
-            const uint8_t* pr = prb_cqi_in + ((size_t)owner * R + r2) * G;
+          if (per_prb) {
+            /* per-PRB reports (the simulated channel's, or a per-PRB batch source): read the RBG's PRBs from HBM */
+            const uint8_t* pr = prb_ptr(kFlows ? owner >> 1 : owner, r2);
             for (int k = 0; k < G; ++k) sum += s_e[pr[k]];
           } else {
             const double ev = s_e[col[r2 * Upad]];

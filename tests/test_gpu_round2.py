@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the product library first touches HIP: torch ships its own HIP runtime and must initialise first)
 
 from conftest import GOLDEN, synth_cqi
 from test_oracle_pins import cqi_keys_of_eff, ref_maximize_cell
@@ -172,3 +173,51 @@ def test_rccl_single_rank_all_reduce_of_slice_bytes(rs):
         b.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sched", [9, 8, 7, 1, 10])
+def test_per_prb_cqi_sources_in_batches(rs, oracle, sched):
+    """Reports that differ inside an RBG (enb-mac-entity.cc:173-186 stores all 512 PRBs): the batch keeps the per-PRB grids / trace
+    rows in HBM, the metric reads each RBG's first PRB (downlink-transport-scheduler.cpp:536), link adaptation every allocated
+    PRB (:643-646).  Epoch source and trace source, built-in and shape-specialised kernels."""
+    ues, R, G, n_cells, n_ttis = [5] * 6, 16, 4, 2, 90
+    sc = rs.SliceConfig(ues)
+    U = sc.n_users
+    grids = synth_cqi(50 + sched, (n_cells, 3, U, R * G), HIST)
+    assert (grids.reshape(n_cells, 3, U, R, G).std(axis=4) > 0).any()
+    seeds = np.arange(n_cells, dtype=np.uint32) + 900
+    for jit in (False, True):
+        b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=jit)
+        b.seed(seeds)
+        b.upload_cqi_epochs_prb(grids)
+        got = b.run_logged(n_ttis)
+        st = b.state()
+        b.close()
+        for c in range(n_cells):
+            cell = oracle.Cell(ues, R, G, sched)
+            logs = cell.run_synth(grids[c], int(seeds[c]), n_ttis, per_prb=True)
+            np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"])
+            np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"])
+            assert (st["cum_bytes"][c] == cell.state()["cum_bytes"]).all()
+            assert st["avg_rate"][c].tobytes() == cell.state()["avg_rate"].tobytes()
+    # the same grids as uniform RBGs give different transport blocks: the per-PRB path is really taken
+    flat = np.repeat(grids.reshape(n_cells, 3, U, R, G)[..., :1], G, axis=4).reshape(grids.shape)
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched)
+    b.seed(seeds)
+    b.upload_cqi_epochs_prb(flat)
+    other = b.run_logged(n_ttis)
+    b.close()
+    assert (other["tbs_bits"] != got["tbs_bits"]).any()
+    # trace source: 12 traces x 8 rows of per-PRB reports
+    tr = synth_cqi(70 + sched, (12, 8, R * G), HIST)
+    ut = (np.arange(n_cells * U).reshape(n_cells, U) * 5 % 12).astype(np.int32)
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, phy_error_draws=True, jit=True)
+    b.seed(seeds)
+    b.set_trace_prb(tr, ut, row_modulus=8)
+    got = b.run_logged(n_ttis)
+    b.close()
+    for c in range(n_cells):
+        cell = oracle.Cell(ues, R, G, sched)
+        logs = cell.run_trace(tr, ut[c], int(seeds[c]), 0, n_ttis, row_modulus=8, per_prb=True)
+        np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"])
+        np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"])
