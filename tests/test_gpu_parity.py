@@ -477,7 +477,8 @@ def test_maximum_sizes(rs, oracle):
 
 
 def test_subopt_policy_on_the_device(rs, oracle):
-    """N4: SubOpt (ref: downlink-transport-scheduler.cpp:274-349).  Ties between equal efficiency losses follow the order
+    """ORACLE UNPINNED (SubOpt has no reference output, tests/PINS.md): this proves device == oracle, nothing more.
+    N4: SubOpt (ref: downlink-transport-scheduler.cpp:274-349).  Ties between equal efficiency losses follow the order
     libstdc++'s unordered_map yields the under-quota slices: the oracle uses the real container, the device its own
     restatement of the hashtable (rs_umap_order, checked against the container on the CPU).  More than 13 / 29 / 59
     under-quota slices exercise the rehashes; skewed weights make slices over and under quota every TTI."""
@@ -504,7 +505,9 @@ def test_vogel_policy_on_the_device(rs, oracle):
 
 
 def test_upper_bound_policy_on_the_device(rs, oracle):
-    """N4: UpperBound (sched 10; ref: downlink-transport-scheduler.cpp:223-246, :603-616): one unstable std::sort per
+    """ORACLE UNPINNED (no reference output for sched 10; the rbg_to_user "lowest slice wins" report is this build's own convention,
+    tests/PINS.md): this proves device == oracle, nothing more.
+    N4: UpperBound (sched 10; ref: downlink-transport-scheduler.cpp:223-246, :603-616): one unstable std::sort per
     slice (run as one segmented level-synchronous pass on the device), the top-quota RBGs per slice, link adaptation over
     each UE's RBGs in push order.  Ties at the quota boundary are the norm with 16 key levels, so per-UE PRB counts, TBS
     and the cumulative counters pin the sort order.  Oracle restated from the cited lines (no reference output exists)."""
@@ -520,7 +523,8 @@ def test_upper_bound_policy_on_the_device(rs, oracle):
 
 
 def test_nvs_nongreedy_sampler_on_the_device(rs, oracle):
-    """N4: the CLI's scheduler 11 (DownlinkNVSScheduler, is_nongreedy_; ref: downlink-nvs-scheduler.cpp:405-528): 300 sampled
+    """ORACLE UNPINNED (no reference output for sched 11, tests/PINS.md): this proves device == oracle, nothing more.
+    N4: the CLI's scheduler 11 (DownlinkNVSScheduler, is_nongreedy_; ref: downlink-nvs-scheduler.cpp:405-528): 300 sampled
     CQI-index vectors per TTI from the libc rand() stream (generated on the device 31 ring words per step), per sample a
     per-RBG first-maximum scan, the first best sample applied.  Oracle restated from the cited lines (no reference output
     exists); the device must reproduce it bit for bit, rand() coupling with the error-model draws included."""
@@ -533,6 +537,7 @@ def test_nvs_nongreedy_sampler_on_the_device(rs, oracle):
 
 
 def test_nvs_nongreedy_drop_in(rs, oracle):
+    """ORACLE UNPINNED (sched 11): device == oracle through the drop-in entry point."""
     ues, R, G = [6] * 5, 25, 4
     sc = rs.SliceConfig(ues)
     ts = rs.TtiScheduler(sc, R, G, sched=11)
@@ -622,7 +627,7 @@ def test_drop_in_nvs_big_slice(rs, oracle):
 
 
 def test_upper_bound_drop_in_lists(rs, oracle):
-    """RS_SCHED_UPPERBOUND through the drop-in entry point: besides the per-user results, the per-slice lists the
+    """ORACLE UNPINNED (sched 10): device == oracle.  RS_SCHED_UPPERBOUND through the drop-in entry point: besides the per-user results, the per-slice lists the
     reference's apply step walks (RBGs in push order = the slice's std::sort order, and the user each one goes to)."""
     ues, R, G = [5] * 20, 64, 8
     sc = rs.SliceConfig(ues, weight=[0.05] * 20)
