@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 5 /* 5: per-PRB batch sources (rs_batch_upload_cqi_epochs_prb, rs_batch_set_trace_prb);
+#define RS_ABI_VERSION 6 /* 6: rs_tti_in.required_rbs / data_to_transmit (the gates of schedulers 7 and 1 in the drop-in mode);
+                            5: per-PRB batch sources (rs_batch_upload_cqi_epochs_prb, rs_batch_set_trace_prb);
                             4: finite queues in batches (rs_batch_set_bearers, rs_batch_set_arrivals, rs_batch_read_bearer_state, rs_internet_flow_arrivals);
                             2: rs_tti_in.rand_draws, schedulers 10 / 11 / 101 / 103, rs_trace_*, rs_hbm_copy_probe, rs_lds_bytes_per_cell;
                             3: rs_get_rbg_size, rs_dl_prbs_for_bandwidth, rs_batch_read_clock, rs_batch_jit_status,
@@ -144,6 +145,12 @@ typedef struct rs_tti_in {
   const int32_t* rand_draws;     /* RS_SCHED_NVS_NONGREEDY only: the 300 * n values rand() returns to
                                     RBsAllocationNonGreedyPF, in draw order (sample-major, user-minor;
                                     downlink-nvs-scheduler.cpp:431-441); NULL for every other scheduler     */
+  /* finite queues: the two gates that never bind for InfiniteBuffer flows.  NULL = backlogged (no gate). */
+  const int32_t* required_rbs;     /* RS_SCHED_NVS, [n]: UserToSchedule::m_requiredRBs in PRBs; a user competes for an RBG
+                                      only while its allocated PRBs are below it (downlink-nvs-scheduler.cpp:299-300)       */
+  const int32_t* data_to_transmit; /* RS_SCHED_PF, [n] bytes: FlowToSchedule::GetDataToTransmit(); a flow leaves the TTI's
+                                      competition once the transport block of its PRBs so far carries data * 8 bits
+                                      (downlink-packet-scheduler.cpp:253-265)                                               */
 } rs_tti_in;
 
 /* What RBsAllocation() leaves behind (ref: :589-620 allocation lists + slice_rbs_offset_,

@@ -53,12 +53,11 @@ void DL_GPU_PF_PacketScheduler::RBsAllocation() {
   /* the "users" of the C ABI are this scheduler's flows, ids = positions in the flow list (user_id NULL) */
   std::vector<uint8_t> cqi_prb((size_t)n * nb_rbs);
   std::vector<double> avg(n);
+  std::vector<int> data(n);
   for (int i = 0; i < n; i++) {
     FlowToSchedule* f = flows->at(i);
-    /* the break at :253-265 (transport block >= dataToTransmit * 8) never fires for InfiniteBuffer flows (1e8 bytes);
-     * finite queues need it -- the C ABI has no input for it, so refuse rather than allocate differently */
-    if (f->GetDataToTransmit() < 100000000)
-      throw std::runtime_error("DL_GPU_PF_PacketScheduler: finite queues are not supported by the GPU path (backlogged flows only)");
+    /* the break at :253-265 (transport block >= dataToTransmit * 8): rs_tti_in.data_to_transmit carries every flow's queue */
+    data[i] = f->GetDataToTransmit();
     const std::vector<int> fb = f->GetCqiFeedbacks();
     for (int k = 0; k < nb_rbs; k++) cqi_prb[(size_t)i * nb_rbs + k] = (uint8_t)fb.at(k);
     avg[i] = f->GetBearer()->GetAverageTransmissionRate(); /* metric (se * 180000.) / avg, dl-pf-packet-scheduler.cpp:128-140 */
@@ -73,6 +72,8 @@ void DL_GPU_PF_PacketScheduler::RBsAllocation() {
   in.hol_delay = NULL;
   in.prio_has_data = NULL;
   in.rand_draws = NULL;
+  in.required_rbs = NULL;
+  in.data_to_transmit = data.data();
   int target = 0, quota = 0;
   std::vector<int> map(R), nprb(n), fcqi(n), mcs(n), tbs(n);
   rs_tti_out out;

@@ -88,14 +88,13 @@ void DownlinkGpuNVSScheduler::RBsAllocation() {
   std::vector<int> ids(n);
   std::vector<uint8_t> cqi_prb((size_t)n * nb_rbs), prio_has_data(n, 1);
   std::vector<double> avg(n), hol(n, 0.0);
+  std::vector<int> required(n);
   for (int i = 0; i < n; i++) {
     UserToSchedule* u = users->at(i);
     ids[i] = u->GetUserID();
     if (i && ids[i] <= ids[i - 1]) throw std::runtime_error("DownlinkGpuNVSScheduler: users are not in ascending id order");
-    /* the gate at :299-300 (allocated PRBs < m_requiredRBs) never binds for InfiniteBuffer flows (1e8 bytes need more
-     * than 512 PRBs at any CQI); finite queues can make it bind -- the C ABI has no input for it, so refuse */
-    if (u->m_requiredRBs < nb_rbs)
-      throw std::runtime_error("DownlinkGpuNVSScheduler: m_requiredRBs below the PRB grid (finite queue): not supported by the GPU path");
+    /* the gate at :299-300 (allocated PRBs < m_requiredRBs): rs_tti_in.required_rbs */
+    required[i] = u->m_requiredRBs;
     const std::vector<int>& fb = u->GetCqiFeedbacks();
     for (int k = 0; k < nb_rbs; k++) cqi_prb[(size_t)i * nb_rbs + k] = (uint8_t)fb.at(k);
     double k1 = 1, only = 0; /* :364-369: averageRate = 1; += every bearer's average */
@@ -128,6 +127,8 @@ void DownlinkGpuNVSScheduler::RBsAllocation() {
   in.hol_delay = alpha_[sid] ? hol.data() : NULL;
   in.prio_has_data = alpha_[sid] ? prio_has_data.data() : NULL;
   in.rand_draws = nongreedy_ ? draws.data() : NULL;
+  in.required_rbs = nongreedy_ ? NULL : required.data(); /* RBsAllocationNonGreedyPF has no such gate */
+  in.data_to_transmit = NULL;
   std::vector<int> target(num_slices_), quota(num_slices_), map(R), nprb(n), fcqi(n), mcs(n), tbs(n);
   rs_tti_out out;
   out.target_rbs = target.data();

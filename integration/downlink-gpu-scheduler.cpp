@@ -140,6 +140,8 @@ void DownlinkGpuScheduler::RBsAllocation() {
   in.hol_delay = any_alpha_ ? hol.data() : NULL;
   in.prio_has_data = any_alpha_ ? prio_has_data.data() : NULL;
   in.rand_draws = NULL;
+  in.required_rbs = NULL; /* DownlinkTransportScheduler::RBsAllocation has no per-user gate */
+  in.data_to_transmit = NULL;
 
   std::vector<int> target(num_slices_), quota(num_slices_), map(R), nprb(n), fcqi(n), mcs(n), tbs(n);
   std::vector<int> upper_rbg, upper_user;

@@ -56,7 +56,8 @@ class _TtiIn(C.Structure):
                 ("cqi", C.POINTER(C.c_uint8)), ("avg_rate", C.POINTER(C.c_double)),
                 ("rand0", C.c_int32), ("rand1", C.c_int32), ("cqi_prb", C.POINTER(C.c_uint8)),
                 ("hol_delay", C.POINTER(C.c_double)), ("prio_has_data", C.POINTER(C.c_uint8)),
-                ("rand_draws", C.POINTER(C.c_int32))]
+                ("rand_draws", C.POINTER(C.c_int32)),
+                ("required_rbs", C.POINTER(C.c_int32)), ("data_to_transmit", C.POINTER(C.c_int32))]
 
 
 class _TtiOut(C.Structure):
@@ -395,7 +396,8 @@ class TtiScheduler:
     __del__ = close
 
     def schedule_tti(self, cqi, avg_rate, rand0=0, rand1=0, user_id: Optional[Sequence[int]] = None,
-                     cqi_prb=None, hol_delay=None, prio_has_data=None, rand_draws=None) -> TtiResult:
+                     cqi_prb=None, hol_delay=None, prio_has_data=None, rand_draws=None, required_rbs=None,
+                     data_to_transmit=None) -> TtiResult:
         """cqi [n][R] per-RBG CQI, or cqi_prb [n][R*rbg_size] per-PRB CQI (then cqi may be None).
         rand_draws (RS_SCHED_NVS_NONGREEDY): the 300 * n rand() values of RBsAllocationNonGreedyPF, in draw order."""
         prb = None
@@ -415,6 +417,9 @@ class TtiScheduler:
         prio = None if prio_has_data is None else np.ascontiguousarray(prio_has_data, np.uint8)
         draws = None if rand_draws is None else np.ascontiguousarray(rand_draws, np.int32)
         assert draws is None or draws.size == 300 * n
+        req = None if required_rbs is None else np.ascontiguousarray(required_rbs, np.int32)
+        dat = None if data_to_transmit is None else np.ascontiguousarray(data_to_transmit, np.int32)
+        assert (req is None or req.shape == (n,)) and (dat is None or dat.shape == (n,))
         S = self.slices.n_slices
         res = TtiResult(np.zeros(S, np.int32), np.zeros(S, np.int32), np.zeros(self.R, np.int32),
                         np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32))
@@ -423,7 +428,9 @@ class TtiScheduler:
                      _p(prb, C.c_uint8) if prb is not None else None,
                      _p(hol, C.c_double) if hol is not None else None,
                      _p(prio, C.c_uint8) if prio is not None else None,
-                     _p(draws, C.c_int32) if draws is not None else None)
+                     _p(draws, C.c_int32) if draws is not None else None,
+                     _p(req, C.c_int32) if req is not None else None,
+                     _p(dat, C.c_int32) if dat is not None else None)
         if self.sched == RS_SCHED_UPPERBOUND:
             res.upper_rbg = np.full((S, self.R), -1, np.int32)
             res.upper_user = np.full((S, self.R), -1, np.int32)

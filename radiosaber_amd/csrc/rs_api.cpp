@@ -290,7 +290,9 @@ int validate(const rs_config* c, bool direct) {
 int upad_of(int U) { return rs_upad_of(U); }
 
 void carve_lds(rs_batch* b, RsLaunch* L) {
-  const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads, b->queues ? 1 : 0);
+  /* (drop-in contexts of schedulers 1 and 7 carry the gate scratch too: rs_tti_in.required_rbs / data_to_transmit) */
+  const bool gate_scratch = b->direct && (b->sched == RS_SCHED_PF || b->sched == RS_SCHED_NVS);
+  const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads, (b->queues || gate_scratch) ? 1 : 0);
   L->Upad = c.Upad;
   L->nvs_seg = c.nvs_seg;
   L->off_avgk = c.off_avgk; L->off_rcp = c.off_rcp; L->off_tab = c.off_tab; L->off_slice = c.off_slice;
@@ -1010,7 +1012,7 @@ struct rs_ctx {
 
 namespace {
 struct CtxLayout {
-  size_t grid, slice, avg, hol, prio, draws, prb, in_total, tbs, uinfo, map, quota, target, upper, out_total;
+  size_t grid, slice, avg, hol, prio, gate, draws, prb, in_total, tbs, uinfo, map, quota, target, upper, out_total;
 };
 CtxLayout ctx_layout(int n, int R, int S, int G, bool with_draws) {
   CtxLayout l;
@@ -1019,7 +1021,8 @@ CtxLayout ctx_layout(int n, int R, int S, int G, bool with_draws) {
   l.avg = l.slice + round_up(n, 16);
   l.hol = l.avg + 8 * (size_t)n;
   l.prio = l.hol + 8 * (size_t)n;
-  l.draws = l.prio + round_up(n, 16);
+  l.gate = l.prio + round_up(n, 16);
+  l.draws = l.gate + round_up(4 * n, 16);
   l.prb = l.draws + (with_draws ? round_up(RS_NVS_SAMPLES * n, 16) : 0);
   l.in_total = l.prb + round_up(n * R * G, 16);
   l.tbs = 0;
@@ -1119,6 +1122,12 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
       c->h_in[l.draws + i] = (uint8_t)(in->rand_draws[i] % 4); /* downlink-nvs-scheduler.cpp:438 */
     }
   }
+  const int32_t* gate = b->sched == RS_SCHED_NVS ? in->required_rbs : (b->sched == RS_SCHED_PF ? in->data_to_transmit : nullptr);
+  if (gate) {
+    for (int i = 0; i < n; i++)
+      if (gate[i] < 0) return fail(RS_ERR_INVALID, "%s[%d] = %d is negative", b->sched == RS_SCHED_NVS ? "required_rbs" : "data_to_transmit", i, gate[i]);
+    memcpy(c->h_in + l.gate, gate, 4 * (size_t)n);
+  }
   if (b->any_alpha) {
     bool need_hol = false;
     for (int i = 0; i < n; i++) {
@@ -1156,6 +1165,7 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   L.hol = (const double*)(dev_in + l.hol);
   L.prio = dev_in + l.prio;
   L.draws = dev_in + l.draws;
+  L.gate = gate ? (const int32_t*)(dev_in + l.gate) : nullptr;
   if (b->sched == RS_SCHED_PF) { L.n_seg = (n + RS_PF_SEG - 1) / RS_PF_SEG; L.n_items = R * L.n_seg; }
   L.log_tbs = (int32_t*)(dev_out + l.tbs);
   L.log_uinfo = (int32_t*)(dev_out + l.uinfo);

@@ -1402,6 +1402,83 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             __builtin_amdgcn_wave_barrier();
           }
         }
+      } else if (DIRECT && (SCHED == 1 || SCHED == 7) && p.gate != nullptr) {
+        /* Drop-in mode with finite queues (rs_tti_in.data_to_transmit / required_rbs): the same RBG-by-RBG race as above on the
+         * caller's candidates -- flows (sched 1: every passed "user" is one flow) / the served slice's users (sched 7). */
+        for (int u = lane; u < U; u += 64) {
+          q_need[u] = p.gate[u];
+          q_done[u] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int sl7 = (int)p.user_slice[0];
+        const int sl_eps = SCHED == 7 ? (m->eps_psi[sl7] & 1) : 1, sl_psi = SCHED == 7 ? ((m->eps_psi[sl7] >> 1) & 1) : 1;
+        const bool custom7 = SCHED == 7 && queue_mode_in && p.alpha[sl7] != 0;
+        for (int r = 0; r < R; ++r) {
+          int bhi = -1, blo = (int)0x80000000, bpick = -1;
+          for (int c0 = 0; c0 < U; c0 += 64) {
+            const int u = c0 + lane;
+            bool valid = u < U;
+            double metric = 0.0;
+            if (valid) {
+              const int cq = s_cqi[r * Upad + u];
+              if (SCHED == 1) {
+                valid = q_done[u] == 0;
+                metric = s_num[cq] / s_avg[u];
+                valid = valid && metric > 0;
+              } else {
+                valid = q_need[u] > 0;
+                const double num = sl_eps ? s_num[cq] : 1.0, den = sl_psi ? s_avgk[u] : 1.0;
+                if (!custom7) metric = num / den;
+                else metric = (prio_in && (prio_in[u] & 1) == 0) ? 0.0 : hol_in[u] * num / den;
+              }
+            }
+            const int hi = valid ? __double2hiint(metric) : -1;
+            const int lo = (int)((unsigned)__double2loint(metric) ^ 0x80000000u);
+            const int mhi = wave_max(hi);
+            const int mlo = wave_max(hi == mhi ? lo : (int)0x80000000);
+            if (mhi >= 0 && (mhi > bhi || (mhi == bhi && mlo > blo))) {
+              bhi = mhi;
+              blo = mlo;
+              bpick = c0 + __ffsll((long long)__ballot(valid && hi == mhi && lo == mlo)) - 1;
+            }
+          }
+          if (lane == r) owner = bpick;
+          if (bpick >= 0) {
+            if (SCHED == 7) {
+              if (lane == 0) q_need[bpick] -= G;
+            } else {
+              const unsigned long long mine = __ballot(owner == bpick && lane <= r);
+              if (lane == r) {
+                unsigned long long mm = mine;
+                double sum = 0;
+                int nprb = 0;
+                while (mm) {
+                  const int r2 = __ffsll((long long)mm) - 1;
+                  mm &= mm - 1;
+                  if (per_prb) {
+                    const uint8_t* pr = prb_ptr(bpick, r2);
+                    for (int k = 0; k < G; ++k) sum += s_e[pr[k]];
+                  } else {
+                    const double ev = s_e[s_cqi[r2 * Upad + bpick]];
+                    for (int k = 0; k < G; ++k) sum += ev;
+                  }
+                  nprb += G;
+                }
+                const double x = sum / (double)nprb;
+                int fq = 15;
+                if (!(x == 0)) {
+                  fq = 1;
+#pragma unroll
+                  for (int k = 1; k <= 13; ++k) fq += (x <= xthr_k[k - 1]) ? 1 : 0;
+                }
+                if (s_tbs[(nprb / G) * 16 + fq] >= q_need[bpick] * 8) q_done[bpick] = 1;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
       } else if constexpr (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103) {
         /* DownlinkTransportScheduler's inter-slice policies (rs_interslice.h): lane r learns the slice of RBG r */
         int my_slice;

@@ -221,3 +221,79 @@ def test_per_prb_cqi_sources_in_batches(rs, oracle, sched):
         logs = cell.run_trace(tr, ut[c], int(seeds[c]), 0, n_ttis, row_modulus=8, per_prb=True)
         np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"])
         np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"])
+
+
+def test_drop_in_gates_of_schedulers_7_and_1(rs, oracle):
+    """rs_tti_in.required_rbs (sched 7: a user competes only while its PRBs are below m_requiredRBs, downlink-nvs-scheduler.cpp:
+    299-300) and rs_tti_in.data_to_transmit (sched 1: a flow leaves once the transport block of its PRBs so far carries its queue,
+    downlink-packet-scheduler.cpp:253-265) against plain sequential restatements of the two loops (numpy + the oracle's EESM / TBS
+    helpers).  ORACLE-SIDE UNPINNED like the rest of schedulers 1 and 7."""
+    R, G = 25, 4
+    lt = rs.link_tables()
+    tabs = oracle.tables()
+    rng = np.random.default_rng(77)
+    # ---- sched 7
+    ues = [9, 14, 6]
+    sc = rs.SliceConfig(ues, algo_alpha=[0, 1, 0], algo_psi=[1, 1, 0])
+    ts = rs.TtiScheduler(sc, R, G, sched=7)
+    starts = np.cumsum([0] + ues)
+    bound = 0
+    for it in range(12):
+        sl = it % 3
+        ids = np.arange(starts[sl], starts[sl + 1])
+        n = len(ids)
+        cqi = synth_cqi(600 + it, (n, R), HIST)
+        avg = rng.uniform(1e3, 5e6, n)
+        hol = rng.uniform(1e-5, 0.4, n)
+        prio = (rng.random(n) < 0.8).astype(np.uint8)
+        req = rng.integers(0, 40, n).astype(np.int32)
+        if it % 4 == 3:
+            req[:] = 10 ** 6  # backlogged: the gate never binds
+        res = ts.schedule_tti(cqi, avg, user_id=ids, hol_delay=hol, prio_has_data=prio, required_rbs=req)
+        num = lt["kbps"][cqi] if sc.algo_epsilon[sl] else np.ones((n, R))
+        den = ((1 + avg) / 1000.0)[:, None] if sc.algo_psi[sl] else np.ones((n, 1))
+        met = np.where(prio[:, None] != 0, hol[:, None] * num / den, 0.0) if sc.algo_alpha[sl] else num / den
+        alloc = np.zeros(n, np.int64)
+        want = np.full(R, -1)
+        for r in range(R):
+            ok = alloc < req
+            if ok.any():
+                k = int(np.flatnonzero(ok)[np.argmax(met[ok, r])])
+                want[r] = ids[k]
+                alloc[k] += G
+        np.testing.assert_array_equal(res.rbg_to_user, want, err_msg=f"sched 7 it {it}")
+        np.testing.assert_array_equal(res.user_nprb, alloc)
+        bound += int((want < 0).sum())
+    assert bound > 0, "the m_requiredRBs gate never left an RBG unallocated"
+    ts.close()
+    # ---- sched 1: the passed "users" are flows
+    n = 12
+    sc1 = rs.SliceConfig([n])
+    ts = rs.TtiScheduler(sc1, R, G, sched=1)
+    left = 0
+    for it in range(10):
+        cqi = synth_cqi(700 + it, (n, R), HIST)
+        avg = rng.uniform(1e3, 5e6, n)
+        data = rng.integers(20, 150, n).astype(np.int32)
+        if it % 3 == 2:
+            data[: n // 2] = 100000000  # backlogged flows beside the finite ones: they take what the others leave
+        res = ts.schedule_tti(cqi, avg, data_to_transmit=data)
+        met = (lt["eff"][cqi] * 180000.) / avg[:, None]
+        done = np.zeros(n, bool)
+        prbs = [[] for _ in range(n)]
+        want = np.full(R, -1)
+        for r in range(R):
+            ok = ~done & (met[:, r] > 0)
+            if not ok.any():
+                continue
+            k = int(np.flatnonzero(ok)[np.argmax(met[ok, r])])
+            want[r] = k
+            prbs[k] += [cqi[k, r]] * G
+            fc = oracle.final_cqi(np.array(prbs[k], np.uint8))
+            tbs = oracle.lib().rso_tbs_bits(int(tabs["cqi_to_mcs"][fc - 1]), len(prbs[k]))
+            if tbs >= int(data[k]) * 8:
+                done[k] = True
+        np.testing.assert_array_equal(res.rbg_to_user, want, err_msg=f"sched 1 it {it}")
+        left += int((want < 0).sum())
+    assert left > 0, "every RBG was taken: the satisfied-flow break never emptied the race"
+    ts.close()
