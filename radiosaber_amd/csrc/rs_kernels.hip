@@ -486,6 +486,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #ifdef RS_SPEC_ALL
       return n;
 #else
+      /* the serial phase lasts ~330 cycles per RBG, a round of scans ~4 000-5 000: with many RBGs every round fits (64 RBGs:
+       * 13.06 instead of 12.92 M TTIs/s), with 25 a second, nearly empty round would outlast the serial wave */
+      const int rounds_all = (n + nsp_ - 1) / nsp_;
+      if (rounds_all * 16 <= R) return n;
       const int rounds = n / nsp_;
       return rounds == 0 ? n : rounds * nsp_;
 #endif
