@@ -65,7 +65,7 @@ __device__ __forceinline__ int interslice_greedy_by_row(const uint32_t* s_elems,
   return my_slice;
 }
 
-/* s_sorted: the R*S records in std::sort's order */
+/* s_sorted: the R*S records in std::sort's order.  One record per step (the default; the vector form below is -DRS_GREEDY_VECTOR) */
 template <int S_T, int R_T>
 __device__ __forceinline__ int interslice_maximize_cell(const uint32_t* s_sorted, const RsMisc* m, int S_rt, int R_rt, int& got
 #ifdef RS_STAMPS
@@ -131,6 +131,126 @@ __device__ __forceinline__ int interslice_maximize_cell(const uint32_t* s_sorted
 #endif
   if (lane < S) got = m->quota[lane] - left;
   return my_slice;
+}
+
+/*
+ * MaximizeCell greedy scan, ref: :362-369 -- the sorted records in order; a record takes its RBG when the RBG is still free and
+ * its slice is under quota.  A single wave issues one instruction every ~8 cycles whatever the instruction is, so the
+ * record-at-a-time loop (22 instructions per granted RBG + 28 per chunk of 64 records) costs ~7 000 cycles at 25 RBGs.  Here a
+ * whole vector of 64 records is decided at once:
+ *   taken(i) = live(i) and no taken(k < i) has i's RBG and fewer than left[slice(i)] taken(k < i) have i's slice
+ * is a recursion on the position, so the map T -> F(T) (evaluate the right-hand side with T in place of `taken`) has exactly
+ * one fixed point, the scan's answer, and iterating it from T = live reaches it: after n rounds the first n positions are final
+ * (measured: ~6 rounds for the first 64 records, which hold ~18 of 25 grants, ~4 for the rest).  A round is two masked popcounts
+ * per lane -- the lanes of the vector that hold my RBG / my slice and lie before me come from one LDS atomic OR per lane.
+ * After the first vector the rest of the array is compacted in place to the records that are still live (~40 of 436), which
+ * normally fit one more vector; if not, the compaction repeats after every vector.
+ * s_sorted is consumed (overwritten by the compaction); scratch: m->maskA / maskB (lane masks by RBG / by slice) and m->n_level
+ * (the slice every RBG went to), all free between the sort and the end of the TTI.
+ */
+template <bool K32> struct RsMaskT { typedef unsigned long long type; };
+template <> struct RsMaskT<true> { typedef uint32_t type; };
+
+template <int S_T, int R_T>
+__device__ __forceinline__ int interslice_maximize_cell_vector(uint32_t* s_sorted, RsMisc* m, int S_rt, int R_rt, int& got
+#ifdef RS_STAMPS
+                                                        , unsigned long long* stamp_acc
+#endif
+) {
+  const int lane = lane_id();
+  const int S = S_T ? S_T : S_rt, R = R_T ? R_T : R_rt; /* front-end constants in a shape-specialised build */
+  const int N = R * S;
+  /* RBG and slice sets as 32-bit scalars when the shape is known to fit (64-bit shifts by a lane value are slow) */
+  typedef typename RsMaskT<(S_T != 0 && R_T != 0 && S_T <= 32 && R_T <= 32)>::type set_t;
+  const unsigned long long me = 1ull << lane, lt = me - 1ull;
+  unsigned long long* const by_rbg = m->maskA;
+  unsigned long long* const by_slice = m->maskB;
+  unsigned char* const owner_of = (unsigned char*)m->n_level;
+  set_t free_rbg = R >= (int)(8 * sizeof(set_t)) ? ~(set_t)0 : (set_t)(((set_t)1 << R) - 1);
+  int left = lane < S ? m->quota[lane] : 0; /* lane s: quota[s] - granted[s] */
+  int n_taken = 0;
+#ifdef RS_STAMPS
+  int n_vec = 0;
+#endif
+  by_rbg[lane] = 0ull;
+  by_slice[lane] = 0ull;
+  owner_of[lane] = 0xFF;
+  int n = N, pos = 0;
+  while (n_taken < R && pos < n) {
+    {
+      const int i = pos + lane;
+      const bool valid = i < n;
+      const uint32_t e = s_sorted[valid ? i : 0];
+      const int rbg = (e >> 8) & 63, sl = e & 63;
+      /* lanes of this vector by RBG and by slice (every valid lane: the ones that are not live never enter T) */
+      if (valid) {
+        atomicOr(&by_rbg[rbg], me);
+        atomicOr(&by_slice[sl], me);
+      }
+      const int sl_left = __shfl(left, sl, 64); /* quota left of my record's slice (all lanes take part) */
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const unsigned long long before_r = by_rbg[rbg] & lt, before_s = by_slice[sl] & lt;
+      const unsigned long long of_rbg = by_rbg[lane], of_slice = by_slice[lane]; /* lane r: records of RBG r; lane s: of slice s */
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (valid) { /* clean for the next vector */
+        by_rbg[rbg] = 0ull;
+        by_slice[sl] = 0ull;
+      }
+      const unsigned long long live = __ballot(valid & (((free_rbg >> rbg) & 1) != 0) & (sl_left > 0));
+      unsigned long long T = live;
+      for (;;) {
+        const bool rbg_gone = (before_r & T) != 0ull;
+        const int used = __popcll(before_s & T);
+        const unsigned long long Tn = __ballot(!rbg_gone & (used < sl_left)) & live;
+        if (Tn == T) break;
+        T = Tn;
+      }
+      if ((T >> lane) & 1ull) owner_of[rbg] = (unsigned char)sl;
+      free_rbg &= ~(set_t)__ballot((of_rbg & T) != 0ull);
+      left -= __popcll(of_slice & T);
+      n_taken += __popcll(T);
+#ifdef RS_STAMPS
+      ++n_vec;
+#endif
+    }
+    pos += 64;
+    if (n_taken < R && n - pos > 64) {
+      /* keep what is still live of the rest (in place: the writes trail the reads; eight chunks of reads in flight) */
+      const set_t open_sl = (set_t)__ballot(left > 0);
+      int kept = 0;
+      for (int b = pos; b < n; b += 8 * 64) {
+        uint32_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int x = b + j * 64 + lane;
+          e[j] = s_sorted[x < n ? x : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int x = b + j * 64 + lane;
+          const int rbg = (e[j] >> 8) & 63, sl = e[j] & 63;
+          const unsigned long long mk = __ballot((x < n) & (((free_rbg >> rbg) & (open_sl >> sl) & 1) != 0));
+          if ((mk >> lane) & 1ull) s_sorted[kept + __popcll(mk & lt)] = e[j];
+          kept += __popcll(mk);
+        }
+      }
+      n = kept;
+      pos = 0;
+    }
+  }
+#ifdef RS_STAMPS
+  if (threadIdx.x == 0) {
+    stamp_acc[9] += (unsigned long long)n_taken;
+    stamp_acc[10] += (unsigned long long)n_vec; /* vectors decided */
+  }
+#endif
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < S) got = m->quota[lane] - left;
+  const int o = owner_of[lane];
+  return (lane < R && o != 0xFF) ? o : -1; /* lane r: slice that got RBG r */
 }
 
 template <int S_T, int R_T>

@@ -52,6 +52,9 @@ template <int N> struct RsInt { static constexpr int v = N; };
 #ifndef RS_SPEC_NAP
 #define RS_SPEC_NAP 2 /* s_sleep argument (x 64 cycles) while the scanning waves wait for the allocation */
 #endif
+#ifndef RS_SERIAL_PRIO
+#define RS_SERIAL_PRIO 3 /* issue priority of the wave that runs the serial end of the TTI (inter-slice policy, link adaptation) */
+#endif
 #ifndef RS_SPEC_PRIO
 #define RS_SPEC_PRIO 0 /* issue priority of the scanning waves during the serial phase */
 #endif
@@ -1315,7 +1318,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     if (SCHED != 10 && wave == 0) {
       /* the only running wave of this cell until the end-of-TTI barrier: ask the SIMD's arbiter to prefer it
        * over the co-resident cell's waves (measured +3 % with two cells per CU) */
-      __builtin_amdgcn_s_setprio(3);
+      __builtin_amdgcn_s_setprio(RS_SERIAL_PRIO);
       int owner = -1;
       int got = 0; /* lane s: RBGs granted to slice s */
       int my_target = 0, my_quota = 0; /* lane s: this TTI's values (the quota wave may overwrite the LDS copies for TTI t+1) */
@@ -1491,10 +1494,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         else if constexpr (SCHED == 101) my_slice = interslice_subopt<kS, kR>(cur_rec, m, (uint8_t*)(lds + o.sortx), S, R, got);
         else if constexpr (SCHED == 103) my_slice = interslice_vogel<kS, kR>(cur_rec, m, S, R, got);
         else {
-#ifdef RS_STAMPS
-          my_slice = interslice_maximize_cell<kS, kR>(s_sorted, m, S, R, got, stamp_acc);
+#ifdef RS_GREEDY_VECTOR /* whole vectors of records decided at once (rs_interslice.h): shorter alone on a CU, no gain with two cells per CU */
+#define RS_MAXCELL_SCAN interslice_maximize_cell_vector
 #else
-          my_slice = interslice_maximize_cell<kS, kR>(s_sorted, m, S, R, got);
+#define RS_MAXCELL_SCAN interslice_maximize_cell
+#endif
+#ifdef RS_STAMPS
+          my_slice = RS_MAXCELL_SCAN<kS, kR>(s_sorted, m, S, R, got, stamp_acc);
+#else
+          my_slice = RS_MAXCELL_SCAN<kS, kR>(s_sorted, m, S, R, got);
 #endif
         }
         if (kSpecSched && spec_next && !p.phy_draws) {

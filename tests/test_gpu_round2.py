@@ -297,3 +297,18 @@ def test_drop_in_gates_of_schedulers_7_and_1(rs, oracle):
         left += int((want < 0).sum())
     assert left > 0, "every RBG was taken: the satisfied-flow break never emptied the race"
     ts.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", ["-DRS_GREEDY_VECTOR"])
+def test_opt_in_kernel_variants_stay_bit_exact(rs, oracle, extra, monkeypatch):
+    """Build options of the shape-specialised kernel that are not the default (RS_JIT_EXTRA, part of the kernel cache key):
+    the vector form of the MaximizeCell scan (whole vectors of records decided by a fixed-point iteration, the rest of the
+    array compacted in place) against the oracle, on the headline shape, the 64-RBG grid and ragged / tiny cells."""
+    from test_gpu_parity import _check_batch
+    monkeypatch.setenv("RS_JIT_EXTRA", extra)
+    _check_batch(rs, oracle, 9, [25] * 20, 25, 4, n_cells=2, n_ttis=90, jit=True)
+    _check_batch(rs, oracle, 9, [25] * 20, 64, 8, n_cells=2, n_ttis=60, jit=True)
+    _check_batch(rs, oracle, 9, [3, 0, 7, 1, 12], 12, 2, n_cells=2, n_ttis=60, jit=True, threads=64)
+    _check_batch(rs, oracle, 9, [2] * 64, 64, 8, n_cells=1, n_ttis=45, jit=True)
+    _check_batch(rs, oracle, 9, [5] * 33, 33, 3, n_cells=2, n_ttis=60, jit=True, phy=1)
