@@ -151,7 +151,7 @@ __device__ __forceinline__ int interslice_maximize_cell(const uint32_t* s_sorted
 template <bool K32> struct RsMaskT { typedef unsigned long long type; };
 template <> struct RsMaskT<true> { typedef uint32_t type; };
 
-template <int S_T, int R_T>
+template <int S_T, int R_T, bool K32> /* K32: at most 32 RBGs and 32 slices */
 __device__ __forceinline__ int interslice_maximize_cell_vector(uint32_t* s_sorted, RsMisc* m, int S_rt, int R_rt, int& got
 #ifdef RS_STAMPS
                                                         , unsigned long long* stamp_acc
@@ -160,8 +160,8 @@ __device__ __forceinline__ int interslice_maximize_cell_vector(uint32_t* s_sorte
   const int lane = lane_id();
   const int S = S_T ? S_T : S_rt, R = R_T ? R_T : R_rt; /* front-end constants in a shape-specialised build */
   const int N = R * S;
-  /* RBG and slice sets as 32-bit scalars when the shape is known to fit (64-bit shifts by a lane value are slow) */
-  typedef typename RsMaskT<(S_T != 0 && R_T != 0 && S_T <= 32 && R_T <= 32)>::type set_t;
+  /* RBG and slice sets as 32-bit scalars when they fit (64-bit shifts by a lane value are slow) */
+  typedef typename RsMaskT<K32>::type set_t;
   const unsigned long long me = 1ull << lane, lt = me - 1ull;
   unsigned long long* const by_rbg = m->maskA;
   unsigned long long* const by_slice = m->maskB;

@@ -148,13 +148,33 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   /* Measured on MI355X (profiles/r02_spec_notes.md): it pays while a slice's scan is short -- +1 % (sched 9) ... +7 % (sched 8) at
    * 25 UEs per slice, -4 ... -7 % at 50, where the rescans after the barrier cost more than the scan they replace: on up to
    * 32 UEs per slice on average; a shape-specialised build for a larger shape does not carry the code at all. */
+  /* MaximizeCell's greedy scan (rs_interslice.h) in its vector form up to 32 RBGs, one record per step above (measured, 512
+   * cells: 25 RBGs 31.1 against 30.3 M TTIs/s, 64 RBGs 12.4 against 13.1 M -- with many RBGs the scanning waves' LDS traffic slows
+   * the vector form's atomics and compaction more than the serial loop's lane reads).  The vector form shortens the serial
+   * phase to the point where the speculation no longer pays for its fix-up pass and its flags (31.1 M without, 30.8 M with the
+   * averages alone prepared, 29.9 M with the scan): MaximizeCell speculates only where it keeps the serial scan.
+   * -DRS_GREEDY_SERIAL / -DRS_GREEDY_VECTOR force one form, -DRS_SPEC_WITH_VECTOR keeps the speculation beside the vector form. */
+#if defined(RS_GREEDY_SERIAL)
+  constexpr int kVecMaxR = 0;
+#elif defined(RS_GREEDY_VECTOR)
+  constexpr int kVecMaxR = 64;
+#else
+  constexpr int kVecMaxR = 32;
+#endif
+  constexpr bool kVecScan = SCHED == 9 && kVecMaxR > 0 && (!FIXED || RS_JIT_R <= kVecMaxR);
+  const bool vec_scan = kVecScan && R <= kVecMaxR;
+#ifdef RS_SPEC_WITH_VECTOR
+  constexpr bool kSpecBesideVec = true;
+#else
+  constexpr bool kSpecBesideVec = false;
+#endif
 #ifdef RS_NO_SPEC
   constexpr bool kSpecSched = false;
 #else
   constexpr bool kSpecSched = !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103) &&
-                              (!FIXED || RS_JIT_U <= 32 * RS_JIT_S);
+                              (!FIXED || RS_JIT_U <= 32 * RS_JIT_S) && (kSpecBesideVec || !(FIXED && kVecScan));
 #endif
-  const bool spec_enabled = kSpecSched && nwaves >= 2 && U <= 32 * S;
+  const bool spec_enabled = kSpecSched && nwaves >= 2 && U <= 32 * S && (kSpecBesideVec || !vec_scan);
 
   double* s_avg = (double*)lds;
   double* s_avgk = (double*)(lds + o.avgk);
@@ -486,7 +506,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     /* items the scanning waves take in the serial phase: whole rounds of nt - 64 lanes (at least one round) */
     auto spec_items = [&](int n) {
       const int nsp_ = nt > 64 ? nt - 64 : 64; /* (one-wave cells never speculate) */
-#ifdef RS_SPEC_ALL
+#if defined(RS_SPEC_EWMA_ONLY)
+      return 0; /* the serial phase prepares the averages and the quotas of TTI t+1 only; every item is scanned at the top */
+#elif defined(RS_SPEC_ALL)
       return n;
 #else
       /* the serial phase lasts ~330 cycles per RBG, a round of scans ~4 000-5 000: with many RBGs every round fits (64 RBGs:
@@ -1494,16 +1516,22 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         else if constexpr (SCHED == 101) my_slice = interslice_subopt<kS, kR>(cur_rec, m, (uint8_t*)(lds + o.sortx), S, R, got);
         else if constexpr (SCHED == 103) my_slice = interslice_vogel<kS, kR>(cur_rec, m, S, R, got);
         else {
-#ifdef RS_GREEDY_VECTOR /* whole vectors of records decided at once (rs_interslice.h): shorter alone on a CU, no gain with two cells per CU */
-#define RS_MAXCELL_SCAN interslice_maximize_cell_vector
-#else
-#define RS_MAXCELL_SCAN interslice_maximize_cell
-#endif
 #ifdef RS_STAMPS
-          my_slice = RS_MAXCELL_SCAN<kS, kR>(s_sorted, m, S, R, got, stamp_acc);
+#define RS_SCAN_ARGS s_sorted, m, S, R, got, stamp_acc
 #else
-          my_slice = RS_MAXCELL_SCAN<kS, kR>(s_sorted, m, S, R, got);
+#define RS_SCAN_ARGS s_sorted, m, S, R, got
 #endif
+          if constexpr (kVecScan) {
+            if constexpr (FIXED) {
+              my_slice = interslice_maximize_cell_vector<kS, kR, (kS <= 32 && kR <= 32)>(RS_SCAN_ARGS);
+            } else {
+              if (vec_scan && R <= 32 && S <= 32) my_slice = interslice_maximize_cell_vector<0, 0, true>(RS_SCAN_ARGS);
+              else if (vec_scan) my_slice = interslice_maximize_cell_vector<0, 0, false>(RS_SCAN_ARGS);
+              else my_slice = interslice_maximize_cell<0, 0>(RS_SCAN_ARGS);
+            }
+          } else {
+            my_slice = interslice_maximize_cell<kS, kR>(RS_SCAN_ARGS);
+          }
         }
         if (kSpecSched && spec_next && !p.phy_draws) {
           /* slice_rbs_offset_ is final as soon as the RBGs are dealt out (ref: :618-620): the quota wave can start TTI t+1's

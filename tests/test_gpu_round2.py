@@ -300,11 +300,12 @@ def test_drop_in_gates_of_schedulers_7_and_1(rs, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", ["-DRS_GREEDY_VECTOR"])
+@pytest.mark.parametrize("extra", ["-DRS_GREEDY_VECTOR", "-DRS_GREEDY_SERIAL", "-DRS_GREEDY_VECTOR -DRS_SPEC_WITH_VECTOR", "-DRS_NO_SPEC"])
 def test_opt_in_kernel_variants_stay_bit_exact(rs, oracle, extra, monkeypatch):
-    """Build options of the shape-specialised kernel that are not the default (RS_JIT_EXTRA, part of the kernel cache key):
-    the vector form of the MaximizeCell scan (whole vectors of records decided by a fixed-point iteration, the rest of the
-    array compacted in place) against the oracle, on the headline shape, the 64-RBG grid and ragged / tiny cells."""
+    """Build options of the shape-specialised kernel (RS_JIT_EXTRA, part of the kernel cache key) that force what the default
+    picks by shape: the vector form of the MaximizeCell scan (whole vectors of records decided by a fixed-point iteration,
+    the rest of the array compacted in place; default up to 32 RBGs) or the serial one everywhere, the speculation beside the
+    vector form, no speculation at all -- each against the oracle on the headline shape, the 64-RBG grid and ragged / tiny cells."""
     from test_gpu_parity import _check_batch
     monkeypatch.setenv("RS_JIT_EXTRA", extra)
     _check_batch(rs, oracle, 9, [25] * 20, 25, 4, n_cells=2, n_ttis=90, jit=True)
