@@ -151,6 +151,50 @@ __device__ __forceinline__ int interslice_maximize_cell(const uint32_t* s_sorted
 template <bool K32> struct RsMaskT { typedef unsigned long long type; };
 template <> struct RsMaskT<true> { typedef uint32_t type; };
 
+/* one vector: records src[pos .. pos+64) of a stream of n, decided on the calling wave; free_rbg / left / n_taken updated */
+template <class set_t>
+__device__ __forceinline__ void rs_scan_decide_vector(const uint32_t* src, int pos, int n, RsMisc* m, set_t& free_rbg, int& left,
+                                                      int& n_taken) {
+  const int lane = lane_id();
+  const unsigned long long me = 1ull << lane, lt = me - 1ull;
+  unsigned long long* const by_rbg = m->maskA;
+  unsigned long long* const by_slice = m->maskB;
+  unsigned char* const owner_of = (unsigned char*)m->n_level;
+  const int i = pos + lane;
+  const bool valid = i < n;
+  const uint32_t e = src[valid ? i : 0];
+  const int rbg = (e >> 8) & 63, sl = e & 63;
+  /* lanes of this vector by RBG and by slice (every valid lane: the ones that are not live never enter T) */
+  if (valid) {
+    atomicOr(&by_rbg[rbg], me);
+    atomicOr(&by_slice[sl], me);
+  }
+  const int sl_left = __shfl(left, sl, 64); /* quota left of my record's slice (all lanes take part) */
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long before_r = by_rbg[rbg] & lt, before_s = by_slice[sl] & lt;
+  const unsigned long long of_rbg = by_rbg[lane], of_slice = by_slice[lane]; /* lane r: records of RBG r; lane s: of slice s */
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (valid) { /* clean for the next vector */
+    by_rbg[rbg] = 0ull;
+    by_slice[sl] = 0ull;
+  }
+  const unsigned long long live = __ballot(valid & (((free_rbg >> rbg) & 1) != 0) & (sl_left > 0));
+  unsigned long long T = live;
+  for (;;) {
+    const bool rbg_gone = (before_r & T) != 0ull;
+    const int used = __popcll(before_s & T);
+    const unsigned long long Tn = __ballot(!rbg_gone & (used < sl_left)) & live;
+    if (Tn == T) break;
+    T = Tn;
+  }
+  if ((T >> lane) & 1ull) owner_of[rbg] = (unsigned char)sl;
+  free_rbg &= ~(set_t)__ballot((of_rbg & T) != 0ull);
+  left -= __popcll(of_slice & T);
+  n_taken += __popcll(T);
+}
+
 template <int S_T, int R_T, bool K32> /* K32: at most 32 RBGs and 32 slices */
 __device__ __forceinline__ int interslice_maximize_cell_vector(uint32_t* s_sorted, RsMisc* m, int S_rt, int R_rt, int& got
 #ifdef RS_STAMPS
@@ -162,59 +206,22 @@ __device__ __forceinline__ int interslice_maximize_cell_vector(uint32_t* s_sorte
   const int N = R * S;
   /* RBG and slice sets as 32-bit scalars when they fit (64-bit shifts by a lane value are slow) */
   typedef typename RsMaskT<K32>::type set_t;
-  const unsigned long long me = 1ull << lane, lt = me - 1ull;
-  unsigned long long* const by_rbg = m->maskA;
-  unsigned long long* const by_slice = m->maskB;
-  unsigned char* const owner_of = (unsigned char*)m->n_level;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   set_t free_rbg = R >= (int)(8 * sizeof(set_t)) ? ~(set_t)0 : (set_t)(((set_t)1 << R) - 1);
   int left = lane < S ? m->quota[lane] : 0; /* lane s: quota[s] - granted[s] */
   int n_taken = 0;
 #ifdef RS_STAMPS
   int n_vec = 0;
 #endif
-  by_rbg[lane] = 0ull;
-  by_slice[lane] = 0ull;
-  owner_of[lane] = 0xFF;
+  m->maskA[lane] = 0ull;
+  m->maskB[lane] = 0ull;
+  ((unsigned char*)m->n_level)[lane] = 0xFF;
   int n = N, pos = 0;
   while (n_taken < R && pos < n) {
-    {
-      const int i = pos + lane;
-      const bool valid = i < n;
-      const uint32_t e = s_sorted[valid ? i : 0];
-      const int rbg = (e >> 8) & 63, sl = e & 63;
-      /* lanes of this vector by RBG and by slice (every valid lane: the ones that are not live never enter T) */
-      if (valid) {
-        atomicOr(&by_rbg[rbg], me);
-        atomicOr(&by_slice[sl], me);
-      }
-      const int sl_left = __shfl(left, sl, 64); /* quota left of my record's slice (all lanes take part) */
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const unsigned long long before_r = by_rbg[rbg] & lt, before_s = by_slice[sl] & lt;
-      const unsigned long long of_rbg = by_rbg[lane], of_slice = by_slice[lane]; /* lane r: records of RBG r; lane s: of slice s */
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (valid) { /* clean for the next vector */
-        by_rbg[rbg] = 0ull;
-        by_slice[sl] = 0ull;
-      }
-      const unsigned long long live = __ballot(valid & (((free_rbg >> rbg) & 1) != 0) & (sl_left > 0));
-      unsigned long long T = live;
-      for (;;) {
-        const bool rbg_gone = (before_r & T) != 0ull;
-        const int used = __popcll(before_s & T);
-        const unsigned long long Tn = __ballot(!rbg_gone & (used < sl_left)) & live;
-        if (Tn == T) break;
-        T = Tn;
-      }
-      if ((T >> lane) & 1ull) owner_of[rbg] = (unsigned char)sl;
-      free_rbg &= ~(set_t)__ballot((of_rbg & T) != 0ull);
-      left -= __popcll(of_slice & T);
-      n_taken += __popcll(T);
+    rs_scan_decide_vector<set_t>(s_sorted, pos, n, m, free_rbg, left, n_taken);
 #ifdef RS_STAMPS
-      ++n_vec;
+    ++n_vec;
 #endif
-    }
     pos += 64;
     if (n_taken < R && n - pos > 64) {
       /* keep what is still live of the rest (in place: the writes trail the reads; eight chunks of reads in flight) */
@@ -249,8 +256,109 @@ __device__ __forceinline__ int interslice_maximize_cell_vector(uint32_t* s_sorte
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (lane < S) got = m->quota[lane] - left;
-  const int o = owner_of[lane];
+  const int o = ((unsigned char*)m->n_level)[lane];
   return (lane < R && o != 0xFF) ? o : -1; /* lane r: slice that got RBG r */
+}
+
+/*
+ * The same scan called by EVERY wave of the workgroup (when the other waves have nothing else to do in the serial phase, i.e. no
+ * speculation): wave 0 decides the vectors, the compaction between two vectors is shared -- every wave tests its chunks of the
+ * rest of the stream (pass 1: one ballot per chunk to LDS), then writes the live records of its chunks behind those of the
+ * chunks before (pass 2: a prefix over the chunk counts) into the OTHER buffer, so nobody overwrites what somebody still reads.
+ * Three workgroup barriers per round (state published / masks complete / records written); wave 0's share of a round drops from
+ * ~170 to ~40 instructions.  Scratch: m->hist (state words by round parity, chunk masks).  Results in wave 0 only.
+ */
+template <int S_T, int R_T, bool K32>
+__device__ __forceinline__ int interslice_maximize_cell_vector_wg(uint32_t* buf_a, uint32_t* buf_b, RsMisc* m, int S_rt, int R_rt, int& got
+#ifdef RS_STAMPS
+                                                           , unsigned long long* stamp_acc
+#endif
+) {
+  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
+  const int S = S_T ? S_T : S_rt, R = R_T ? R_T : R_rt;
+  const int N = R * S;
+  typedef typename RsMaskT<K32>::type set_t;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int32_t* const st = (int32_t*)m->hist;                                /* [parity][8]: free_rbg, open slices, RBGs granted so far */
+  unsigned long long* const lmask = (unsigned long long*)(st + 16);     /* [32] live lanes of a chunk */
+  set_t free_rbg = R >= (int)(8 * sizeof(set_t)) ? ~(set_t)0 : (set_t)(((set_t)1 << R) - 1);
+  int left = lane < S ? m->quota[lane] : 0;
+  int n_taken = 0;
+#ifdef RS_STAMPS
+  int n_vec = 0;
+#endif
+  if (wave == 0) {
+    m->maskA[lane] = 0ull;
+    m->maskB[lane] = 0ull;
+    ((unsigned char*)m->n_level)[lane] = 0xFF;
+  }
+  uint32_t* src = buf_a;
+  uint32_t* dst = buf_b;
+  int n = N, pos = 0;
+  for (int round = 0;; ++round) {
+    int32_t* const stp = st + 8 * (round & 1);
+    if (wave == 0) {
+      rs_scan_decide_vector<set_t>(src, pos, n, m, free_rbg, left, n_taken);
+#ifdef RS_STAMPS
+      ++n_vec;
+#endif
+      const unsigned long long open = __ballot(left > 0);
+      if (lane == 0) {
+        stp[0] = (int32_t)(uint32_t)free_rbg;
+        stp[1] = (int32_t)(uint32_t)((unsigned long long)free_rbg >> 32);
+        stp[2] = (int32_t)(uint32_t)open;
+        stp[3] = (int32_t)(uint32_t)(open >> 32);
+        stp[4] = n_taken;
+      }
+    }
+    __syncthreads();
+    const int taken = stp[4];
+    pos += 64;
+    if (taken >= R || pos >= n) break;
+    if (n - pos > 64) {
+      const set_t fr = (set_t)((unsigned long long)(uint32_t)stp[0] | ((unsigned long long)(uint32_t)stp[1] << 32));
+      const set_t op = (set_t)((unsigned long long)(uint32_t)stp[2] | ((unsigned long long)(uint32_t)stp[3] << 32));
+      const int c_tot = (n - pos + 63) >> 6; /* at most 32 chunks (2 048 records) */
+      for (int c = wave; c < c_tot; c += nwaves) {
+        const int x = pos + (c << 6) + lane;
+        const uint32_t e = src[x < n ? x : 0];
+        const int rbg = (e >> 8) & 63, sl = e & 63;
+        const unsigned long long mk = __ballot((x < n) & (((fr >> rbg) & (op >> sl) & 1) != 0));
+        if (lane == 0) lmask[c] = mk;
+      }
+      __syncthreads();
+      const int cnt = lane < c_tot ? __popcll(lmask[lane]) : 0;
+      const int incl = wave_scan_incl(cnt);
+      const int kept = __builtin_amdgcn_readlane(incl, 63);
+      const int pre = incl - cnt;
+      for (int c = wave; c < c_tot; c += nwaves) {
+        const int cu = __builtin_amdgcn_readfirstlane(c);
+        const int x = pos + (cu << 6) + lane;
+        const uint32_t e = src[x < n ? x : 0];
+        const unsigned long long mk = lmask[cu];
+        const int base = __builtin_amdgcn_readlane(pre, cu);
+        if ((mk >> lane) & 1ull) dst[base + __popcll(mk & lt)] = e;
+      }
+      __syncthreads();
+      uint32_t* t = src;
+      src = dst;
+      dst = t;
+      n = kept;
+      pos = 0;
+    }
+  }
+  if (wave != 0) return -1;
+#ifdef RS_STAMPS
+  if (threadIdx.x == 0) {
+    stamp_acc[9] += (unsigned long long)n_taken;
+    stamp_acc[10] += (unsigned long long)n_vec;
+  }
+#endif
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < S) got = m->quota[lane] - left;
+  const int o = ((unsigned char*)m->n_level)[lane];
+  return (lane < R && o != 0xFF) ? o : -1;
 }
 
 template <int S_T, int R_T>

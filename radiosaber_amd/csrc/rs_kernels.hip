@@ -1337,6 +1337,31 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         spec_next = reported && !(((int)(t_next * 1000) - last_sent) >= 40);
       }
     }
+    /* Opt-in (-DRS_COOP_SCAN): MaximizeCell's vector scan with nothing speculated beside it and every wave taking part (the
+     * compaction between two vectors is shared, rs_interslice.h); the decisions still fall on wave 0, which keeps the result */
+#ifdef RS_STAMPS
+#define RS_SCAN_WG_ARGS s_sorted, s_elems, m, S, R, pre_got, stamp_acc
+#else
+#define RS_SCAN_WG_ARGS s_sorted, s_elems, m, S, R, pre_got
+#endif
+#ifdef RS_COOP_SCAN /* measured at 25 RBGs, two cells per CU: 30.75 against 31.03 M TTIs/s (three more barriers per TTI); +3 % at 64 RBGs */
+    constexpr bool kCoopScan = kVecScan;
+#else
+    constexpr bool kCoopScan = false;
+#endif
+    const bool coop_scan = kCoopScan && vec_scan && !spec_enabled;
+    int pre_slice = -1, pre_got = 0;
+    if constexpr (kCoopScan) {
+      if (coop_scan) {
+        if (wave == 0) __builtin_amdgcn_s_setprio(RS_SERIAL_PRIO);
+        if constexpr (FIXED) {
+          pre_slice = interslice_maximize_cell_vector_wg<RS_JIT_S, RS_JIT_R, (RS_JIT_S <= 32 && RS_JIT_R <= 32)>(RS_SCAN_WG_ARGS);
+        } else {
+          if (R <= 32 && S <= 32) pre_slice = interslice_maximize_cell_vector_wg<0, 0, true>(RS_SCAN_WG_ARGS);
+          else pre_slice = interslice_maximize_cell_vector_wg<0, 0, false>(RS_SCAN_WG_ARGS);
+        }
+      }
+    }
     if (SCHED != 10 && wave == 0) {
       /* the only running wave of this cell until the end-of-TTI barrier: ask the SIMD's arbiter to prefer it
        * over the co-resident cell's waves (measured +3 % with two cells per CU) */
@@ -1521,7 +1546,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #else
 #define RS_SCAN_ARGS s_sorted, m, S, R, got
 #endif
-          if constexpr (kVecScan) {
+          if (coop_scan) {
+            my_slice = pre_slice;
+            got = pre_got;
+          } else if constexpr (kVecScan) {
             if constexpr (FIXED) {
               my_slice = interslice_maximize_cell_vector<kS, kR, (kS <= 32 && kR <= 32)>(RS_SCAN_ARGS);
             } else {
