@@ -14,7 +14,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 tag = sys.argv[1]
-f = sorted(glob.glob(str(ROOT / f"gpurun_out/pmc_{tag}/*/*_counter_collection.csv")))[-1]
+f = max(glob.glob(str(ROOT / f"gpurun_out/pmc_{tag}/*/*_counter_collection.csv")), key=lambda q: Path(q).stat().st_mtime)  # newest run
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     if "rs_cell_kernel" in r["Kernel_Name"]:
