@@ -1620,9 +1620,31 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       constexpr int kOwnerMax = FIXED ? (kFlows ? 2 * RS_JIT_U : RS_JIT_U) : 0;
       constexpr int kOwnerBits = !FIXED ? (kFlows ? 12 : 11) : kOwnerMax < 63 ? 6 : kOwnerMax < 127 ? 7 : kOwnerMax < 255 ? 8
                                  : kOwnerMax < 511 ? 9 : kOwnerMax < 1023 ? 10 : kOwnerMax < 2047 ? 11 : 12;
+#ifdef RS_OWNER_BALLOTS /* the form this replaced: one ballot per bit of the owner index (~55 instructions at 500 UEs) */
       BitBallots<kOwnerBits> ob;
       ob.gather(owner + 1, lane < R && owner >= 0);
       const unsigned long long same = owner >= 0 ? ob.lanes_with(owner + 1) : 0ull;
+#else
+      /* owner + 1 < 4096 = two base-64 digits: the lanes that share both digits share the owner.  One LDS atomic OR per digit
+       * into the sort's two 64-entry mask arrays (idle here), ~15 instructions and one LDS round trip */
+      unsigned long long same = 0ull;
+      {
+        const bool has = lane < R && owner >= 0;
+        const int key = has ? owner + 1 : 0;
+        m->maskA[lane] = 0ull;
+        m->maskB[lane] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (has) {
+          atomicOr(&m->maskA[key & 63], 1ull << lane);
+          atomicOr(&m->maskB[key >> 6], 1ull << lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long lo = m->maskA[key & 63], hi = m->maskB[key >> 6];
+        if (has) same = lo & hi;
+      }
+#endif
       const bool leader = owner >= 0 && (same & ((1ull << lane) - 1ull)) == 0;
       const unsigned long long lead_mask = __ballot(leader);
       served_prev = __popcll(lead_mask);
