@@ -1667,6 +1667,23 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         unsigned long long mm = leader ? same : 0ull;
         double sum = 0;
         const uint8_t* col = s_cqi + (owner < 0 ? 0 : (kFlows ? owner >> 1 : owner));
+#ifndef RS_LA_NO_GATHER /* (the opt-out is the form this replaced: sched 7 -4 % at 25 RBGs, -8 % at 64) */
+        /* every RBG lane looks up the E value of its own RBG for its owner once (two dependent LDS reads, all lanes side by
+         * side); the leaders then collect their lanes' values in RBG order with lane reads instead of two LDS round trips per RBG */
+        if (!per_prb) {
+          const double ev_mine = (lane < R && owner >= 0) ? s_e[col[lane * Upad]] : 0.0;
+          while (__ballot(mm != 0ull) != 0ull) { /* every lane stays in the loop: a lane read from a masked-off lane returns 0 */
+            const bool more = mm != 0ull;
+            const int r2 = more ? __ffsll((long long)mm) - 1 : 0;
+            mm &= mm - 1;
+            const double ev = __shfl(ev_mine, r2, 64);
+            if (more) {
+              for (int k = 0; k < G; ++k) sum += ev;
+              nprb += G;
+            }
+          }
+        }
+#endif
         while (mm) {
           const int r2 = __ffsll((long long)mm) - 1;
           mm &= mm - 1;
