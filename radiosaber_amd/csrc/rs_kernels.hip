@@ -49,6 +49,22 @@ namespace {
 #define RS_P3_BLOCK_TOP 0 /* users per stage-1 block of the scan at the top of the TTI (0: the same as in the serial phase) */
 #endif
 template <int N> struct RsInt { static constexpr int v = N; };
+
+/* x / 1000.0 correctly rounded in three instructions instead of the ~35 of the FP64 division sequence (ref: averageRate /= 1000.0,
+ * downlink-transport-scheduler.cpp:685-689; one per user per TTI).  Markstein's theorem: if q is a faithful approximation of a / b
+ * and y approximates 1 / b with a relative error below 2^-53, then r = fma(-b, q, a) is exact and fma(r, y, q) = RN(a / b).
+ * Here y = 0.001 as a double (relative error 2.08e-17 = 2^-55.4), so q = RN(x * y) lies within 0.5 + 0.19 ulp of x / 1000, i.e.
+ * it is one of its two neighbours.  No underflow: x >= 1.  tests/test_abi.py checks the identity in exact rational arithmetic
+ * (random, near-midpoint and small-integer quotients); -DRS_DIV1000_HW restores the division. */
+__device__ __forceinline__ double rs_div_1000(double x) {
+#ifdef RS_DIV1000_HW
+  return x / 1000.0;
+#else
+  const double q = x * 0.001;
+  const double r = __builtin_fma(-q, 1000.0, x);
+  return __builtin_fma(r, 0.001, q);
+#endif
+}
 #ifndef RS_SPEC_NAP
 #define RS_SPEC_NAP 2 /* s_sleep argument (x 64 cycles) while the scanning waves wait for the allocation */
 #endif
@@ -523,7 +539,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     auto pf_terms = [&](int u, double a) {
       double k = 1;
       k += a;
-      k /= 1000.0;
+      k = rs_div_1000(k);
       s_avgk[u] = k;
       const int uo = s_uoff[u];
       /* stage-1 ranking only, never part of a result; psi == 0 slices rank on the numerator */
@@ -588,7 +604,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         double k = 1; /* averageRate = 1; += every bearer of the record, in index order (:681-686) */
         if (has[0]) k += bavg[0];
         if (has[1]) k += bavg[1];
-        k /= 1000.0;
+        k = rs_div_1000(k);
         s_avgk[u] = k;
         if (active) {
           const int sl = p.user_slice[u];
@@ -654,7 +670,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             /* ref: :685-689  averageRate = 1 + sum(avg); averageRate /= 1000.0 */
             double k = 1;
             k += a;
-            k /= 1000.0;
+            k = rs_div_1000(k);
             s_avgk[u] = k;
             const int uo = s_uoff[u];
             float r32 = (uo & 1) ? __builtin_amdgcn_rcpf((float)k) : 1.0f;

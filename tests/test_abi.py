@@ -127,3 +127,36 @@ def test_headline_shapes_keep_four_cells_per_cu(rs):
     assert rs.lds_bytes_per_cell(20, 500, 25, 10, 512) <= 40960
     with pytest.raises(rs.RadioSaberError):
         rs.lds_bytes_per_cell(65, 500, 25)
+
+
+def test_division_by_1000_in_three_operations_is_correctly_rounded():
+    """The kernel replaces `averageRate /= 1000.0` by q = x * 0.001; r = fma(-q, 1000, x); fma(r, 0.001, q) (rs_div_1000, Markstein's
+    theorem).  Checked here in exact rational arithmetic -- float(Fraction) rounds to nearest even, so an fma is one exact
+    expression rounded once -- on random inputs over the PF averages' range, on inputs whose quotient lies next to a midpoint of two
+    doubles, and on small integers."""
+    from fractions import Fraction
+    import math
+    import random
+
+    y = 0.001
+
+    def fma(a, b, c):
+        return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+    def div3(x):
+        q = x * y
+        return fma(fma(-q, 1000.0, x), y, q)
+
+    rnd = random.Random(7)
+    xs = [float(i) for i in range(1, 3000)]
+    xs += [1.0 + rnd.random() * 10 ** rnd.uniform(0, 9) for _ in range(60000)]
+    xs += [math.ldexp(1.0 + rnd.random(), rnd.randrange(0, 40)) for _ in range(20000)]
+    # quotients half an ulp away from a double: x = RN(1000 * (q + ulp(q)/2)) and its neighbours
+    for _ in range(20000):
+        q = math.ldexp(1.0 + rnd.random(), rnd.randrange(-9, 30))
+        mid = Fraction(q) + Fraction(math.ulp(q)) / 2
+        x = float(mid * 1000)
+        xs += [x, math.nextafter(x, math.inf), math.nextafter(x, 0.0)]
+    for x in xs:
+        if x >= 1.0:
+            assert div3(x) == x / 1000.0, x

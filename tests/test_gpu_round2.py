@@ -300,7 +300,7 @@ def test_drop_in_gates_of_schedulers_7_and_1(rs, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", ["-DRS_GREEDY_VECTOR", "-DRS_GREEDY_SERIAL", "-DRS_GREEDY_VECTOR -DRS_SPEC_WITH_VECTOR", "-DRS_NO_SPEC", "-DRS_COOP_SCAN", "-DRS_COOP_SCAN -DRS_GREEDY_VECTOR -DRS_NO_SPEC", "-DRS_GREEDY_SERIAL -DRS_SPEC_EWMA_ONLY", "-DRS_OWNER_BALLOTS -DRS_LA_NO_GATHER"])
+@pytest.mark.parametrize("extra", ["-DRS_GREEDY_VECTOR", "-DRS_GREEDY_SERIAL", "-DRS_GREEDY_VECTOR -DRS_SPEC_WITH_VECTOR", "-DRS_NO_SPEC", "-DRS_COOP_SCAN", "-DRS_COOP_SCAN -DRS_GREEDY_VECTOR -DRS_NO_SPEC", "-DRS_GREEDY_SERIAL -DRS_SPEC_EWMA_ONLY", "-DRS_OWNER_BALLOTS -DRS_LA_NO_GATHER -DRS_DIV1000_HW"])
 def test_opt_in_kernel_variants_stay_bit_exact(rs, oracle, extra, monkeypatch):
     """Build options of the shape-specialised kernel (RS_JIT_EXTRA, part of the kernel cache key) that force what the default
     picks by shape: the vector form of the MaximizeCell scan (whole vectors of records decided by a fixed-point iteration,
