@@ -389,7 +389,11 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     {
       int cnt = 0;
       if (lane < n_chunks) cnt = __popcll(m->maskA[lane]) | (__popcll(m->maskB[lane]) << 16);
+#ifdef RS_SORT_SCAN64
       pre = wave_scan_incl(cnt) - cnt;
+#else
+      pre = (n_chunks <= 8 ? wave_scan_incl8(cnt) : wave_scan_incl(cnt)) - cnt; /* (512 records: the counts sit in lanes 0..7) */
+#endif
     }
     int slot[EPT]; /* where my element went / where its replacement arrives; -1: not swapped */
 #pragma unroll

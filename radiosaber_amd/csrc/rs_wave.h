@@ -184,6 +184,15 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
   return v;
 }
 
+/* the same for values that live in lanes 0..7 only (three steps inside the first row of 16 lanes) */
+__device__ __forceinline__ int wave_scan_incl8(int v) {
+  const int identity = 0;
+  RS_DPP_STEP(op_add, 0x111, 0xf, 0xf); /* row_shr:1 */
+  RS_DPP_STEP(op_add, 0x112, 0xf, 0xf); /* row_shr:2 */
+  RS_DPP_STEP(op_add, 0x114, 0xf, 0xe); /* row_shr:4 */
+  return v;
+}
+
 /* inclusive wave64 prefix maximum */
 __device__ __forceinline__ int wave_scan_max_incl(int v) {
   const int identity = (int)0x80000000;
