@@ -392,7 +392,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
 #ifdef RS_SORT_SCAN64
       pre = wave_scan_incl(cnt) - cnt;
 #else
-      pre = (n_chunks <= 8 ? wave_scan_incl8(cnt) : wave_scan_incl(cnt)) - cnt; /* (512 records: the counts sit in lanes 0..7) */
+      pre = n_chunks <= 8 ? wave_scan_excl8(cnt) : wave_scan_incl(cnt) - cnt; /* (512 records: the counts sit in lanes 0..7) */
 #endif
     }
     int slot[EPT]; /* where my element went / where its replacement arrives; -1: not swapped */

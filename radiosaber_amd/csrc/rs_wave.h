@@ -184,9 +184,11 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
   return v;
 }
 
-/* the same for values that live in lanes 0..7 only (three steps inside the first row of 16 lanes) */
-__device__ __forceinline__ int wave_scan_incl8(int v) {
+/* EXCLUSIVE prefix sum of values that live in lanes 0..7 only: shift by one lane, then three steps inside the first row of 16
+ * lanes (the input is dead after the shift, so every step is one v_add_u32_dpp in place) */
+__device__ __forceinline__ int wave_scan_excl8(int x) {
   const int identity = 0;
+  int v = __builtin_amdgcn_update_dpp(identity, x, 0x111, 0xf, 0xf, true); /* row_shr:1, lane 0 <- 0 */
   RS_DPP_STEP(op_add, 0x111, 0xf, 0xf); /* row_shr:1 */
   RS_DPP_STEP(op_add, 0x112, 0xf, 0xf); /* row_shr:2 */
   RS_DPP_STEP(op_add, 0x114, 0xf, 0xe); /* row_shr:4 */
