@@ -217,7 +217,7 @@ __device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* 
     /* piece bounds in lane space; every lane takes part in the four register reads (a masked-off source lane would
      * read as 0) */
     const int pf = active ? F + shift : 0, pl = active ? L + shift : 2;
-    const int ja = pf + 1, jb = pf + (pl - pf) / 2, jc = pl - 1;
+    const int ja = pf + 1, jb = pf + (int)((unsigned)(pl - pf) >> 1), jc = pl - 1;
     const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_bpermute(pf << 2, (int)e);
     const uint32_t sa = (uint32_t)__builtin_amdgcn_ds_bpermute(ja << 2, (int)e);
     const uint32_t sb = (uint32_t)__builtin_amdgcn_ds_bpermute(jb << 2, (int)e);
@@ -353,7 +353,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       moved[i] = false;
       if (active) {
         const int f = F[i], l = L[i];
-        const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
+        const int ia = f + 1, ib = f + (int)((unsigned)(l - f) >> 1), ic = l - 1; /* l > f: the halving needs no sign fix */
         uint32_t s0 = v[f];
         const uint32_t sa = v[ia], sb = v[ib], sc = v[ic];
         asm volatile("" : "+v"(s0)); /* keep the four LDS reads in one batch (one latency, not two) */
