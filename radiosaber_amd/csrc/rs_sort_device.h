@@ -370,10 +370,13 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
         if (x == f) { e[i] = sp; moved[i] = true; cuts[f >> 4] = 0x7fffffff; }
         else if (x == pick) { e[i] = s0; moved[i] = true; }
       }
-      const int k = (int)(e[i] >> 16);
+      /* keys are 0..15: compared as floats, with NaN for a position outside (f, l), each stop ballot is ONE v_cmp (both
+       * comparisons are false on NaN; an integer form needs the range test ANDed in and the mask rebuilt under EXEC) */
       const bool in = active && x > F[i];
-      isA[i] = in && k <= pk;
-      isB[i] = in && k >= pk;
+      const float kf = in ? (float)(e[i] >> 16) : __builtin_nanf("");
+      const float pkf = (float)pk;
+      isA[i] = kf <= pkf;
+      isB[i] = kf >= pkf;
       mAi[i] = __ballot(isA[i]);
       mBi[i] = __ballot(isB[i]);
       if (lane == 0 && c < n_chunks) {
