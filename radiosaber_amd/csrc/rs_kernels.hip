@@ -1734,7 +1734,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               else s_tx[owner >> 1] = bytes | (nprb << RS_TX_NPRB_SHIFT);
             } else if (kCumRegs || QUEUE) {
               /* the owner thread of P1 counts it (registers) / splits it over the user's bearers and dequeues (queue model) */
-              s_tx[owner] += bytes | (nprb << RS_TX_NPRB_SHIFT);
+              atomicAdd(&s_tx[owner], bytes | (nprb << RS_TX_NPRB_SHIFT)); /* one ds_add, nothing to wait for (this lane is the word's only writer) */
             } else {
               /* the next EWMA update consumes the bytes: in a speculated TTI that happens right below, on this lane */
               if (!(kSpecSched && spec_next)) s_tx[owner] += bytes;
