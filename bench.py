@@ -4,14 +4,18 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no launcher around it starts its own N ranks: the parent process touches
+neither HIP nor torch, runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port <free> bench.py ...` as a CHILD (no exec), relays rank 0's single JSON line and exits with the child's code.
+
 Workload (BASELINE.json configs[3]/[4], the batched form of the metric's 20 x 500 x 25 grid):
 every GPU holds `--cells` (512) independent cells of 20 slices x 25 UEs (500 UEs) x 25 RBGs,
 scheduler 9 (RadioSaber / MaximizeCell), PF parameters epsilon=1 psi=1, weights 0.05, backlogged
 flows, synthetic per-RBG CQI drawn i.i.d. from the reference trace corpus' histogram and redrawn
 every 40 TTIs, one libc-compatible rand() stream per cell.  One STEP = one kernel launch that runs
-`--ttis` (2000) complete DoSchedule() iterations of every cell; all inputs (the CQI grids of every
+`--ttis` (8000) complete DoSchedule() iterations of every cell; all inputs (the CQI grids of every
 epoch, the cell state) are resident in HBM before the timed region starts.  The default timed region
-is 60 launches = 120 000 TTIs per cell, about two seconds.
+is 20 launches = 160 000 TTIs per cell, about four seconds.
 
 value = cells_total * ttis * steps / wall time, wall time bracketed by barrier + device sync on
 both sides, max over ranks.  Cells are independent, so ranks share nothing during the run (cell ids,
@@ -156,14 +160,65 @@ def cpu_baseline(args, slices, seeds):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _launch_own_ranks(n):
+    """`python bench.py --gpus N` (N > 1) without a launcher: N fresh rank processes under torch.distributed.run, started as a
+    CHILD of this process (never exec: a process that replaces itself after touching the GPU takes the box down; this parent
+    has not touched HIP, and still does not exec).  stdout of the children is relayed: the one JSON line of rank 0 goes to
+    stdout, anything else to stderr.  Returns the children's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")  # torch.distributed.run would set 1 and warn; the ranks' host work is tiny
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    n_lines = 0
+    for ln in proc.stdout:
+        is_line = False
+        if ln.lstrip().startswith("{"):
+            try:
+                is_line = "metric" in json.loads(ln)
+            except ValueError:
+                is_line = False
+        if is_line:
+            n_lines += 1
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and n_lines != 1:
+        print(f"bench.py: expected one JSON line from rank 0, saw {n_lines}", file=sys.stderr)
+        return 1
+    return rc
+
+
+def _rccl_version(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:  # reporting nicety only
+        return f"unknown ({e})"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60,
-                    help="timed launches; the default measures 120 000 TTIs per cell, about 2 s")
+    ap.add_argument("--steps", type=int, default=20,
+                    help="timed launches; the default measures 160 000 TTIs per cell, about 4 s")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cells", type=int, default=512, help="independent cells per GPU")
-    ap.add_argument("--ttis", type=int, default=2000, help="TTIs per step (per launch)")
+    ap.add_argument("--ttis", type=int, default=8000,
+                    help="TTIs per step (per launch; at most 32 768): 8 000 makes one step ~0.2 s, so that even a "
+                         "20-step run is seconds long and visible to an external GPU-activity sampler")
     ap.add_argument("--slices", type=int, default=20)
     ap.add_argument("--ues-per-slice", type=int, default=25)
     ap.add_argument("--rbgs", type=int, default=25)
@@ -174,7 +229,22 @@ def main():
     ap.add_argument("--no-r64", action="store_true", help="skip the extra 64-RBG measurement (value_r64)")
     ap.add_argument("--no-jit", action="store_true", help="use the kernels built into the library instead of the "
                     "shape-specialised one compiled at create time")
+    ap.add_argument("--allow-variant", action="store_true",
+                    help="run although RS_JIT_EXTRA / RS_JIT is set in the environment (tuning experiments; the line says so)")
     args = ap.parse_args()
+
+    # A headline must come from the product kernel: build switches in the environment are refused unless asked for, and the
+    # JSON line always says what the run-time compiler was given.
+    jit_extra = os.environ.get("RS_JIT_EXTRA", "")
+    jit_env = os.environ.get("RS_JIT")
+    if (jit_extra.strip() or jit_env is not None) and not args.allow_variant:
+        raise SystemExit(f"bench.py: RS_JIT_EXTRA={jit_extra!r} RS_JIT={jit_env!r} is set: the kernel would not be the product "
+                         "build; unset it, or pass --allow-variant for a tuning experiment (recorded as jit_extra in the line)")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: start the ranks ourselves, BEFORE anything in this process touches HIP (or imports torch)
+        raise SystemExit(_launch_own_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -183,25 +253,29 @@ def main():
     from radiosaber_amd import sharding
 
     args.hist = rs.TRACE_CQI_HISTOGRAM
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world  # launched under torch.distributed.run: its world size is the number of GPUs
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     # one rank per GPU; RS_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs than ranks
     backend = os.environ.get("RS_BENCH_BACKEND", "nccl")
-    local_rank %= torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and backend == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks but only {n_dev} GPU(s) visible: RCCL needs one GPU per rank "
+                         "(RS_BENCH_BACKEND=gloo runs the N > 1 code path with ranks sharing a GPU, for plumbing tests only)")
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
+    ranks_in_group = 1
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        ranks_in_group = dist.get_world_size()
 
+    red_dev = "cuda" if backend == "nccl" else "cpu"  # where the tiny reductions live
     S, U, R = args.slices, args.slices * args.ues_per_slice, args.rbgs
     slices = rs.SliceConfig([args.ues_per_slice] * S, weight=[1.0 / S] * S)
     want_jit = not args.no_jit
@@ -210,9 +284,20 @@ def main():
         b = rs.BatchScheduler(slices, n_rbgs, rbg_size, args.cells, sched=args.sched, device=local_rank,
                               threads_per_cell=args.threads, jit=want_jit)
         code, msg = b.jit_status()
-        if want_jit and code != 1:
+        ok = (not want_jit) or code == 1
+        if world > 1:
+            # every rank leaves together: one rank exiting alone would leave the others in the next collective forever
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            all_ok = bool(flag.item())
+        else:
+            all_ok = ok
+        if not all_ok:
             # a headline measured on the slower built-in kernel must not pass unnoticed
-            raise SystemExit(f"bench.py: the shape-specialised kernel was requested but is not in use ({msg or code}); "
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(f"bench.py: the shape-specialised kernel was requested but is not in use on "
+                             f"{'this rank' if not ok else 'another rank'} ({msg or code}); "
                              "rerun with --no-jit to measure the built-in kernels on purpose")
         # cell ids are global: rank r owns cells [r*cells, (r+1)*cells); seeds and CQI grids are keyed on them
         b.seed(sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, args.cells)))
@@ -222,7 +307,6 @@ def main():
 
     batch = make_batch(R, args.rbg_size, args.steps + args.warmup, args.ttis)
     seeds = sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, args.cells))
-    red_dev = "cuda" if backend == "nccl" else "cpu"  # where the tiny reductions live
 
     def sync_all():
         torch.cuda.synchronize()
@@ -261,13 +345,26 @@ def main():
         b_tti = algorithmic_bytes_per_tti(U, R, S)
         achieved = b_tti * args.cells * args.ttis / launch_s / 1e9
         key = f"sched{args.sched}_S{S}_U{U}_R{R}_cells{args.cells}"
-        traffic = traffic_src = None
-        tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
-            ent = json.loads(tfile.read_text()).get(key)
-            if ent:  # recorded per TTI per cell so that it scales to this run's launch length
-                traffic = ent["hbm_bytes_per_cell_tti"] * args.cells * args.ttis
-                traffic_src = f"profiles/traffic.json[{key}]@{ent.get('commit', '?')} (PMC passes of an earlier run, not this one)"
+        src_hash = rs.device_source_hash()  # identity of the kernel sources inside the library that just ran
+
+        def recorded(fname):
+            """Entry of profiles/<fname> for this workload + whether it was recorded on other kernel code than this run's."""
+            f = ROOT / "profiles" / fname
+            ent = json.loads(f.read_text()).get(key) if f.exists() else None
+            if not ent:
+                return None, None
+            stale = ent.get("source_hash") != src_hash
+            if stale:
+                print(f"bench.py: profiles/{fname}[{key}] was recorded on device sources {ent.get('source_hash', '(no hash)')}, "
+                      f"this library is {src_hash}: STALE (re-run tools/profile_round.sh / tools/pmc_insts.sh)", file=sys.stderr)
+            return ent, stale
+
+        traffic = traffic_src = traffic_stale = None
+        ent, traffic_stale = recorded("traffic.json")
+        if ent:  # recorded per TTI per cell so that it scales to this run's launch length
+            traffic = ent["hbm_bytes_per_cell_tti"] * args.cells * args.ttis
+            traffic_src = (f"profiles/traffic.json[{key}]@{ent.get('commit', '?')} source_hash {ent.get('source_hash', 'none')} "
+                           "(PMC passes of an earlier run, not this one)")
         try:  # attainable HBM rate of this GPU (16 B/lane streaming copy, 1 GiB each way), beside the spec peak
             copy_gbs = rs.hbm_copy_probe(local_rank, 1 << 30, 10)
         except Exception as e:  # measurement nicety only
@@ -286,10 +383,15 @@ def main():
                        "sched": args.sched, "parallelism": f"cells sharded over {world} GPU(s), no data-path collective"},
             "us_per_tti_per_cell": launch_s / args.ttis * 1e6,
             "kernel": kernel_name,
+            # who reduced: the process-group backend ("nccl" IS RCCL on ROCm), the ranks it saw, the library version
+            "backend": backend if world > 1 else None, "ranks_in_group": ranks_in_group,
+            "rccl_version": _rccl_version(torch) if (world > 1 and backend == "nccl") else None,
+            "jit_extra": jit_extra, "jit_env": jit_env,
             "kernel_ms_per_launch": [round(float(x), 4) for x in ms],
             "total_slice_bytes": total_bytes,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_stale": traffic_stale,
                          "traffic_frac_of_peak": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "algorithmic_bytes_per_cell_tti": b_tti,
                          "resident_bytes_per_cell_tti": resident_bytes_per_tti(U, R, S, args.ttis),
@@ -298,19 +400,20 @@ def main():
                                  "issue/latency-bound: see roofline_issue",
                          "measured_copy_gbs": copy_gbs},
         }
-        ifile = ROOT / "profiles" / "inst_counts.json"
-        if ifile.exists():
-            ent = json.loads(ifile.read_text()).get(key)
-            if ent:
-                rate = value / world  # per GPU
-                line["roofline_issue"] = {
-                    "bound": "valu-issue + dependent-chain latency",
-                    "valu_per_cell_tti": ent["valu"], "salu_per_cell_tti": ent["salu"], "lds_per_cell_tti": ent["lds"],
-                    "valu_issue_frac": ent["valu"] * rate / VALU_ISSUE_PEAK,
-                    "valu_issue_peak_per_s": VALU_ISSUE_PEAK,
-                    "phase_shares": ent.get("phase_shares"),
-                    "source": f"profiles/inst_counts.json[{key}]@{ent.get('commit', '?')} (SQ_INSTS_* per cell-TTI from "
-                              "tools/pmc_insts.sh, phase shares from tools/phase_stamps.py; counts are per build, the rate is this run's)"}
+        line["source_hash"] = src_hash
+        ent, inst_stale = recorded("inst_counts.json")
+        if ent:
+            rate = value / world  # per GPU
+            line["roofline_issue"] = {
+                "stale": inst_stale,
+                "bound": "valu-issue + dependent-chain latency",
+                "valu_per_cell_tti": ent["valu"], "salu_per_cell_tti": ent["salu"], "lds_per_cell_tti": ent["lds"],
+                "valu_issue_frac": ent["valu"] * rate / VALU_ISSUE_PEAK,
+                "valu_issue_peak_per_s": VALU_ISSUE_PEAK,
+                "phase_shares": ent.get("phase_shares"),
+                "source": f"profiles/inst_counts.json[{key}]@{ent.get('commit', '?')} source_hash {ent.get('source_hash', 'none')} "
+                          "(SQ_INSTS_* per cell-TTI from tools/pmc_insts.sh, phase shares from tools/phase_stamps.py; counts "
+                          "are per build, the rate is this run's)"}
         if world == 1 and not args.no_r64 and (R, args.rbg_size) != (64, 8):
             # the as-shipped grid: 100 MHz = 512 PRBs = 64 RBGs of 8 (SURVEY 8d asks for it beside the headline)
             b64 = make_batch(64, 8, 4, args.ttis)

@@ -101,6 +101,8 @@ def lib():
         L.rso_cell_step_queues.argtypes = [C.c_void_p, C.c_double, C.POINTER(_Rng), C.POINTER(_TtiOut)]
         L.rso_run_synth_queues.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_uint, C.c_int,
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.rso_run_synth_queues_prb.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_uint, C.c_int,
+                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.rso_cell_get_bearer_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.rso_run_synth_prb.argtypes = L.rso_run_synth.argtypes
@@ -292,12 +294,13 @@ class Cell:
     def step_queues(self, now, rng, out):
         return lib().rso_cell_step_queues(self.h, now, C.byref(rng.g), C.byref(out.c))
 
-    def run_synth_queues(self, cqi_epochs, seed, n_ttis, refresh=40):
+    def run_synth_queues(self, cqi_epochs, seed, n_ttis, refresh=40, per_prb=False):
         e = np.ascontiguousarray(cqi_epochs, np.uint8)
-        assert e.shape[1:] == (self.U, self.R)
+        assert e.shape[1:] == (self.U, self.R * (self.rbg_size if per_prb else 1))
         logs = {"rbg_to_user": np.zeros((n_ttis, self.R), np.int32), "tbs_bits": np.zeros((n_ttis, self.U), np.int32)}
-        rc = lib().rso_run_synth_queues(self.h, _p(e, C.c_uint8), e.shape[0], refresh, seed, n_ttis,
-                                        _p(logs["rbg_to_user"], C.c_int), _p(logs["tbs_bits"], C.c_int))
+        fn = lib().rso_run_synth_queues_prb if per_prb else lib().rso_run_synth_queues
+        rc = fn(self.h, _p(e, C.c_uint8), e.shape[0], refresh, seed, n_ttis,
+                _p(logs["rbg_to_user"], C.c_int), _p(logs["tbs_bits"], C.c_int))
         if rc:
             raise RuntimeError(f"rso_run_synth_queues rc={rc}")
         return logs

@@ -1170,9 +1170,21 @@ int rso_cell_step_queues(rso_cell* c, double now, rso_rng* g, rso_tti_out* out) 
   return 0;
 }
 
-/* queue-mode run on synthetic grids: the clock, the CQI refresh and the rand() coupling of rso_run_synth */
+/* queue-mode run on synthetic grids: the clock, the CQI refresh and the rand() coupling of rso_run_synth; per_prb: the grids
+ * hold one CQI per PRB ([U][R*G] per epoch; the metric reads each RBG's first PRB, link adaptation, m_requiredRBs and the
+ * satisfied-flow break every PRB) */
+static int run_synth_queues_impl(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed, int n_ttis,
+                                 int* log_rbg_to_user, int* log_tbs_bits, bool per_prb);
 int rso_run_synth_queues(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed, int n_ttis,
                          int* log_rbg_to_user, int* log_tbs_bits) {
+  return run_synth_queues_impl(c, cqi_epochs, n_epochs, refresh, seed, n_ttis, log_rbg_to_user, log_tbs_bits, false);
+}
+int rso_run_synth_queues_prb(rso_cell* c, const uint8_t* cqi_prb_epochs, int n_epochs, int refresh, unsigned seed, int n_ttis,
+                             int* log_rbg_to_user, int* log_tbs_bits) {
+  return run_synth_queues_impl(c, cqi_prb_epochs, n_epochs, refresh, seed, n_ttis, log_rbg_to_user, log_tbs_bits, true);
+}
+static int run_synth_queues_impl(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed, int n_ttis,
+                                 int* log_rbg_to_user, int* log_tbs_bits, bool per_prb) {
   const int S = c->S, U = c->U, R = c->R;
   rso_rng g;
   rso_srand(&g, seed);
@@ -1184,7 +1196,8 @@ int rso_run_synth_queues(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, i
     if (n % refresh == 0) {
       int e = n / refresh;
       if (e >= n_epochs) return -10;
-      rso_cell_set_cqi(c, cqi_epochs + (size_t)e * U * R);
+      if (per_prb) rso_cell_set_cqi_prb(c, cqi_epochs + (size_t)e * U * R * c->rbg_size);
+      else rso_cell_set_cqi(c, cqi_epochs + (size_t)e * U * R);
     }
     int rc = rso_cell_step_queues(c, t, &g, &out);
     if (rc) return rc;

@@ -183,6 +183,9 @@ void rso_cell_set_arrivals(rso_cell* c, int user, int prio, int n, const double*
 int rso_cell_step_queues(rso_cell* c, double now, rso_rng* g, rso_tti_out* out); /* draws 2 values when it allocates */
 int rso_run_synth_queues(rso_cell* c, const uint8_t* cqi_epochs, int n_epochs, int refresh, unsigned seed, int n_ttis,
                          int* log_rbg_to_user, int* log_tbs_bits);
+/* the same run on per-PRB grids ([U][R*G] per epoch) */
+int rso_run_synth_queues_prb(rso_cell* c, const uint8_t* cqi_prb_epochs, int n_epochs, int refresh, unsigned seed, int n_ttis,
+                         int* log_rbg_to_user, int* log_tbs_bits);
 /* per bearer [U][2]: PF average, cumulative bytes / RBs, MAC queue bytes and packets; any pointer may be NULL */
 void rso_cell_get_bearer_state(const rso_cell* c, double* avg, int64_t* cum_bytes, int64_t* cum_rbs, int32_t* queue_bytes,
                                int32_t* queue_packets);

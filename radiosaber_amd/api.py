@@ -88,6 +88,7 @@ ABI_SYMBOLS = [
     "rs_batch_read_clock", "rs_batch_jit_status",
     "rs_batch_upload_cqi_epochs_prb", "rs_batch_set_trace_prb",
     "rs_batch_set_bearers", "rs_batch_set_arrivals", "rs_batch_read_bearer_state", "rs_internet_flow_arrivals",
+    "rs_device_source_hash",
 ]
 
 _lib = None
@@ -153,6 +154,8 @@ def lib():
     L.rs_batch_kernel_name.restype = C.c_char_p
     L.rs_batch_kernel_name.argtypes = [C.c_void_p]
     L.rs_lds_bytes_per_cell.argtypes = [C.c_int] * 5
+    L.rs_device_source_hash.restype = C.c_char_p
+    L.rs_device_source_hash.argtypes = []
     L.rs_hbm_copy_probe.argtypes = [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.rs_trace_read_mapping.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_int32]
     L.rs_trace_read_ue_log.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8),
@@ -189,6 +192,11 @@ def jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCH
 
 def device_count():
     return lib().rs_device_count()
+
+
+def device_source_hash():
+    """Identity of the device code inside the library (FNV-1a of the embedded kernel sources, 16 hex digits)."""
+    return lib().rs_device_source_hash().decode()
 
 
 def get_rbg_size(nb_rbs):

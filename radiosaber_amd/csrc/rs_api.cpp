@@ -523,8 +523,6 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
   L.user_trace = b->d_user_trace;
   L.epochs_prb = b->cqi_mode == RS_CQI_EPOCHS ? b->d_epochs_prb : nullptr; L.grid_stride_prb = b->grid_stride_prb;
   L.trace_prb = b->cqi_mode == RS_CQI_TRACE ? b->d_trace_prb : nullptr;
-  if (b->queues && b->sched == RS_SCHED_NVS && (L.epochs_prb || L.trace_prb))
-    return fail(RS_ERR_INVALID, "sched 7 with queues computes m_requiredRBs from the per-RBG grid: per-PRB sources are not supported there");
   L.log_map = d_map; L.log_quota = d_quota; L.log_target = d_target; L.log_tbs = d_tbs; L.log_uinfo = d_uinfo;
   L.log_keys = d_keys;
   if (b->queues) {
@@ -640,6 +638,9 @@ int rs_batch_synthesize_cqi_at(rs_batch* b, uint64_t seed, const double* w, int3
   b->grid_stride = (int64_t)stride;
   b->n_epochs = n_epochs;
   b->cqi_mode = RS_CQI_EPOCHS;
+  /* the per-PRB twin of an earlier upload belongs to the grids just replaced (other epoch count, other values) */
+  if (b->d_epochs_prb) { HIP_TRY(hipFree(b->d_epochs_prb)); b->d_epochs_prb = nullptr; }
+  b->grid_stride_prb = 0;
   return RS_OK;
 }
 
@@ -798,6 +799,17 @@ int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
     if (!bearer_kind[u * 2] && !bearer_kind[u * 2 + 1]) return fail(RS_ERR_INVALID, "user %zu has no bearer", u);
   }
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  /* validate the queue model's LDS carve and build its kernel BEFORE the batch changes: on failure it stays as it was */
+  {
+    const RsCarve qc = rs_carve(b->S, b->U, b->R, b->sched, b->threads, 1);
+    if (qc.lds_bytes > 160 * 1024) return fail(RS_ERR_INVALID, "cell needs %d B of LDS with the queue model (> 160 KiB)", qc.lds_bytes);
+  }
+  RsJitKernel* qjit = nullptr;
+  char qmsg[sizeof b->jit_msg] = {0};
+  if (b->jit_wanted) { /* the shape-specialised kernel of the queue model is a different code object */
+    qjit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 1, qmsg, sizeof qmsg);
+    if (!qjit && !qmsg[0]) snprintf(qmsg, sizeof qmsg, "hiprtc build of the queue-model kernel failed");
+  }
   const size_t n = (size_t)b->n_cells * 2 * U;
   if (!b->d_bearer_kind) {
     HIP_TRY(hipMalloc(&b->d_bearer_kind, 2 * U));
@@ -814,12 +826,12 @@ int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
   HIP_TRY(hipMemset(b->d_qhol, 0, 8 * (size_t)b->n_cells * U));
   std::vector<double> avg(n, 100000.0); /* radio-bearer.cpp:54 */
   HIP_TRY(hipMemcpy(b->d_bavg, avg.data(), 8 * n, hipMemcpyHostToDevice));
+  /* commit: mode, carve and kernel together (the queue = 0 kernel must never run with queue arguments) */
   b->queues = true;
   carve_lds(b, &b->base); /* schedulers 1 and 7 keep per-bearer scratch in LDS in this mode */
-  if (b->base.lds_bytes > 160 * 1024) return fail(RS_ERR_INVALID, "cell needs %d B of LDS (> 160 KiB)", b->base.lds_bytes);
-  if (b->jit_wanted) { /* the shape-specialised kernel of the queue model is a different code object */
-    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 1, b->jit_msg, sizeof b->jit_msg);
-    if (b->jit) b->jit_msg[0] = 0;
+  if (b->jit_wanted) {
+    b->jit = qjit; /* nullptr: the built-in queue kernels run, rs_batch_jit_status says why */
+    snprintf(b->jit_msg, sizeof b->jit_msg, "%s", qmsg);
   }
   return RS_OK;
 }
@@ -1114,6 +1126,24 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   }
   memset(c->h_in + l.grid + (size_t)n * R, 0, l.slice - (size_t)n * R);
   memcpy(c->h_in + l.avg, in->avg_rate, 8 * (size_t)n);
+  /* The metric scan ranks users with an FP32 product first; its error bound needs every factor to be an
+   * ordinary FP32 number.  The reference takes any double (downlink-transport-scheduler.cpp:677-713: a non-finite, huge, tiny
+   * or negative average simply flows through the division and the strict '>' scan), so inputs outside the safe range switch
+   * this call to the exact FP64 scan of every user instead of being rejected.  (The EWMA keeps real averages in [1, ~1e12].) */
+  bool exact_scan = false;
+  {
+    auto ordinary = [](double x, double lo, double hi) { return x >= lo && x <= hi; }; /* false for NaN */
+    for (int i = 0; i < n; i++) {
+      const double a = in->avg_rate[i];
+      const double k = b->sched == RS_SCHED_PF ? a : (1 + a) / 1000.0;
+      exact_scan |= !ordinary(k, 0x1p-60, 0x1p60);
+    }
+    if (b->any_alpha && in->hol_delay)
+      for (int i = 0; i < n; i++) {
+        const double h = in->hol_delay[i];
+        exact_scan |= !(h == 0 || ordinary(h, 0x1p-40, 0x1p40));
+      }
+  }
   if (b->sched == RS_SCHED_NVS_NONGREEDY) {
     if (!in->rand_draws) return fail(RS_ERR_INVALID, "RS_SCHED_NVS_NONGREEDY needs rand_draws (%d x n_users values)", RS_NVS_SAMPLES);
     const size_t nd = (size_t)RS_NVS_SAMPLES * n;
@@ -1166,6 +1196,7 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   L.prio = dev_in + l.prio;
   L.draws = dev_in + l.draws;
   L.gate = gate ? (const int32_t*)(dev_in + l.gate) : nullptr;
+  L.exact_scan = exact_scan ? 1 : 0;
   if (b->sched == RS_SCHED_PF) { L.n_seg = (n + RS_PF_SEG - 1) / RS_PF_SEG; L.n_items = R * L.n_seg; }
   L.log_tbs = (int32_t*)(dev_out + l.tbs);
   L.log_uinfo = (int32_t*)(dev_out + l.uinfo);

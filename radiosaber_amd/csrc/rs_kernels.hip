@@ -535,11 +535,20 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       return rounds == 0 ? n : rounds * nsp_;
 #endif
     };
+    /* averageRate /= 1000.0 (ref: :685-689).  The three-instruction form needs an ordinary operand (no underflow, finite); the
+     * drop-in entry point takes any double from its caller, and when one is out of range (p.exact_scan, set by the host) it
+     * divides for real -- inf / 1000 is inf, the short form would give NaN. */
+    auto div_1000 = [&](double k) -> double {
+      if constexpr (DIRECT) {
+        if (p.exact_scan) return k / 1000.0;
+      }
+      return rs_div_1000(k);
+    };
     /* PF terms of a user whose average is `a`: exact denominator and stage-1 reciprocal (ref: :685-689) */
     auto pf_terms = [&](int u, double a) {
       double k = 1;
       k += a;
-      k = rs_div_1000(k);
+      k = div_1000(k);
       s_avgk[u] = k;
       const int uo = s_uoff[u];
       /* stage-1 ranking only, never part of a result; psi == 0 slices rank on the numerator */
@@ -670,7 +679,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             /* ref: :685-689  averageRate = 1 + sum(avg); averageRate /= 1000.0 */
             double k = 1;
             k += a;
-            k = rs_div_1000(k);
+            k = div_1000(k);
             s_avgk[u] = k;
             const int uo = s_uoff[u];
             float r32 = (uo & 1) ? __builtin_amdgcn_rcpf((float)k) : 1.0f;
@@ -1033,13 +1042,22 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           if (sl_custom == 2) return hol_in[u] * num / den; /* HoL * pow(se) / pow(avg), left to right */
           return num / den;
         };
-#ifdef RS_EXP_P3_SKIP
-        bu = ub; best = 1.0; exact = true; /* timing experiment only: wrong results */
-        for (int blk = ue; blk < ue; blk += kP3Block) {
-#else
+        if constexpr (DIRECT) {
+          /* The caller's averages / head-of-line delays are arbitrary doubles (the batch EWMA keeps its own in [1, ~1e12]): when
+           * one of them is not an ordinary FP32 number -- huge, tiny, negative, infinite, NaN -- the stage-1 error bound does not
+           * hold, the host says so (rs_schedule_tti), and every user of the segment is compared with the reference's expression
+           * itself, ascending, strict '>' (a NaN metric never wins, as in the reference's scan). */
+          if (p.exact_scan) {
+            for (int u = ub; u < ue; ++u) {
+              const double metric = exact_metric(u, rowp[u]);
+              if (metric > best) { best = metric; bu = u; }
+            }
+            exact = true;
+            ub = ue; /* nothing left for the block loop */
+          }
+        }
         /* (an empty segment must not enter: its 8-aligned start lies before its end, inside a neighbour's window) */
         for (int blk = ue > ub ? (ub & ~7) : ue; blk < ue; blk += kP3Block) {
-#endif
           /* a~ of the 32 users blk..blk+31 (0 for users outside [ub, ue) and for the padding) */
           float av[kP3Block];
           float best_a = 0.0f;
@@ -1154,9 +1172,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         int need = 0;
         if (prio_in[u] & 2) {
           double sum = 0;
-          for (int r = 0; r < R; ++r) {
-            const double ev = s_e[s_cqi[r * Upad + u]];
-            for (int k = 0; k < G; ++k) sum += ev;
+          if (per_prb) { /* per-PRB reports: every PRB of the band as the user reported it */
+            for (int r = 0; r < R; ++r) {
+              const uint8_t* pr = prb_ptr(u, r);
+              for (int k = 0; k < G; ++k) sum += s_e[pr[k]];
+            }
+          } else {
+            for (int r = 0; r < R; ++r) {
+              const double ev = s_e[s_cqi[r * Upad + u]];
+              for (int k = 0; k < G; ++k) sum += ev;
+            }
           }
           const double x = sum / (double)(R * G);
           int wide = 15;
@@ -1198,12 +1223,6 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     RS_STAMP(2);
 
     /* ---------------- P4: inter-slice assignment ---------------- */
-#ifdef RS_EXP_NO_SORT
-    if (SCHED == 9) { /* counter experiment only (tools/pmc_insts.sh): wrong results */
-      for (int i = tid; i < R * S; i += nt) s_sorted[i] = s_elems[i];
-      __syncthreads();
-    } else
-#endif
     if (SCHED == 9) {
       const int N = R * S;
       /* std::sort emulation (:361): introsort loop, then the final insertion sort */
@@ -1453,8 +1472,13 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
                 while (mm) {
                   const int r2 = __ffsll((long long)mm) - 1;
                   mm &= mm - 1;
-                  const double ev = s_e[s_cqi[r2 * Upad + u]];
-                  for (int k = 0; k < G; ++k) sum += ev;
+                  if (per_prb) { /* the flow's per-PRB feedback (ref: downlink-packet-scheduler.cpp:245-264) */
+                    const uint8_t* pr = prb_ptr(u, r2);
+                    for (int k = 0; k < G; ++k) sum += s_e[pr[k]];
+                  } else {
+                    const double ev = s_e[s_cqi[r2 * Upad + u]];
+                    for (int k = 0; k < G; ++k) sum += ev;
+                  }
                   nprb += G;
                 }
                 const double x = sum / (double)nprb;

@@ -1,0 +1,228 @@
+"""Round 3: bench.py starting its own ranks, the headline's guards against build switches, arbitrary doubles at the
+drop-in entry point, and the CQI-source bookkeeping the advisor flagged."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import synth_cqi
+
+ROOT = Path(__file__).resolve().parents[1]
+HIST = [152600, 56656, 270880, 2088792, 3509504, 1595568, 4145392, 5295816, 1903424, 6890232, 4770864, 2842552, 3579624, 96000, 1227696]
+
+
+def _bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.pop("RS_JIT_EXTRA", None)
+    env.pop("RS_JIT", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+# ---------------------------------------------------------------- CPU side: argument handling of bench.py
+
+def test_bench_refuses_build_switches_in_the_environment():
+    """an inflated headline must not be one `export` away."""
+    r = _bench(["--steps", "1"], {"RS_JIT_EXTRA": "-DRS_NO_SPEC"})
+    assert r.returncode != 0 and "RS_JIT_EXTRA" in r.stderr and r.stdout.strip() == ""
+    r = _bench(["--steps", "1"], {"RS_JIT": "0"})
+    assert r.returncode != 0 and "RS_JIT" in r.stderr
+
+
+def test_product_kernel_source_has_no_wrong_result_switches():
+    src = (ROOT / "radiosaber_amd" / "csrc" / "rs_kernels.hip").read_text()
+    assert "RS_EXP_" not in src
+    jit = (ROOT / "radiosaber_amd" / "csrc" / "rs_jit.cpp").read_text()
+    assert "%.60s" not in jit  # the whole RS_JIT_EXTRA string is part of the cache key
+
+
+def test_device_source_hash_is_stable_and_hex(rs):
+    h = rs.device_source_hash()
+    assert len(h) == 16 and int(h, 16) >= 0 and h == rs.device_source_hash()
+
+
+# ---------------------------------------------------------------- GPU side
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: two ranks (gloo here: the box has one GPU), rc 0, exactly one JSON
+    line, n_gpus 2, and the line says which backend reduced and how many ranks it saw."""
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--cells", "16", "--ttis", "200", "--no-cpu-baseline", "--no-r64"],
+               {"RS_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["ranks_in_group"] == 2 and d["steps"] == 2
+    assert d["value"] > 0 and d["total_slice_bytes"] > 0 and d["jit_extra"] == "" and d["source_hash"]
+    # both shards contributed: twice the cells of the N = 1 run of the same command
+    r1 = _bench(["--steps", "2", "--warmup", "1", "--cells", "16", "--ttis", "200", "--no-cpu-baseline", "--no-r64"])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert d1["n_gpus"] == 1 and d1["backend"] is None and d1["ranks_in_group"] == 1
+    assert d["total_slice_bytes"] > 1.5 * d1["total_slice_bytes"]
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    import radiosaber_amd
+    if radiosaber_amd.device_count() >= 2:
+        pytest.skip("box has several GPUs")
+    r = _bench(["--gpus", "2", "--steps", "1", "--cells", "8", "--ttis", "40", "--no-cpu-baseline", "--no-r64"])
+    assert r.returncode != 0 and "one GPU per rank" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_bench_variant_runs_only_when_allowed():
+    r = _bench(["--steps", "1", "--warmup", "0", "--cells", "8", "--ttis", "80", "--no-cpu-baseline", "--no-r64", "--allow-variant"],
+               {"RS_JIT_EXTRA": "-DRS_NO_SPEC"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["jit_extra"] == "-DRS_NO_SPEC"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched", [9, 8, 1, 103, 101, 10])
+def test_drop_in_accepts_any_double(rs, oracle, sched):
+    """The reference's metric takes whatever double the bearer holds (downlink-transport-scheduler.cpp:677-713): averages of 1,
+    1e12, 1e300, infinity, sub-unit and negative values, head-of-line delays of 1e-5, 0 and 1e6 -- outside the FP32 ranking's
+    safe range the device compares every user exactly."""
+    ues = [6, 5, 7, 4, 8, 6]
+    custom = sched in (9, 8)
+    alpha = [0, 1, 1, 1, 1, 0] if custom else [0] * 6
+    beta = [0, 0, 1, 1, 1, 0] if custom else [0] * 6
+    eps = [1, 1, 1, 1, 0, 1]
+    psi = [1, 1, 1, 0, 1, 0]
+    S, R, G = len(ues), 25, 4
+    w = [1.0 / S] * S
+    sc = rs.SliceConfig(ues, weight=w, algo_alpha=alpha, algo_beta=beta, algo_epsilon=eps, algo_psi=psi)
+    U = sc.n_users
+    ts = rs.TtiScheduler(sc, R, G, sched=sched)
+    cell = oracle.Cell(ues, R, G, sched, weights=w, epsilon=eps, psi=psi, alpha=alpha, beta=beta)
+    rng = np.random.default_rng(5)
+    pools = [np.array([1.0, 1e12, 1e300]), np.array([1.0, 3.4e41, 1e38, 1e300]), np.array([1e300]), np.array([np.inf, 1e5]),
+             np.array([0.25, 1.0, 1e-300]), np.array([-0.5, -1.0, -3.0, 2.0]), np.array([1.0, 98000.0, 1e12])]
+    hols = [np.array([1e-5, 0.0, 1e6]), np.array([1e-300, 1e300, 1.0]), np.array([0.0])]
+    for it in range(3 * len(pools)):
+        cqi = synth_cqi(900 + it, (U, R), HIST)
+        avg = rng.choice(pools[it % len(pools)], U)
+        hol = rng.choice(hols[it % len(hols)], U)
+        prio = (rng.random(U) < 0.8).astype(np.uint8)
+        r0, r1 = int(rng.integers(0, 2**31 - 1)), int(rng.integers(0, 2**31 - 1))
+        cell.set_cqi(cqi)
+        if custom:
+            cell.set_queue_state(hol, prio)
+        out = cell.new_out()
+        assert cell.allocate(avg, r0, r1, out) == 0
+        kw = dict(hol_delay=hol, prio_has_data=prio) if custom else {}
+        res = ts.schedule_tti(cqi, avg, r0, r1, **kw)
+        np.testing.assert_array_equal(res.rbg_to_user, out.rbg_to_user, err_msg=f"it {it}")
+        np.testing.assert_array_equal(res.quota_rbgs, out.quota_rbgs)
+        np.testing.assert_array_equal(res.user_nprb, out.user_nprb)
+        np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits)
+    ts.close()
+
+
+@pytest.mark.gpu
+def test_drop_in_nvs_accepts_any_double(rs):
+    """sched 7 (one slice per call): first maximum of the slice metric from lowest(), whatever the doubles are."""
+    ues, R, G = [8] * 4, 25, 4
+    sc = rs.SliceConfig(ues, weight=[0.25] * 4)
+    ts = rs.TtiScheduler(sc, R, G, sched=7)
+    kb = rs.link_tables()["kbps"]
+    rng = np.random.default_rng(8)
+    for it in range(8):
+        sl = it % 4
+        ids = np.arange(sl * 8, sl * 8 + 8)
+        cqi = synth_cqi(40 + it, (8, R), HIST)
+        avg = rng.choice(np.array([1.0, 1e12, 1e300, 5e40]), 8)
+        res = ts.schedule_tti(cqi, avg, user_id=ids)
+        met = kb[cqi] / ((1 + avg) / 1000.0)[:, None]
+        np.testing.assert_array_equal(res.rbg_to_user, ids[np.argmax(met, axis=0)], err_msg=f"it {it}")
+    ts.close()
+
+
+@pytest.mark.gpu
+def test_synthesize_after_per_prb_upload_drops_the_stale_twin(rs):
+    """upload_cqi_epochs_prb(A epochs) then synthesize_cqi(B > A epochs) left the per-PRB twin of the OLD grids in
+    place -- link adaptation read stale CQIs (and past the allocation).  The batch must behave like a fresh one."""
+    ues, R, G, n_cells = [4] * 5, 12, 2, 3
+    sc = rs.SliceConfig(ues, weight=[0.2] * 5)
+    U = sc.n_users
+    seeds = np.arange(n_cells, dtype=np.uint32) + 3
+
+    def run(pre_upload):
+        b = rs.BatchScheduler(sc, R, G, n_cells, sched=9)
+        b.seed(seeds)
+        if pre_upload:
+            prb = np.full((n_cells, 1, U, R * G), 3, np.uint8)
+            prb[..., 1::2] = 15  # differs inside every RBG: a stale twin would change every final CQI
+            b.upload_cqi_epochs_prb(prb)
+        b.synthesize_cqi(77, 4)
+        got = b.run_logged(160)
+        st = b.state()
+        b.close()
+        return got, st
+
+    g0, s0 = run(False)
+    g1, s1 = run(True)
+    np.testing.assert_array_equal(g0["rbg_to_user"], g1["rbg_to_user"])
+    np.testing.assert_array_equal(g0["tbs_bits"], g1["tbs_bits"])
+    np.testing.assert_array_equal(s0["cum_bytes"], s1["cum_bytes"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched", [1, 7, 9])
+@pytest.mark.parametrize("jit", [False, True])
+def test_queue_model_on_per_prb_sources(rs, oracle, sched, jit):
+    """with finite queues the gates of schedulers 1 and 7 (the satisfied-flow break: the transport block of the
+    flow's PRBs so far, downlink-packet-scheduler.cpp:245-264; m_requiredRBs: the wideband CQI over every PRB of the band,
+    packet-scheduler.cpp:319-334) must read the per-PRB reports when the batch has them, like the final link adaptation."""
+    from test_gpu_queues import _random_bursts
+    ues, R, G, n_cells, n_ttis = [4, 5, 3, 6], 25, 4, 2, 120
+    kinds_of = ["B-", "Q-", "QQ", "Q-"]
+    alpha = [0, 1, 1, 0] if sched != 1 else [0] * 4
+    beta = [0, 0, 1, 0] if sched != 1 else [0] * 4
+    sc = rs.SliceConfig(ues, algo_alpha=alpha, algo_beta=beta)
+    U, u2s = sc.n_users, sc.user_to_slice
+    code = {"B": rs.BEARER_BACKLOG, "Q": rs.BEARER_QUEUE, "-": rs.BEARER_NONE}
+    kinds = np.array([[code[kinds_of[u2s[u]][0]], code[kinds_of[u2s[u]][1]]] for u in range(U)], np.uint8)
+    rng = np.random.default_rng(61 + sched)
+    bursts = {(c, u, k): _random_bursts(rng, n_ttis, 8, 1500) for c in range(n_cells) for u in range(U) for k in range(2)
+              if kinds[u, k] == rs.BEARER_QUEUE}
+    base = synth_cqi(70 + sched, (n_cells, (n_ttis + 39) // 40, U, R), HIST).astype(np.int16)
+    prb = np.clip(np.repeat(base, G, axis=3) + rng.integers(-3, 4, base.shape[:3] + (R * G,)), 1, 15).astype(np.uint8)
+    seeds = np.array([9, 10], np.uint32)
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=jit)
+    b.set_bearers(kinds)
+    b.set_arrivals(bursts)
+    b.seed(seeds)
+    b.upload_cqi_epochs_prb(prb)
+    got = b.run_logged(n_ttis)
+    bst = b.bearer_state()
+    b.close()
+    differs = 0
+    for c in range(n_cells):
+        cell = oracle.Cell(ues, R, G, sched, alpha=alpha, beta=beta)
+        cell.enable_queues(kinds)
+        for (cc, u, k), (t, nf, la) in bursts.items():
+            if cc == c:
+                cell.set_arrivals(u, k, t, nf, la)
+        logs = cell.run_synth_queues(prb[c], int(seeds[c]), n_ttis, per_prb=True)
+        ob = cell.bearer_state()
+        np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"], err_msg=f"cell {c} RBG map")
+        np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"], err_msg=f"cell {c} TBS")
+        for key in ("cum_bytes", "cum_rbs", "queue_bytes", "queue_packets"):
+            np.testing.assert_array_equal(bst[key][c], ob[key], err_msg=f"cell {c} {key}")
+        # the per-PRB reports matter: the same run on each RBG's first PRB alone ends elsewhere
+        cell2 = oracle.Cell(ues, R, G, sched, alpha=alpha, beta=beta)
+        cell2.enable_queues(kinds)
+        for (cc, u, k), (t, nf, la) in bursts.items():
+            if cc == c:
+                cell2.set_arrivals(u, k, t, nf, la)
+        logs2 = cell2.run_synth_queues(prb[c][..., ::G], int(seeds[c]), n_ttis)
+        differs += int((logs2["tbs_bits"] != logs["tbs_bits"]).any())
+    assert differs > 0, "per-PRB and per-RBG runs agree everywhere: the test does not exercise the per-PRB reads"

@@ -30,7 +30,8 @@ key = f"sched{cfg['sched']}_S{cfg['slices']}_U{cfg['ues']}_R{cfg['rbgs']}_cells{
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 ent = {"valu": per["SQ_INSTS_VALU"], "salu": per["SQ_INSTS_SALU"], "lds": per["SQ_INSTS_LDS"],
        "active_inst_any_over_wave_cycles": per["SQ_ACTIVE_INST_ANY"] / per["SQ_WAVE_CYCLES"],
-       "us_per_tti_per_cell_under_pmc": d["us_per_tti_per_cell"], "kernel": d["kernel"], "commit": commit, "tag": tag}
+       "us_per_tti_per_cell_under_pmc": d["us_per_tti_per_cell"], "kernel": d["kernel"], "commit": commit, "tag": tag,
+       "source_hash": d.get("source_hash")}  # device sources of the library that was profiled (bench.py flags a mismatch as stale)
 if "--phase-shares" in sys.argv:
     ent["phase_shares"] = json.loads(sys.argv[sys.argv.index("--phase-shares") + 1])
 out = ROOT / "profiles" / "inst_counts.json"

@@ -58,6 +58,7 @@ traffic = {"kernel": cell["Name"], "launches_profiled": len(fetch),
            "hbm_read_bytes_per_launch": fetch_b, "hbm_write_bytes_per_launch": write_b,
            "hbm_bytes_per_launch": fetch_b + write_b, "ttis_per_launch": cfg["ttis_per_step"],
            "hbm_bytes_per_cell_tti": (fetch_b + write_b) / cell_ttis, "commit": commit, "round": tag,
+           "source_hash": bench_line.get("source_hash"),  # device sources of the profiled library (bench.py flags a mismatch as stale)
            "kernel_trace_avg_ns": float(cell["AverageNs"]), "kernel_trace_calls": int(cell["Calls"]),
            "note": "FETCH_SIZE doubled per the gfx950 correction; cumulative byte / RB counters ride in registers and "
                    "are flushed once per launch (round 1: two 8-byte atomics per served UE per TTI)"}
