@@ -241,8 +241,10 @@ def main():
         raise SystemExit(f"bench.py: RS_JIT_EXTRA={jit_extra!r} RS_JIT={jit_env!r} is set: the kernel would not be the product "
                          "build; unset it, or pass --allow-variant for a tuning experiment (recorded as jit_extra in the line)")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    # a launcher (torch.distributed.run) exports WORLD_SIZE, RANK and LOCAL_RANK together; a stray WORLD_SIZE alone is not one
+    under_launcher = all(k in os.environ for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    world = int(os.environ["WORLD_SIZE"]) if under_launcher else 1
+    if not under_launcher and args.gpus > 1:
         # no launcher around us: start the ranks ourselves, BEFORE anything in this process touches HIP (or imports torch)
         raise SystemExit(_launch_own_ranks(args.gpus))
 

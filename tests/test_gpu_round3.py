@@ -17,8 +17,8 @@ HIST = [152600, 56656, 270880, 2088792, 3509504, 1595568, 4145392, 5295816, 1903
 
 def _bench(args, env_extra=None, timeout=900):
     env = dict(os.environ)
-    env.pop("RS_JIT_EXTRA", None)
-    env.pop("RS_JIT", None)
+    for k in ("RS_JIT_EXTRA", "RS_JIT", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RS_BENCH_BACKEND"):
+        env.pop(k, None)  # (an earlier test of the session may have left a one-rank rendezvous in os.environ)
     env.update(env_extra or {})
     return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
 
