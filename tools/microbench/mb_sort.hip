@@ -1,7 +1,7 @@
 // Diagnostic micro-benchmark (not part of the product): the std::sort emulation of rs_sort_device.h alone on MaximizeCell-shaped
 // key arrays (tools/sort_study.py dumps them from the CPU oracle): the workgroup-level introsort loop against the task-per-wave
 // form, results compared element by element, cycles per sort printed.  One or two workgroups per CU.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -DMB_N=500 -I../../radiosaber_amd/csrc -I../../include -o mb_sort mb_sort.hip
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -DRS_TASK_STAMPS -DMB_N=500 -I. -I../../radiosaber_amd/csrc -I../../include -o mb_sort mb_sort.hip
 //   ./mb_sort keys_r25.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -9,7 +9,7 @@
 #include <cstdint>
 #include <vector>
 #include <algorithm>
-#include "rs_sort_device.h"
+#include "rs_sort_tasks.h"
 
 #ifndef MB_N
 #define MB_N 500
@@ -41,8 +41,7 @@ __global__ void __launch_bounds__(MB_NT) bench(const uint32_t* recs, int n_prob_
       unsigned long long t0 = __builtin_readcyclecounter();
       __builtin_amdgcn_s_setprio(1);
       if (V == 0) introsort_levels_reg<kEpt>(s_elems, MB_N, s_sorted, s_cuts, &misc, nullptr);
-      else if (V == 1) introsort_tasks<8, kEpt>(s_elems, MB_N, s_sorted, s_cuts, &misc, 0, sub);
-      else introsort_levels_reg<kEpt, (V >= 2 ? V : 1)>(s_elems, MB_N, s_sorted, s_cuts, &misc, sub);
+      else introsort_tasks<8, kEpt>(s_elems, MB_N, s_sorted, s_cuts, &misc, 0, sub);
       unsigned long long t1 = __builtin_readcyclecounter();
       if (r == 0 && blockIdx.x == 0)
         for (int i = tid; i < MB_N; i += MB_NT) out_loop[(size_t)p * MB_N + i] = s_elems[i];
@@ -80,21 +79,14 @@ int main(int argc, char** argv) {
   (void)hipMalloc(&d_cyc, 8192 * 8);
   (void)hipMemcpy(d_recs, recs.data(), recs.size() * 4, hipMemcpyHostToDevice);
   const int reps = 20;
-  const char* names[] = {"workgroup levels", "task per wave", "hybrid, K <= 2", "hybrid, K <= 3", "hybrid, K <= 4", "hybrid, K <= 5", "hybrid, K <= 6"};
+  const char* names[] = {"workgroup levels", "task per wave"};
   for (int blocks : {256, 512, 1024})
-    for (int v = 0; v < 7; ++v) {
+    for (int v = 0; v < 2; ++v) {
       (void)hipMemset(d_sorted, 0, recs.size() * 4);
       for (int it = 0; it < 2; ++it) {
 #define MB_LAUNCH(V_) hipLaunchKernelGGL(bench<V_>, dim3(blocks), dim3(MB_NT), 0, 0, d_recs, n_prob, d_loop, d_sorted, d_cyc, reps)
-        switch (v) {
-          case 0: MB_LAUNCH(0); break;
-          case 1: MB_LAUNCH(1); break;
-          case 2: MB_LAUNCH(2); break;
-          case 3: MB_LAUNCH(3); break;
-          case 4: MB_LAUNCH(4); break;
-          case 5: MB_LAUNCH(5); break;
-          default: MB_LAUNCH(6); break;
-        }
+        if (v == 0) MB_LAUNCH(0);
+        else MB_LAUNCH(1);
         if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "kernel failed\n"); return 3; }
       }
       std::vector<unsigned long long> c(blocks * 2);
