@@ -226,3 +226,52 @@ def test_queue_model_on_per_prb_sources(rs, oracle, sched, jit):
         logs2 = cell2.run_synth_queues(prb[c][..., ::G], int(seeds[c]), n_ttis)
         differs += int((logs2["tbs_bits"] != logs["tbs_bits"]).any())
     assert differs > 0, "per-PRB and per-RBG runs agree everywhere: the test does not exercise the per-PRB reads"
+
+
+# ---------------------------------------------------------------- the C++ multi-GPU host (RCCL called directly)
+
+def _build_multi_gpu():
+    r = subprocess.run([str(ROOT / "tools" / "build_multi_gpu.sh")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exe = ROOT / "tools" / "rs_multi_gpu"
+    assert exe.exists()
+    return exe
+
+
+def test_cpp_multi_gpu_host_builds_and_fails_loudly_without_a_gpu(rs):
+    """tools/rs_multi_gpu.cpp (one process, one rs_batch per GPU, ncclAllReduce over ncclCommInitAll) compiles and links against
+    the C ABI library and RCCL; without a HIP device it must refuse, not fall back."""
+    exe = _build_multi_gpu()
+    if rs.device_count() > 0:
+        pytest.skip("a GPU is visible: the run itself is the gpu test")
+    r = subprocess.run([str(exe), "--gpus", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_multi_gpu_host_reduces_with_rccl_and_matches_the_python_path(rs):
+    """The C++ host on every visible GPU: the RCCL all-reduce of the device-resident per-slice vectors equals the host-side sums
+    (--check), and on one GPU the per-slice bytes equal those of the Python path bench.py uses (same sharding rule: seeds and CQI
+    grids keyed on the global cell id)."""
+    from radiosaber_amd import sharding
+    exe = _build_multi_gpu()
+    cells, ttis, launches = 8, 200, 2
+    r = subprocess.run([str(exe), "--gpus", "1", "--cells", str(cells), "--ttis", str(ttis), "--launches", str(launches), "--check"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["check"] == "ok" and d["n_gpus"] == 1 and d["rccl_version"] > 0
+    sc = rs.SliceConfig([25] * 20, weight=[0.05] * 20)
+    b = rs.BatchScheduler(sc, 25, 4, cells, sched=rs.RS_SCHED_MAXCELL, jit=True)
+    b.seed(sharding.seeds_for_cells(sharding.cell_ids_for_rank(0, 1, cells)))
+    b.synthesize_cqi(0x5AB3, (launches * ttis + 40 + 39) // 40, first_cell=0)
+    b.run(40)
+    for _ in range(launches):
+        b.run(ttis)
+    want = b.slice_bytes().astype(np.uint64)
+    b.close()
+    np.testing.assert_array_equal(np.array(d["slice_bytes"], np.uint64), want)
+    # every visible GPU (the driver's 8-GPU node; one here)
+    r = subprocess.run([str(exe), "--cells", "4", "--ttis", "120", "--launches", "1", "--check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == rs.device_count()
