@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 7 /* 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
+#define RS_ABI_VERSION 8 /* 8: rs_jit_selfcheck_queue; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
                             6: rs_tti_in.required_rbs / data_to_transmit (the gates of schedulers 7 and 1 in the drop-in mode);
                             5: per-PRB batch sources (rs_batch_upload_cqi_epochs_prb, rs_batch_set_trace_prb);
                             4: finite queues in batches (rs_batch_set_bearers, rs_batch_set_arrivals, rs_batch_read_bearer_state, rs_internet_flow_arrivals);
@@ -347,6 +347,9 @@ int rs_batch_slice_bytes(rs_batch* b, uint64_t* h_out /* [S] */);
  * code object size or a negative value with the compiler log in err */
 int rs_jit_selfcheck(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, char* err,
                      size_t errlen);
+/* the same for the queue-model kernel (the code object rs_batch_set_bearers switches a batch to; schedulers 1, 7, 8, 9, 101, 103) */
+int rs_jit_selfcheck_queue(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, char* err,
+                           size_t errlen);
 /* 16 hex digits: FNV-1a hash of the device sources this library was built from (and compiles at run time); measurement
  * records under profiles/ carry it so that a record taken on other kernel code can be told apart (bench.py: "stale") */
 const char* rs_device_source_hash(void);

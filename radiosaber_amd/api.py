@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "rs_batch_synthesize_cqi", "rs_batch_download_cqi_epochs", "rs_batch_set_trace",
     "rs_batch_run", "rs_batch_run_async", "rs_batch_sync", "rs_batch_run_logged",
     "rs_batch_run_timed", "rs_batch_read_state", "rs_batch_slice_bytes_device",
-    "rs_batch_slice_bytes", "rs_jit_selfcheck", "rs_batch_debug_stamps", "rs_batch_ttis_done", "rs_batch_stream", "rs_batch_kernel_name",
+    "rs_batch_slice_bytes", "rs_jit_selfcheck", "rs_jit_selfcheck_queue", "rs_batch_debug_stamps", "rs_batch_ttis_done", "rs_batch_stream", "rs_batch_kernel_name",
     "rs_trace_read_mapping", "rs_trace_read_ue_log", "rs_trace_load_dir", "rs_hbm_copy_probe", "rs_lds_bytes_per_cell",
     "rs_get_rbg_size", "rs_dl_prbs_for_bandwidth", "rs_batch_synthesize_cqi_at", "rs_batch_run_logged_ex",
     "rs_batch_read_clock", "rs_batch_jit_status",
@@ -146,6 +146,7 @@ def lib():
     L.rs_batch_slice_bytes_device.argtypes = [C.c_void_p, C.c_void_p]
     L.rs_batch_slice_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.rs_jit_selfcheck.argtypes = [C.c_int] * 6 + [C.c_char_p, C.c_size_t]
+    L.rs_jit_selfcheck_queue.argtypes = [C.c_int] * 6 + [C.c_char_p, C.c_size_t]
     L.rs_batch_debug_stamps.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]
     L.rs_batch_ttis_done.restype = C.c_int64
     L.rs_batch_ttis_done.argtypes = [C.c_void_p]
@@ -181,10 +182,12 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-def jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCHED_MAXCELL):
-    """Compile the shape-specialised kernel for one shape (hiprtc, no GPU needed); returns the code size."""
+def jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCHED_MAXCELL, queues=False):
+    """Compile the shape-specialised kernel for one shape (hiprtc, no GPU needed); returns the code size.  queues=True: the
+    queue-model kernel of the shape."""
     buf = C.create_string_buffer(4096)
-    n = lib().rs_jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads, sched, buf, 4096)
+    fn = lib().rs_jit_selfcheck_queue if queues else lib().rs_jit_selfcheck
+    n = fn(n_slices, n_users, n_rbgs, rbg_size, threads, sched, buf, 4096)
     if n < 0:
         raise RadioSaberError(n, buf.value.decode(errors="replace"))
     return n

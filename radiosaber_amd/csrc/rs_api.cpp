@@ -292,13 +292,15 @@ int upad_of(int U) { return rs_upad_of(U); }
 void carve_lds(rs_batch* b, RsLaunch* L) {
   /* (drop-in contexts of schedulers 1 and 7 carry the gate scratch too: rs_tti_in.required_rbs / data_to_transmit) */
   const bool gate_scratch = b->direct && (b->sched == RS_SCHED_PF || b->sched == RS_SCHED_NVS);
-  const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads, (b->queues || gate_scratch) ? 1 : 0);
+  const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads, b->queues ? 2 : (gate_scratch ? 1 : 0));
   L->Upad = c.Upad;
   L->nvs_seg = c.nvs_seg;
   L->off_avgk = c.off_avgk; L->off_rcp = c.off_rcp; L->off_tab = c.off_tab; L->off_slice = c.off_slice;
   L->off_tx = c.off_tx; L->off_misc = c.off_misc; L->off_tbs = c.off_tbs; L->off_elems = c.off_elems;
   L->off_sorted = c.off_sorted; L->off_items = c.off_items; L->off_sortx = c.off_sortx; L->off_cqi = c.off_cqi;
   L->off_queue = c.off_queue;
+  L->off_qstate = c.off_qstate;
+  L->q_lds = c.q_lds;
   L->lds_bytes = c.lds_bytes;
   L->n_seg = c.n_seg;
   L->n_items = c.n_items;
@@ -801,7 +803,7 @@ int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   /* validate the queue model's LDS carve and build its kernel BEFORE the batch changes: on failure it stays as it was */
   {
-    const RsCarve qc = rs_carve(b->S, b->U, b->R, b->sched, b->threads, 1);
+    const RsCarve qc = rs_carve(b->S, b->U, b->R, b->sched, b->threads, 2);
     if (qc.lds_bytes > 160 * 1024) return fail(RS_ERR_INVALID, "cell needs %d B of LDS with the queue model (> 160 KiB)", qc.lds_bytes);
   }
   RsJitKernel* qjit = nullptr;

@@ -67,7 +67,7 @@ struct RsMisc {
 struct RsCarve {
   int Upad, n_seg, n_items, ept, nvs_seg;
   int off_avgk, off_rcp, off_tab, off_slice, off_tx, off_misc, off_tbs, off_elems, off_sorted, off_items,
-      off_sortx, off_cqi, off_queue, lds_bytes;
+      off_sortx, off_cqi, off_queue, off_qstate, q_lds, lds_bytes;
 };
 constexpr int rs_round_up(int x, int a) { return (x + a - 1) / a * a; }
 constexpr int rs_upad_of(int U) {
@@ -90,9 +90,17 @@ constexpr int rs_nvs_scratch_bytes(int U, int R) {
  * (user u16 + metric f64 per RBG) are reduced per RBG in ascending order afterwards.  With slices of more than 32 users on
  * average rs_carve picks the smallest run length in {8, 16, 32} that keeps the cell at or under 80 KB of LDS (two cells per
  * CU); otherwise nvs_seg = 0: one work item per RBG scans the whole slice (measured on 25-user slices: runs cost 8-10 %). */
-/* queue = 1: the batch runs the queue model (finite MAC queues, two bearers per user); schedulers 1 and 7 then allocate RBG by
- * RBG on one wave (the per-flow "satisfied" break / the m_requiredRBs gate) and keep per-bearer scratch in LDS:
- * grant1 i32[U] | data0 i32[U] | data1 i32[U] | need i32[U] | flags u8[2U] */
+/* queue != 0: schedulers 1 and 7 allocate RBG by RBG on one wave (the per-flow "satisfied" break / the m_requiredRBs gate) and
+ * keep per-bearer scratch in LDS: grant1 i32[U] | data0 i32[U] | data1 i32[U] | need i32[U] | flags u8[2U]  (queue = 1: only
+ * that -- the drop-in contexts' gate scratch).
+ * queue = 2: the batch runs the queue model (finite MAC queues, two bearers per user) and, when the cell still fits the CU's
+ * 160 KB, keeps the bearers' hot words in LDS for the whole launch instead of reading and writing them in HBM every TTI
+ * (RS_QSTATE_BYTES_PER_USER per user at off_qstate, q_lds = 1; round 3, profiles/r03_queue_mode.md):
+ *   avg f64[2][U] | next arrival time f64[2][U] | head burst time f64[2][U] | HoL delay f64[U] |
+ *   head, tail, pk, frag, bytes, pkts, tx i32[7][2][U] | first burst i64[2][U] | bursts, head burst's n_full / last i32[3][2][U] |
+ *   bearer kind u8[U][2] | user flags u8[U] | user slice u8[U] */
+#define RS_QSTATE_BYTES_PER_USER 156
+#define RS_LDS_LIMIT (160 * 1024)
 constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int nvs_seg, int queue = 0) {
   RsCarve c{};
   c.Upad = rs_upad_of(U);
@@ -123,6 +131,9 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
                                                            : (sched == 11 ? rs_round_up(rs_nvs_scratch_bytes(U, R), 16) : (sched == 101 ? RS_UMAP_SCRATCH_BYTES : 0));
   c.off_cqi = off; off += rs_round_up(c.Upad * R, 16);
   c.off_queue = off; off += (queue && (sched == 1 || sched == 7)) ? rs_round_up(18 * U, 16) : 0;
+  c.off_qstate = off;
+  c.q_lds = (queue == 2 && off + rs_round_up(RS_QSTATE_BYTES_PER_USER * U, 16) <= RS_LDS_LIMIT) ? 1 : 0;
+  off += c.q_lds ? rs_round_up(RS_QSTATE_BYTES_PER_USER * U, 16) : 0;
   c.lds_bytes = off;
   return c;
 }
@@ -237,7 +248,7 @@ struct RsLaunch {
   unsigned long long* stamps; /* diagnostic build (-DRS_STAMPS): [cells][20] phase cycles, else unused */
   /* LDS carve (byte offsets from the dynamic LDS base) */
   int32_t off_avgk, off_rcp, off_tx, off_tab, off_slice, off_items, off_elems,
-      off_sorted, off_sortx, off_misc, off_tbs, off_cqi, off_queue, lds_bytes;
+      off_sorted, off_sortx, off_misc, off_tbs, off_cqi, off_queue, off_qstate, q_lds, lds_bytes;
   int32_t n_seg, n_items;    /* segments per RBG scan, R*n_seg */
 };
 

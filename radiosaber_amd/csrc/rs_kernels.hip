@@ -140,13 +140,31 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   const int queue_mode_in = DIRECT ? p.queue_mode : (QUEUE ? 1 : 0);
   /* customised-slice inputs per user: the caller's arrays (drop-in mode) or this cell's rows of the queue model's
    * (bit 0: the prioritized bearer has data; queue model only, bit 1: the user has any queued data = is in UsersToSchedule) */
-  const uint8_t* const prio_in = QUEUE ? p.q_flags + (size_t)blockIdx.x * (FIXED ? RS_JIT_U : p.U) : (DIRECT ? p.prio : nullptr);
-  const double* const hol_in = QUEUE ? p.q_hol + (size_t)blockIdx.x * (FIXED ? RS_JIT_U : p.U) : (DIRECT ? p.hol : nullptr);
+  /* The queue model's per-bearer words (RS_QSTATE_BYTES_PER_USER per user) stay in LDS for the whole launch when the carve has
+   * room (q_lds; a compile-time fact in a shape-specialised build, so its pointers are plain LDS pointers), else in HBM. */
+  constexpr RsCarve kCvQ = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, QUEUE ? 2 : 0);
+  const bool q_lds = QUEUE && (FIXED ? kCvQ.q_lds != 0 : p.q_lds != 0);
+  const int qU = FIXED ? RS_JIT_U : p.U;
+  unsigned char* const qs = lds + (FIXED ? kCvQ.off_qstate : p.off_qstate);
+  double* const qs_avg = (double*)qs;                  /* [2][U] m_averageTransmissionRate */
+  double* const qs_next = qs_avg + 2 * qU;             /* [2][U] time stamp of the next arrival burst (+inf: none left) */
+  double* const qs_headt = qs_next + 2 * qU;           /* [2][U] time stamp of the head burst (valid while the queue holds bytes) */
+  double* const qs_hol = qs_headt + 2 * qU;            /* [U] head-of-line delay of the slice-priority bearer */
+  int32_t* const qs_i = (int32_t*)(qs_hol + qU);       /* [7][2][U] head, tail, pk, frag, bytes, pkts, tx */
+  long long* const qs_a0 = (long long*)(qs_i + 14 * qU); /* [2][U] first arrival burst of the bearer in the arr_* arrays */
+  int32_t* const qs_narr = (int32_t*)(qs_a0 + 2 * qU); /* [2][U] number of its bursts */
+  int32_t* const qs_hnf = qs_narr + 2 * qU;            /* [2][U] full packets of the head burst ... */
+  int32_t* const qs_hla = qs_hnf + 2 * qU;             /* [2][U] ... and bytes of its last packet (valid while the queue holds packets) */
+  uint8_t* const qs_kind = (uint8_t*)(qs_hla + 2 * qU); /* [U][2] */
+  uint8_t* const qs_flags = qs_kind + 2 * qU;          /* [U] bit 0: prioritized bearer has data, bit 1: user has queued data */
+  uint8_t* const qs_slice = qs_flags + qU;             /* [U] */
+  const uint8_t* const prio_in = QUEUE ? (q_lds ? qs_flags : p.q_flags + (size_t)blockIdx.x * qU) : (DIRECT ? p.prio : nullptr);
+  const double* const hol_in = QUEUE ? (q_lds ? qs_hol : p.q_hol + (size_t)blockIdx.x * qU) : (DIRECT ? p.hol : nullptr);
   const int tid = threadIdx.x;
   const int nt = FIXED ? RS_JIT_NT : (int)blockDim.x;
   const int lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
   const int S = FIXED ? RS_JIT_S : p.S, U = FIXED ? RS_JIT_U : p.U, R = FIXED ? RS_JIT_R : p.R, G = FIXED ? RS_JIT_G : p.G;
-  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, QUEUE ? 1 : 0);
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, QUEUE ? 2 : 0);
   /* byte offsets of the LDS arrays: constants in a shape-specialised build */
   struct Offs { int avgk, rcp, tab, slice, tx, misc, tbs, elems, sorted, items, sortx, cqi, queue, Upad, n_seg, n_items; };
   const Offs o = FIXED ? Offs{kCv.off_avgk, kCv.off_rcp, kCv.off_tab, kCv.off_slice, kCv.off_tx, kCv.off_misc, kCv.off_tbs,
@@ -265,7 +283,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   }
   if (tid < 2) { m->spec[tid].ctr_p1 = 0; m->spec[tid].ctr_p3 = 0; m->spec[tid].greedy_done = 0; m->spec[tid].n_fix = 0; }
   if (tid < S) {
-    m->eps_psi[tid] = (uint8_t)((p.eps[tid] ? 1 : 0) | (p.psi[tid] ? 2 : 0));
+    /* bit 0 = algo_epsilon, bit 1 = algo_psi, bit 2 = algo_alpha, bit 3 = algo_beta */
+    m->eps_psi[tid] = (uint8_t)((p.eps[tid] ? 1 : 0) | (p.psi[tid] ? 2 : 0) | ((p.alpha && p.alpha[tid]) ? 4 : 0) | ((p.beta && p.beta[tid]) ? 8 : 0));
     s_w[tid] = p.weight[tid];
     s_sstate[tid] = p.slice_state[(size_t)cell * S + tid];
   }
@@ -365,19 +384,38 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * priority down, RLC dequeue with 8 bytes of overhead per packet, fragmenting the last), EWMA of every bearer, the arrivals
    * up to now, then the user's record (bearers with packets, dataToTransmit, slice priority, head-of-line delay). */
   auto bearer_index = [&](int u, int b) -> size_t { return ((size_t)cell * 2 + b) * U + u; };
-  auto queue_data = [&](int kind, size_t bi) -> int { /* m_dataToTransmit of a bearer with packets, else 0 */
+  /* the seven 32-bit words of bearer (b, u) -- HBM: seven arrays [cells][2][U] one after the other (RsLaunch::q_head ... b_tx);
+   * LDS: [7][2][U] -- and its average */
+  enum { QF_HEAD = 0, QF_TAIL = 1, QF_PK = 2, QF_FRAG = 3, QF_BYTES = 4, QF_PKTS = 5, QF_TX = 6 };
+  int32_t* const qi_base = !QUEUE ? nullptr : (q_lds ? qs_i : p.q_head + (size_t)cell * 2 * U);
+  const size_t qi_stride = !QUEUE ? 0 : (q_lds ? (size_t)2 * U : (size_t)p.n_cells * 2 * U);
+  double* const qavg_base = !QUEUE ? nullptr : (q_lds ? qs_avg : p.b_avg + (size_t)cell * 2 * U);
+  const uint8_t* const kind_of = !QUEUE ? nullptr : (q_lds ? qs_kind : p.bearer_kind);   /* [U][2] */
+  const uint8_t* const slice_of = (QUEUE && q_lds) ? qs_slice : p.user_slice;
+  uint8_t* const q_fl = !QUEUE ? nullptr : (q_lds ? qs_flags : p.q_flags + (size_t)cell * U);
+  double* const q_ho = !QUEUE ? nullptr : (q_lds ? qs_hol : p.q_hol + (size_t)cell * U);
+  auto QI = [&](int f, int b, int u) -> int32_t& { return qi_base[(size_t)f * qi_stride + b * U + u]; };
+  auto queue_data = [&](int kind, int b, int u) -> int { /* m_dataToTransmit of a bearer with packets, else 0 */
     if (kind == 1) return 100000000;
     if (kind != 2) return 0;
-    const int pk = p.q_pkts[bi];
-    return pk > 0 ? p.q_bytes[bi] + 8 * pk : 0; /* GetQueueSizeWithMACHoverhead */
+    const int pk = QI(QF_PKTS, b, u);
+    return pk > 0 ? QI(QF_BYTES, b, u) + 8 * pk : 0; /* GetQueueSizeWithMACHoverhead */
   };
+  /* RadioBearer::m_cumulativeBytes / m_cumulativeRBs stay in HBM: touched for served bearers only, fire-and-forget adds */
+  auto cum_add = [&](int64_t* w, long long v) { (void)atomicAdd((unsigned long long*)w, (unsigned long long)v); };
   /* one bearer's RLC dequeue of `sent` bytes (TransmissionProcedure): whole packets cost their data + 8 bytes, the last one may
    * leave as a fragment */
-  auto rlc_dequeue = [&](int u, int b, size_t bi, int sent) {
-    int left = sent, head = p.q_head[bi], pk = p.q_pk[bi], frag = p.q_frag[bi], qb = p.q_bytes[bi], qp = p.q_pkts[bi];
-    const size_t a0 = (size_t)p.arr_off[(size_t)(cell * U + u) * 2 + b];
+  auto rlc_dequeue = [&](int u, int b, int sent) {
+    int left = sent, head = QI(QF_HEAD, b, u), pk = QI(QF_PK, b, u), frag = QI(QF_FRAG, b, u), qb = QI(QF_BYTES, b, u), qp = QI(QF_PKTS, b, u);
+    const int head0 = head;
+    const size_t a0 = q_lds ? (size_t)qs_a0[b * U + u] : (size_t)p.arr_off[(size_t)(cell * U + u) * 2 + b];
+    /* the head burst's shape: cached beside the queue words (LDS) or read where it lies */
+    int nfull = 0, last = 0;
+    if (left > 8 && qp > 0) {
+      nfull = q_lds ? qs_hnf[b * U + u] : p.arr_nfull[a0 + head];
+      last = q_lds ? qs_hla[b * U + u] : p.arr_last[a0 + head];
+    }
     while (left > 8 && qp > 0) {
-      const int nfull = p.arr_nfull[a0 + head], last = p.arr_last[a0 + head];
       const int size_cur = pk < nfull ? RS_FULL_PACKET : last;
       const int data_cur = size_cur - frag;
       if (data_cur + 8 > left) { /* fragment */
@@ -399,9 +437,18 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         qp -= k;
         pk += k;
       }
-      if (pk >= nfull + (last > 0 ? 1 : 0)) { head += 1; pk = 0; }
+      if (pk >= nfull + (last > 0 ? 1 : 0)) {
+        head += 1;
+        pk = 0;
+        if (qp > 0) { nfull = p.arr_nfull[a0 + head]; last = p.arr_last[a0 + head]; } /* (packets left: the next burst exists) */
+      }
     }
-    p.q_head[bi] = head; p.q_pk[bi] = pk; p.q_frag[bi] = frag; p.q_bytes[bi] = qb; p.q_pkts[bi] = qp;
+    QI(QF_HEAD, b, u) = head; QI(QF_PK, b, u) = pk; QI(QF_FRAG, b, u) = frag; QI(QF_BYTES, b, u) = qb; QI(QF_PKTS, b, u) = qp;
+    if (q_lds && head != head0 && qp > 0) {
+      qs_headt[b * U + u] = p.arr_time[a0 + head];
+      qs_hnf[b * U + u] = nfull;
+      qs_hla[b * U + u] = last;
+    }
   };
   auto stop_schedule_user = [&](int u) {
     if constexpr (SCHED == 1) {
@@ -415,16 +462,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         *slot = 0;
         const int bytes = grant & RS_TX_BYTES_MASK, nprb = (grant >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK;
         const size_t bi = bearer_index(u, b);
-        p.b_tx[bi] += bytes;
-        p.b_cumb[bi] += bytes;
-        p.b_cumr[bi] += nprb;
+        QI(QF_TX, b, u) += bytes;
+        cum_add(&p.b_cumb[bi], bytes);
+        cum_add(&p.b_cumr[bi], nprb);
         user_bytes += bytes;
         user_rbs += nprb;
-        if (p.bearer_kind[u * 2 + b] == 2) rlc_dequeue(u, b, bi, bytes);
+        if (kind_of[u * 2 + b] == 2) rlc_dequeue(u, b, bytes);
       }
       if (user_bytes) {
-        p.cum_bytes[(size_t)cell * U + u] += user_bytes;
-        p.cum_rbs[(size_t)cell * U + u] += user_rbs;
+        cum_add(&p.cum_bytes[(size_t)cell * U + u], user_bytes);
+        cum_add(&p.cum_rbs[(size_t)cell * U + u], user_rbs);
       }
       return;
     }
@@ -435,23 +482,65 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     const int nprb = (grant >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK;
     long long user_bytes = 0;
     for (int b = 1; b >= 0 && avail > 0; --b) {
-      const int kind = p.bearer_kind[u * 2 + b];
+      const int kind = kind_of[u * 2 + b];
       const size_t bi = bearer_index(u, b);
-      const int data = queue_data(kind, bi);
+      const int data = queue_data(kind, b, u);
       if (data <= 0) continue;
       const int sent = avail < data ? avail : data;
       avail -= sent;
-      p.b_tx[bi] += sent;
-      p.b_cumb[bi] += sent;
-      p.b_cumr[bi] += nprb;
+      QI(QF_TX, b, u) += sent;
+      cum_add(&p.b_cumb[bi], sent);
+      cum_add(&p.b_cumr[bi], nprb);
       user_bytes += sent;
-      if (kind == 2) rlc_dequeue(u, b, bi, sent);
+      if (kind == 2) rlc_dequeue(u, b, sent);
     }
     if (user_bytes) {
-      p.cum_bytes[(size_t)cell * U + u] += user_bytes; /* per-user totals for rs_batch_slice_bytes / read_state */
-      p.cum_rbs[(size_t)cell * U + u] += nprb;
+      cum_add(&p.cum_bytes[(size_t)cell * U + u], user_bytes); /* per-user totals for rs_batch_slice_bytes / read_state */
+      cum_add(&p.cum_rbs[(size_t)cell * U + u], nprb);
     }
   };
+  if constexpr (QUEUE) {
+    if (q_lds) {
+      /* load the bearers of this cell: every thread the users it owns in P1 (the only writer of these words) */
+      const double kNever = __builtin_inf();
+      for (int u = tid; u < U; u += nt) {
+        for (int b = 0; b < 2; ++b) {
+          const size_t bi = bearer_index(u, b);
+          const int kind = p.bearer_kind[u * 2 + b];
+          qs_kind[u * 2 + b] = (uint8_t)kind;
+          qs_avg[b * U + u] = p.b_avg[bi];
+          const size_t n = (size_t)p.n_cells * 2 * U;
+#pragma unroll
+          for (int f = 0; f < 7; ++f) qs_i[(f * 2 + b) * U + u] = p.q_head[(size_t)f * n + bi];
+          double next = kNever, headt = 0.0;
+          long long a0 = 0;
+          int n_arr = 0, hnf = 0, hla = 0;
+          if (kind == 2) {
+            a0 = (long long)p.arr_off[(size_t)(cell * U + u) * 2 + b];
+            n_arr = (int)((long long)p.arr_off[(size_t)(cell * U + u) * 2 + b + 1] - a0);
+            const int tail = p.q_tail[bi];
+            if (tail < n_arr) next = p.arr_time[a0 + tail];
+            if (p.q_pkts[bi] != 0) {
+              const int head = p.q_head[bi];
+              headt = p.arr_time[a0 + head];
+              hnf = p.arr_nfull[a0 + head];
+              hla = p.arr_last[a0 + head];
+            }
+          }
+          qs_next[b * U + u] = next;
+          qs_headt[b * U + u] = headt;
+          qs_a0[b * U + u] = a0;
+          qs_narr[b * U + u] = n_arr;
+          qs_hnf[b * U + u] = hnf;
+          qs_hla[b * U + u] = hla;
+        }
+        qs_slice[u] = p.user_slice[u];
+        qs_flags[u] = 0;
+        qs_hol[u] = 0.0;
+      }
+      __syncthreads();
+    }
+  }
   bool have_spec = false; /* this TTI's EWMA, metric scan and quotas were prepared during the previous TTI's serial phase */
   for (int tti = 0; tti < p.n_ttis; ++tti) {
     RS_STAMP(11);
@@ -565,33 +654,46 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         bool has[2] = {false, false};
         double bavg[2] = {0, 0};
         for (int b = 0; b < 2; ++b) {
-          const int kind = p.bearer_kind[u * 2 + b];
+          const int kind = kind_of[u * 2 + b];
           if (kind == 0) continue;
-          const size_t bi = bearer_index(u, b);
           /* RadioBearer::UpdateAverageTransmissionRate: every bearer, scheduled or not */
-          double a = p.b_avg[bi];
+          double a = qavg_base[b * U + u];
           if (do_ewma) {
-            const double rate = (double)(p.b_tx[bi] * 8) / dt;
+            const double rate = (double)(QI(QF_TX, b, u) * 8) / dt;
             const double beta = 0.02;
             a = ((1 - beta) * a) + (beta * rate);
             if (a < 1) a = 1;
-            p.b_avg[bi] = a;
-            p.b_tx[bi] = 0;
+            qavg_base[b * U + u] = a;
+            QI(QF_TX, b, u) = 0;
           }
           bavg[b] = a;
           if (kind == 2) {
-            /* the applications' Send() events with a time stamp up to now (MacQueue::Enqueue per packet) */
-            const size_t a0 = (size_t)p.arr_off[(size_t)(cell * U + u) * 2 + b];
-            const int n_arr = (int)((size_t)p.arr_off[(size_t)(cell * U + u) * 2 + b + 1] - a0);
-            int tail = p.q_tail[bi], qb = p.q_bytes[bi], qp = p.q_pkts[bi];
-            const int tail0 = tail;
-            while (tail < n_arr && p.arr_time[a0 + tail] <= t) {
-              const int nfull = p.arr_nfull[a0 + tail], last = p.arr_last[a0 + tail];
-              qb += nfull * RS_FULL_PACKET + last;
-              qp += nfull + (last > 0 ? 1 : 0);
-              tail += 1;
+            /* the applications' Send() events with a time stamp up to now (MacQueue::Enqueue per packet).  With the state in LDS
+             * the next burst's time stamp is cached: a TTI without arrivals touches no HBM */
+            int qp = QI(QF_PKTS, b, u);
+            if (!q_lds || qs_next[b * U + u] <= t) {
+              const size_t a0 = q_lds ? (size_t)qs_a0[b * U + u] : (size_t)p.arr_off[(size_t)(cell * U + u) * 2 + b];
+              const int n_arr = q_lds ? qs_narr[b * U + u] : (int)((size_t)p.arr_off[(size_t)(cell * U + u) * 2 + b + 1] - a0);
+              int tail = QI(QF_TAIL, b, u), qb = QI(QF_BYTES, b, u);
+              const int tail0 = tail, qp0 = qp;
+              while (tail < n_arr && p.arr_time[a0 + tail] <= t) {
+                const int nfull = p.arr_nfull[a0 + tail], last = p.arr_last[a0 + tail];
+                qb += nfull * RS_FULL_PACKET + last;
+                qp += nfull + (last > 0 ? 1 : 0);
+                tail += 1;
+              }
+              if (tail != tail0) { QI(QF_TAIL, b, u) = tail; QI(QF_BYTES, b, u) = qb; QI(QF_PKTS, b, u) = qp; }
+              if (q_lds) {
+                qs_next[b * U + u] = tail < n_arr ? p.arr_time[a0 + tail] : __builtin_inf();
+                /* an empty queue's head is its first new burst */
+                if (qp0 == 0 && tail != tail0) {
+                  const int head = QI(QF_HEAD, b, u);
+                  qs_headt[b * U + u] = p.arr_time[a0 + head];
+                  qs_hnf[b * U + u] = p.arr_nfull[a0 + head];
+                  qs_hla[b * U + u] = p.arr_last[a0 + head];
+                }
+              }
             }
-            if (tail != tail0) { p.q_tail[bi] = tail; p.q_bytes[bi] = qb; p.q_pkts[bi] = qp; }
             has[b] = qp > 0;
           } else {
             has[b] = true; /* InfiniteBuffer: HasPackets() is always true */
@@ -599,8 +701,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
         const bool active = has[0] || has[1];
         if constexpr (kQSerial) {
-          q_data0[u] = has[0] ? queue_data(p.bearer_kind[u * 2], bearer_index(u, 0)) : 0;
-          q_data1[u] = has[1] ? queue_data(p.bearer_kind[u * 2 + 1], bearer_index(u, 1)) : 0;
+          q_data0[u] = has[0] ? queue_data(kind_of[u * 2], 0, u) : 0;
+          q_data1[u] = has[1] ? queue_data(kind_of[u * 2 + 1], 1, u) : 0;
           q_done[2 * u] = 0;
           q_done[2 * u + 1] = 0;
         }
@@ -616,36 +718,42 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         k = rs_div_1000(k);
         s_avgk[u] = k;
         if (active) {
-          const int sl = p.user_slice[u];
+          const int sl = slice_of[u];
           atomicMax(&q_slice_prio[sl], has[1] ? 1 : 0);
           q_slice_act[sl] = 1;
         }
-        p.q_flags[(size_t)cell * U + u] = active ? 2 : 0;
+        q_fl[u] = active ? 2 : 0;
       }
       last_update = t;
       __syncthreads();
       for (int u = tid; u < U && SCHED != 1; u += nt) {
-        const int flags = p.q_flags[(size_t)cell * U + u];
-        const int sl = p.user_slice[u];
+        const int flags = q_fl[u];
+        const int sl = slice_of[u];
         const int uo = s_uoff[u];
         float r32 = 0.0f;
         if (flags & 2) {
           r32 = (uo & 1) ? __builtin_amdgcn_rcpf((float)s_avgk[u]) : 1.0f;
-          if (p.alpha[sl]) {
+          const int sl_bits = m->eps_psi[sl];
+          if (sl_bits & 4) {
             /* customised slice (ref: :694-711): the slice's priority = the highest bearer priority with packets in the slice */
             const int pb = q_slice_prio[sl];
-            const int kind = p.bearer_kind[u * 2 + pb];
-            const size_t bi = bearer_index(u, pb);
-            const bool has_data = queue_data(kind, bi) != 0;
+            const int kind = kind_of[u * 2 + pb];
+            const bool has_data = queue_data(kind, pb, u) != 0;
             double hol = 0.0; /* GetHeadOfLinePacketDelay: 0 with an empty MAC queue (an InfiniteBuffer bearer has none) */
-            if (kind == 2 && p.q_bytes[bi] != 0) {
-              const size_t a0 = (size_t)p.arr_off[(size_t)(cell * U + u) * 2 + pb];
-              hol = t - p.arr_time[a0 + p.q_head[bi]];
+            if (kind == 2 && QI(QF_BYTES, pb, u) != 0) {
+              double head_time;
+              if (q_lds) {
+                head_time = qs_headt[pb * U + u];
+              } else {
+                const size_t a0 = (size_t)p.arr_off[(size_t)(cell * U + u) * 2 + pb];
+                head_time = p.arr_time[a0 + QI(QF_HEAD, pb, u)];
+              }
+              hol = t - head_time;
               if (hol < 0.00001) hol = 0.00001;
             }
-            p.q_hol[(size_t)cell * U + u] = hol;
-            p.q_flags[(size_t)cell * U + u] = 2 | (has_data ? 1 : 0);
-            r32 = !has_data ? 0.0f : ((SCHED == 7 || p.beta[sl] != 0) ? r32 * (float)hol : r32);
+            q_ho[u] = hol;
+            q_fl[u] = (uint8_t)(2 | (has_data ? 1 : 0));
+            r32 = !has_data ? 0.0f : ((SCHED == 7 || (sl_bits & 8) != 0) ? r32 * (float)hol : r32);
           }
         }
         s_rcp32[u + (uo & ~7)] = r32;
@@ -1006,7 +1114,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           int sl = SCHED == 7 ? (kDirect ? (int)p.user_slice[0] : seg) : seg;
           sl_eps = m->eps_psi[sl] & 1;
           sl_psi = (m->eps_psi[sl] >> 1) & 1;
-          if (queue_mode_in && p.alpha[sl]) sl_custom = (SCHED == 7 || p.beta[sl] != 0) ? 2 : 1;
+          if (queue_mode_in && (m->eps_psi[sl] & 4)) sl_custom = (SCHED == 7 || (m->eps_psi[sl] & 8) != 0) ? 2 : 1;
         }
         const uint8_t* rowp = s_cqi + r * Upad;
         /* Exact two-stage argmax.  Stage 1 ranks the segment's users by the cheap
@@ -1194,6 +1302,19 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           need = (first * 8) / tab->tbs1_of_cqi[wide];
         }
         q_need[u] = need;
+      }
+      /* The metric of a (user, RBG) pair depends on the RBG through the CQI only: 16 quotients per user of the served slice,
+       * divided here by all threads, instead of one division per candidate and RBG on the serial wave (the idle sort buffers
+       * hold the table when the slice fits: 128 bytes per user) */
+      if (ue - ub <= 64 && (ue - ub) * 128 <= o.items - o.elems) {
+        const int sl_eps7 = m->eps_psi[seg_lo] & 1, sl_psi7 = (m->eps_psi[seg_lo] >> 1) & 1;
+        const bool custom7 = (m->eps_psi[seg_lo] & 4) != 0;
+        double* const qt = (double*)s_elems;
+        for (int i = tid; i < (ue - ub) * 16; i += nt) {
+          const int u = ub + (i >> 4), cq = i & 15;
+          const double num = sl_eps7 ? s_num[cq] : 1.0, den = sl_psi7 ? s_avgk[u] : 1.0;
+          qt[i] = !custom7 ? num / den : ((prio_in[u] & 1) == 0 ? 0.0 : hol_in[u] * num / den); /* ref: nvs :375-387 */
+        }
       }
     }
     if constexpr (SCHED != 11 && !kQSerial) {
@@ -1424,9 +1545,32 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           c_hi = m->seg_begin[seg_lo + 1];
           sl_eps = m->eps_psi[seg_lo] & 1;
           sl_psi = (m->eps_psi[seg_lo] >> 1) & 1;
-          sl_custom = p.alpha[seg_lo] != 0;
+          sl_custom = (m->eps_psi[seg_lo] & 4) != 0;
         }
-        for (int r = 0; r < R; ++r) {
+        /* sched 7, served slice of at most 64 users with its metric table in place: lane = user, the user's remaining
+         * m_requiredRBs in a register, per RBG two LDS reads (the next RBG's CQI is fetched a step ahead) and the two reductions */
+        const bool table7 = SCHED == 7 && c_hi - c_lo <= 64 && (c_hi - c_lo) * 128 <= o.items - o.elems;
+        if (table7) {
+          const int u = c_lo + lane;
+          const bool mine = u < c_hi && (prio_in[u < c_hi ? u : c_lo] & 2) != 0;
+          int need = mine ? q_need[u] : 0;
+          const double* const row = (const double*)s_elems + lane * 16;
+          int cq_next = mine ? (int)s_cqi[u] : 0;
+          for (int r = 0; r < R; ++r) {
+            const int cq = cq_next;
+            if (r + 1 < R && mine) cq_next = s_cqi[(r + 1) * Upad + u];
+            const double metric = mine ? row[cq] : 0.0;
+            const bool valid = mine && need > 0;
+            const int hi = valid ? __double2hiint(metric) : -1;
+            const int lo = (int)((unsigned)__double2loint(metric) ^ 0x80000000u);
+            const int mhi = wave_max(hi);
+            const int mlo = wave_max(hi == mhi ? lo : (int)0x80000000);
+            const int pick = mhi >= 0 ? __ffsll((long long)__ballot(valid && hi == mhi && lo == mlo)) - 1 : -1;
+            if (lane == r) owner = pick >= 0 ? c_lo + pick : -1;
+            if (lane == pick) need -= G;
+          }
+        }
+        for (int r = 0; r < R && !table7; ++r) {
           int bhi = -1, blo = (int)0x80000000, bpick = -1;
           for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
             const int cnd = c0 + lane;
@@ -1887,6 +2031,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   if constexpr (QUEUE) {
     /* DoStopSchedule of the launch's last TTI, so that the bearers' counters and queues the host reads are complete */
     for (int u = tid; u < U; u += nt) stop_schedule_user(u);
+    if (q_lds) { /* the bearers' words back to HBM, by their owner threads */
+      const size_t n = (size_t)p.n_cells * 2 * U;
+      for (int u = tid; u < U; u += nt)
+        for (int b = 0; b < 2; ++b) {
+          const size_t bi = bearer_index(u, b);
+          p.b_avg[bi] = qs_avg[b * U + u];
+#pragma unroll
+          for (int f = 0; f < 7; ++f) p.q_head[(size_t)f * n + bi] = qs_i[(f * 2 + b) * U + u];
+        }
+    }
   }
   /* ---------------- store the cell ---------------- */
 #pragma unroll
@@ -1951,7 +2105,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
 #endif
 /* shape-specialised entry point compiled at run time (rs_jit.cpp): static LDS of exactly the carve's size */
 extern "C" __global__ void __launch_bounds__(RS_JIT_NT, 4) rs_cell_kernel_jit(RsLaunch p) {
-  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_QUEUE != 0 ? 1 : 0);
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_QUEUE != 0 ? 2 : 0);
   __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
   constexpr int kEpt = (RS_JIT_SCHED != 9 && RS_JIT_SCHED != 10) ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);
   rs_cell_body<RS_JIT_SCHED, kEpt, true, false, RS_JIT_QUEUE != 0>(p, lds);

@@ -26,9 +26,24 @@ ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--ues-per-slice", type=int, default=25)
 ap.add_argument("--w1", action="store_true", help="-DRS_STAMPS_W1 build: the sub-stamp slots hold wave 1's serial-phase clock")
 ap.add_argument("--jit", action="store_true", help="shape-specialised kernel (export RS_JIT_EXTRA=-DRS_STAMPS)")
+ap.add_argument("--queues", action="store_true", help="the queue model on exp-customize-20slices (tools/bench_queue_mode.py's workload)")
 a = ap.parse_args()
-sc = rs.SliceConfig([a.ues_per_slice] * 20, weight=[0.05] * 20)
+if a.queues:
+    import json
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import bench_queue_mode as Q
+    cfg = json.loads((Q.GOLDEN / "experiment_configs.json").read_text())["exp-customization/exp-customize-20slices/config.json"]
+    sc = rs.SliceConfig(cfg["ues_per_slice"], cfg["weight"], cfg["algo_alpha"], cfg["algo_beta"], cfg["algo_epsilon"],
+                        cfg["algo_psi"], cfg["traffic"])
+    per_cell = Q.build_bursts(cfg, sc, 8, 2 * a.ttis)
+    bursts = {(c, u, k): v for c in range(a.cells) for (u, k), v in per_cell[c % 8].items()}
+else:
+    sc = rs.SliceConfig([a.ues_per_slice] * 20, weight=[0.05] * 20)
 b = rs.BatchScheduler(sc, a.rbgs, a.rbg_size, a.cells, sched=a.sched, threads_per_cell=a.threads, jit=a.jit)
+if a.queues:
+    b.set_bearers(sc.bearer_kinds())
+    b.set_arrivals(bursts)
+    print("jit status:", b.jit_status())
 b.seed(np.arange(a.cells, dtype=np.uint32) + 1)
 b.synthesize_cqi(1, (2 * a.ttis + 39) // 40)
 b.run(a.ttis)
