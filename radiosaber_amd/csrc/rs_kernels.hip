@@ -1570,9 +1570,86 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             if (lane == pick) need -= G;
           }
         }
+        /* sched 1 in a shape-specialised build: every lane keeps its flows (flow id 64 k + lane, k < kFK) in registers -- the
+         * stage-1 reciprocal of the flow's average and an "in the race" bit -- and ranks them per RBG with the FP32 product of
+         * DESIGN.md 2.6 (one multiply per flow, one wave reduction per RBG); only flows within 2^-19 of the best product can win
+         * or tie, so a single survivor is the winner without any division and several are compared exactly, ascending flow id,
+         * strict '>' (the reference's scan order, downlink-packet-scheduler.cpp:221-237). */
+        constexpr int kFK = FIXED ? (2 * RS_JIT_U + 63) / 64 : 1;
+        constexpr bool kFlowRegs = FIXED && SCHED == 1 && kFK <= 16;
+        float flow_rc[kFK];
+        unsigned flow_alive = 0u;
+        if constexpr (kFlowRegs) {
+#pragma unroll
+          for (int k = 0; k < kFK; ++k) {
+            const int f = 64 * k + lane, u = (f >> 1) < U ? (f >> 1) : U - 1;
+            const int data = f < 2 * U ? ((f & 1) ? q_data1[u] : q_data0[u]) : 0;
+            const double af = (f & 1) ? s_avgk[u] : s_avg[u];
+            flow_rc[k] = __builtin_amdgcn_rcpf((float)af);
+            if (data > 0) flow_alive |= 1u << k;
+          }
+        }
+        int tbs_cap8 = 0; /* sched 1: floor(largest transport block of the table / 8): more bytes than that are never carried */
+        if (SCHED == 1) {
+          for (int i = lane; i < (R + 1) * 16; i += 64) tbs_cap8 = s_tbs[i] > tbs_cap8 ? s_tbs[i] : tbs_cap8;
+          tbs_cap8 = wave_max(tbs_cap8) >> 3;
+        }
+        double run_sum = 0.0; /* sched 1, lane r: EESM sum / PRBs of the flow that holds RBG r, up to and including RBG r */
+        int run_nprb = 0;
         for (int r = 0; r < R && !table7; ++r) {
           int bhi = -1, blo = (int)0x80000000, bpick = -1;
-          for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+          if constexpr (kFlowRegs) {
+            const float kTolF = 0x1.ffffcp-1f; /* 1 - 2^-19 */
+            int cqv[kFK];
+            float av[kFK];
+            float best_a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kFK; ++k) {
+              const int f = 64 * k + lane, u = (f >> 1) < U ? (f >> 1) : U - 1;
+              cqv[k] = s_cqi[r * Upad + u];
+            }
+#pragma unroll
+            for (int k = 0; k < kFK; ++k) {
+              av[k] = ((flow_alive >> k) & 1u) ? s_num32[cqv[k]] * flow_rc[k] : 0.0f;
+              best_a = fmaxf(best_a, av[k]);
+            }
+            const float mx = __int_as_float(wave_max(__float_as_int(best_a))); /* products are >= 0: they order like their bits */
+            if (mx > 0.0f) {
+              const float thr = mx * kTolF;
+              unsigned cm = 0u;
+#pragma unroll
+              for (int k = 0; k < kFK; ++k) cm |= av[k] >= thr ? (1u << k) : 0u; /* thr > 0: a survivor is in the race */
+              const unsigned long long holders = __ballot(cm != 0u);
+              if (__popcll(holders) == 1) {
+                const int src = __ffsll((long long)holders) - 1;
+                const unsigned cmw = (unsigned)__builtin_amdgcn_readlane((int)cm, src);
+                if ((cmw & (cmw - 1u)) == 0u) bpick = 64 * (__ffs((int)cmw) - 1) + src;
+              }
+              if (bpick < 0) {
+                /* several flows within the tolerance (flows that were never served share one average): compared exactly, chunk
+                 * by chunk in ascending flow id, strict '>' (three reductions over per-lane bests measured slower: 63.1 against
+                 * 60.8 us per TTI) */
+#pragma unroll
+                for (int k = 0; k < kFK; ++k) {
+                  if (__ballot((cm >> k) & 1u) == 0ull) continue;
+                  const int f = 64 * k + lane, u = (f >> 1) < U ? (f >> 1) : U - 1;
+                  bool valid = ((cm >> k) & 1u) != 0u;
+                  const double metric = s_num[cqv[k]] / ((f & 1) ? s_avgk[u] : s_avg[u]); /* (se * 180000.) / the flow's own average */
+                  valid = valid && metric > 0; /* the scan starts from 0 with '>' */
+                  const int hi = valid ? __double2hiint(metric) : -1;
+                  const int lo = (int)((unsigned)__double2loint(metric) ^ 0x80000000u);
+                  const int mhi = wave_max(hi);
+                  const int mlo = wave_max(hi == mhi ? lo : (int)0x80000000);
+                  if (mhi >= 0 && (mhi > bhi || (mhi == bhi && mlo > blo))) {
+                    bhi = mhi;
+                    blo = mlo;
+                    bpick = 64 * k + __ffsll((long long)__ballot(valid && hi == mhi && lo == mlo)) - 1;
+                  }
+                }
+              }
+            }
+          }
+          for (int c0 = c_lo; c0 < c_hi && !kFlowRegs; c0 += 64) {
             const int cnd = c0 + lane;
             const int u = SCHED == 1 ? cnd >> 1 : cnd;
             bool valid = cnd < c_hi;
@@ -1606,25 +1683,31 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             if (SCHED == 7) {
               if (lane == 0) q_need[bpick] -= G;
             } else {
-              /* the flow's transport block so far (its PRBs in RBG order): satisfied once it carries the whole queue */
-              const unsigned long long mine = __ballot(owner == bpick && lane <= r);
+              /* the flow's transport block so far (its PRBs in RBG order): satisfied once it carries the whole queue.  The new
+               * RBG is the flow's last, so the EESM sum continues where the lane of the flow's previous RBG left it (the same
+               * additions in the same order as summing all of them again) */
+              /* (a flow with more data than the largest transport block of the table -- every InfiniteBuffer flow -- is never
+               * satisfied: no sum to keep) */
+              const int data_pick = (bpick & 1) ? q_data1[bpick >> 1] : q_data0[bpick >> 1];
+              if (data_pick <= tbs_cap8) {
+              const unsigned long long before = __ballot(owner == bpick && lane < r);
+              const int prev = before != 0ull ? 63 - __clzll((long long)before) : 0;
+              const double psum = __shfl(run_sum, prev, 64);
+              const int pn = __builtin_amdgcn_readlane(run_nprb, prev);
               if (lane == r) {
                 const int u = bpick >> 1;
-                unsigned long long mm = mine;
-                double sum = 0;
-                int nprb = 0;
-                while (mm) {
-                  const int r2 = __ffsll((long long)mm) - 1;
-                  mm &= mm - 1;
-                  if (per_prb) { /* the flow's per-PRB feedback (ref: downlink-packet-scheduler.cpp:245-264) */
-                    const uint8_t* pr = prb_ptr(u, r2);
-                    for (int k = 0; k < G; ++k) sum += s_e[pr[k]];
-                  } else {
-                    const double ev = s_e[s_cqi[r2 * Upad + u]];
-                    for (int k = 0; k < G; ++k) sum += ev;
-                  }
-                  nprb += G;
+                double sum = before != 0ull ? psum : 0.0;
+                int nprb = before != 0ull ? pn : 0;
+                if (per_prb) { /* the flow's per-PRB feedback (ref: downlink-packet-scheduler.cpp:245-264) */
+                  const uint8_t* pr = prb_ptr(u, r);
+                  for (int k = 0; k < G; ++k) sum += s_e[pr[k]];
+                } else {
+                  const double ev = s_e[s_cqi[r * Upad + u]];
+                  for (int k = 0; k < G; ++k) sum += ev;
                 }
+                nprb += G;
+                run_sum = sum;
+                run_nprb = nprb;
                 const double x = sum / (double)nprb;
                 int fq = 15;
                 if (!(x == 0)) {
@@ -1632,12 +1715,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #pragma unroll
                   for (int k = 1; k <= 13; ++k) fq += (x <= xthr_k[k - 1]) ? 1 : 0;
                 }
-                const int data = (bpick & 1) ? q_data1[u] : q_data0[u];
-                if (s_tbs[(nprb / G) * 16 + fq] >= data * 8) q_done[bpick] = 1;
+                if (s_tbs[(nprb / G) * 16 + fq] >= data_pick * 8) q_done[bpick] = 1;
+              }
               }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if constexpr (kFlowRegs) { /* a satisfied flow leaves the race: its lane clears the bit */
+              if (q_done[bpick] != 0 && lane == (bpick & 63)) flow_alive &= ~(1u << (bpick >> 6));
+            }
           }
         }
       } else if (DIRECT && (SCHED == 1 || SCHED == 7) && p.gate != nullptr) {
