@@ -115,6 +115,14 @@ def test_shape_specialised_source_compiles_for_gfx950(rs, shape):
     assert rs.jit_selfcheck(*shape) > 10000
 
 
+@pytest.mark.parametrize("shape", [(20, 194, 64, 8, 512, 9), (20, 194, 64, 8, 512, 7), (20, 194, 64, 8, 512, 1),
+                                   (20, 500, 25, 4, 512, 1), (20, 1000, 25, 4, 512, 1), (4, 18, 25, 4, 64, 8), (3, 30, 12, 2, 128, 103)])
+def test_queue_model_kernels_compile_for_gfx950(rs, shape):
+    """The queue-model code object of a batch (rs_batch_set_bearers switches to it): bearer words in LDS, sched 7's metric table,
+    sched 1's flows in registers (U = 194: 7 per lane, U = 500: 16; U = 1 000 falls back to the chunked loop)."""
+    assert rs.jit_selfcheck(*shape[:5], sched=shape[5], queues=True) > 10000
+
+
 def test_headline_shapes_keep_four_cells_per_cu(rs):
     """160 KB of LDS per CU: a cell of the headline shape (20 slices x 500 UEs x 25 RBGs) must stay at or under 40 960 B so
     that large batches place four cells on a CU (measured: 38 M instead of 23-29 M TTIs/s at 1 024+ cells), and the
