@@ -28,7 +28,7 @@
 extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_t stream);
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes);
 struct RsJitKernel;
-extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, int queue, char* err, size_t errlen);
+extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, int queue, int win, char* err, size_t errlen);
 extern "C" hipError_t rs_jit_launch(RsJitKernel* k, const RsLaunch* p, hipStream_t stream);
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,
                                       uint64_t seed, int64_t first_cell, const uint32_t* cdf16, hipStream_t stream);
@@ -289,6 +289,20 @@ int validate(const rs_config* c, bool direct) {
 
 int upad_of(int U) { return rs_upad_of(U); }
 
+/* the longest slice window of the batch in the stage-1 reciprocal array: 8-aligned start of the slice's first user to the
+ * 8-aligned end behind its last (a compile-time constant of the shape-specialised kernel, RS_JIT_WIN) */
+int slice_window(const rs_batch* b) {
+  int win = 0;
+  for (int u = 0; u < b->U;) {
+    int e = u;
+    while (e < b->U && b->u2s[e] == b->u2s[u]) e++;
+    const int w = ((e + 7) & ~7) - (u & ~7);
+    win = w > win ? w : win;
+    u = e;
+  }
+  return win;
+}
+
 void carve_lds(rs_batch* b, RsLaunch* L) {
   /* (drop-in contexts of schedulers 1 and 7 carry the gate scratch too: rs_tti_in.required_rbs / data_to_transmit) */
   const bool gate_scratch = b->direct && (b->sched == RS_SCHED_PF || b->sched == RS_SCHED_NVS);
@@ -480,7 +494,7 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
     /* failure is not an error of this call: the built-in kernels stay in use and the batch keeps the reason
      * (rs_batch_jit_status); rs_last_error() is left alone */
     b->jit_wanted = true;
-    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, b->jit_msg, sizeof b->jit_msg);
+    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, slice_window(b), b->jit_msg, sizeof b->jit_msg);
     if (b->jit) b->jit_msg[0] = 0;
     else if (!b->jit_msg[0]) snprintf(b->jit_msg, sizeof b->jit_msg, "hiprtc build failed");
   }
@@ -809,7 +823,7 @@ int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
   RsJitKernel* qjit = nullptr;
   char qmsg[sizeof b->jit_msg] = {0};
   if (b->jit_wanted) { /* the shape-specialised kernel of the queue model is a different code object */
-    qjit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 1, qmsg, sizeof qmsg);
+    qjit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 1, slice_window(b), qmsg, sizeof qmsg);
     if (!qjit && !qmsg[0]) snprintf(qmsg, sizeof qmsg, "hiprtc build of the queue-model kernel failed");
   }
   const size_t n = (size_t)b->n_cells * 2 * U;

@@ -123,6 +123,9 @@ __device__ __forceinline__ double rs_div_1000(double x) {
 #define RS_JIT_NT 64
 #define RS_JIT_SCHED 8
 #endif
+#ifndef RS_JIT_WIN
+#define RS_JIT_WIN 0 /* shape-specialised build: the longest 8-aligned slice window of the batch (0: not known at compile time) */
+#endif
 
 template <int SCHED, int EPT, bool FIXED, bool DIRECT, bool QUEUE = false>
 __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* lds) {
@@ -202,10 +205,27 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #else
   constexpr bool kSpecBesideVec = false;
 #endif
+  /* Held winners (round 3): the winner of a (slice, RBG) item is NOT looked for again in a TTI in which it cannot
+   * have changed -- the winner was not served in the previous TTI, the CQI grid is the same, and at the item's last scan its
+   * stage-1 value led the slice by a margin that 40 TTIs of rounding and of the "+1" in (1 + avg) cannot use up.  Such TTIs scan
+   * only the listed items (winner served, or margin too small), four lanes per item.  Supersedes the
+   * speculative scan; -DRS_NO_HOLD restores round 2's behaviour.
+   * Measured (512 cells, same box, against -DRS_NO_HOLD): 25 RBGs sched 9 32.8 against 31.9 M TTIs/s, sched 8 89.6 against 85.6,
+   * sched 8 at 50 UEs per slice 74.5 against 62.2; 64 RBGs sched 8 37.3 against 48.9, sched 9 12.9 against 13.5 -- with many
+   * RBGs the speculative scan hides in a long serial phase while 1 280 items are 2.5 chunks of listing per wave.  So: shape-
+   * specialised builds of up to 32 RBGs (-DRS_HOLD_ALWAYS: every shape-specialised build); the built-in kernels, whose shape is
+   * a run-time value, keep round 2's scan. */
+#if defined(RS_NO_HOLD)
+  constexpr bool kHoldSched = false;
+#elif defined(RS_HOLD_ALWAYS)
+  constexpr bool kHoldSched = FIXED && !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
+#else
+  constexpr bool kHoldSched = FIXED && RS_JIT_R <= 32 && !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
+#endif
 #ifdef RS_NO_SPEC
   constexpr bool kSpecSched = false;
 #else
-  constexpr bool kSpecSched = !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103) &&
+  constexpr bool kSpecSched = !kHoldSched && !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103) &&
                               (!FIXED || RS_JIT_U <= 32 * RS_JIT_S) && (kSpecBesideVec || !(FIXED && kVecScan));
 #endif
   const bool spec_enabled = kSpecSched && nwaves >= 2 && U <= 32 * S && (kSpecBesideVec || !vec_scan);
@@ -334,6 +354,25 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   const int nb_rbs = R * G;
   int local_err = 0;
   __syncthreads();
+  /* held winners (kHoldSched): one "held" bit per item (64 items per word, in the place of the second winner buffer), the users
+   * served in the previous TTI (2 048-bit map) and the list of items to scan again in m->hist (free outside the counting sort) */
+#ifndef RS_HOLD_MAX_AGE
+#define RS_HOLD_MAX_AGE 40 /* TTIs a held winner is trusted without a full scan (the margin below is sized for it) */
+#endif
+  unsigned long long* const hold_bits = (unsigned long long*)(lds + o.items + ((2 * o.n_items + 7) & ~7));
+  uint32_t* const hold_served = (uint32_t*)m->hist; /* [64] */
+  uint16_t* const hold_list = m->hist + 128;        /* RS_HOLD_CAP entries: the items to scan again */
+  int32_t* const hold_n = &m->spec[0].n_fix;
+#define RS_HOLD_CAP 896
+  int hold_win = 0; /* the longest 8-aligned slice window: 32 or 64 lanes per listed item (longer: no held winners) */
+  if (kHoldSched) {
+    int w = 0;
+    if (lane < S && m->seg_begin[lane + 1] > m->seg_begin[lane]) w = ((m->seg_begin[lane + 1] + 7) & ~7) - (m->seg_begin[lane] & ~7);
+    hold_win = wave_max(w);
+  }
+  const bool hold_ok = kHoldSched && o.n_items >= 8 && hold_win > 0 && hold_win <= 64 && U <= 2048 &&
+                       (!(FIXED && RS_JIT_WIN > 0) || hold_win <= RS_JIT_WIN);
+  int hold_age = 0;
 
 #ifndef RS_STAMPS
   unsigned long long* sort_sub = nullptr;
@@ -542,6 +581,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
   }
   bool have_spec = false; /* this TTI's EWMA, metric scan and quotas were prepared during the previous TTI's serial phase */
+  bool have_quota = false; /* held winners: this TTI's quotas were worked out by the quota wave during the previous TTI's serial phase */
   for (int tti = 0; tti < p.n_ttis; ++tti) {
     RS_STAMP(11);
     auto prb_ptr = [&](int user, int r2) -> const uint8_t* { /* the G PRBs of RBG r2 as `user` reported them */
@@ -553,9 +593,11 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       return p.trace_prb + (((size_t)p.user_trace[(size_t)cell * U + user] * p.n_rows + cqi_row) * R + r2) * G;
     };
     /* ---------------- P0: CQI refresh ---------------- */
+    bool grid_loaded = false; /* this TTI scans a new CQI grid (held winners: everything is scanned again) */
     if (p.cqi_mode == RS_CQI_EPOCHS) {
       /* a launch that starts inside an epoch loads that epoch's grid first: LDS does not survive between launches */
       if (kDirect || tti == 0 || epoch_pos == 0) {
+        grid_loaded = true;
         long long e = kDirect ? 0 : epoch;
         if (e >= p.n_epochs) { local_err = RS_CQI_EPOCHS; e = p.n_epochs - 1; }
         /* HBM grid is [U][R] (one row per UE, like the reference's per-UE CQI vectors); LDS keeps it
@@ -588,6 +630,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         load = true;
       }
       if (load) {
+        grid_loaded = true;
         for (int i = tid; i < U * R; i += nt) {
           int u = i / R, r = i - u * R;
           int tr = p.user_trace[(size_t)cell * U + u];
@@ -938,7 +981,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         m->quota[lane] = 0;
       }
     };
-    if (wave == quota_wave && !have_spec) quota_phase(served_prev);
+    if (wave == quota_wave && !have_spec && !have_quota) quota_phase(served_prev);
     int seg_lo = 0;   /* NVS: the served slice */
     int nvs_runs = 1; /* sched 7: runs of the served slice scanned in P3 */
     if (SCHED == 7 || SCHED == 11) {
@@ -1092,7 +1135,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
     const int n_items = nvs_split ? R * nvs_runs : o.n_items;
     /* one work item = (segment, RBG): winner to bu_out[it], its record (transport schedulers) to rec_out */
-    auto scan_item = [&](int it, uint16_t* bu_out, uint32_t* rec_out, auto blk_tag) {
+    auto scan_item = [&](int it, uint16_t* bu_out, uint32_t* rec_out, auto blk_tag) -> bool {
+      bool held = false;
+      float top1 = 0.0f, top2 = 0.0f; /* held winners: the two largest stage-1 values of the segment */
       {
         int sg = it / R, r = it - sg * R; /* r fastest: neighbouring lanes read neighbouring CQI bytes */
         int seg = SCHED == 7 ? seg_lo : sg;
@@ -1195,6 +1240,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               const float a = nm[k] * rc[k];
               av[8 * g + k] = a;
               best_a = fmaxf(best_a, a);
+              if constexpr (kHoldSched) {
+                top2 = fmaxf(top2, fminf(top1, a));
+                top1 = fmaxf(top1, a);
+              }
             }
           }
           if (!sl_custom) {
@@ -1261,6 +1310,22 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         const int bkey = bu >= 0 ? rowp[bu] : 0;
         if ((SCHED == 1 || nvs_split) && !exact && bu >= 0) best = exact_metric(bu, bkey); /* the winners' metrics meet in P4 */
         bu_out[it] = (uint16_t)bu;
+        if constexpr (kHoldSched) {
+          /* Held until the next full scan?  The winner's stage-1 value must BE the segment's largest and lead the second
+           * largest by mu = 2^-18 + 2 / (1 + avg_w) (2^-18 covers the stage-1 error on both sides, 2 / (1 + avg_w)
+           * what RS_HOLD_MAX_AGE unserved TTIs take from the winner through the "+1" of (1 + avg) / 1000; avg_w >= 64 keeps the
+           * clamp at 1 out of reach).  A psi = 0 slice ranks on the CQI alone: its winner stands whoever is served. */
+          if (bu >= 0) {
+            if (!sl_psi) {
+              held = true;
+            } else {
+              const float la = *(const float*)((const char*)numtab + ((uint32_t)bkey << 2)) * rcw[bu];
+              const double aw = s_avg[bu];
+              const float mu = 0x1p-18f + 2.0f / (1.0f + (float)aw);
+              held = aw >= 64.0 && la >= top1 && top2 * (1.0f + mu) * 1.000001f <= la;
+            }
+          }
+        }
         if (SCHED == 10) {
           /* UpperBound sorts one vector per slice (:229-233): slice-major */
           rec_out[sg * R + r] = ((uint32_t)bkey << 16) | ((uint32_t)r << 8) | (uint32_t)sg;
@@ -1271,6 +1336,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           s_best_metric[it] = best;
         }
       }
+      return held;
     };
     if constexpr (kQSerial && SCHED == 7) {
       /* m_requiredRBs (packet-scheduler.cpp:319-334): the data of the bearer that created the user's record, in PRBs of the
@@ -1317,6 +1383,183 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
       }
     }
+    bool hold_full = true; /* held winners: this TTI scanned every item (their records are in cur_rec) */
+    if constexpr (kHoldSched) {
+      /* ---- held winners: scan only what can have changed ---- */
+      /* The items to scan again -- winner not held, or served in the previous TTI (a psi = 0 slice ignores the averages) -- are
+       * listed (one ballot + one LDS atomic per wave; a served user leads many RBGs of ONE slice, so the items cluster: wave-
+       * private lists left some wave with two passes in most TTIs) and, after a barrier, dealt out evenly: FOUR LANES PER ITEM,
+       * 8 (or 16) users of the slice's zero-padded window per lane: the stage-1 products as in scan_item, the window's two
+       * largest by two-step butterflies inside the lane quad, then the lane that holds the only user within 2^-19 of the
+       * largest writes the winner (no division); several such users are compared exactly, ascending, strict '>'.
+       * ~60 of 500 items per TTI at the benchmark's shape: one pass of 16 items on every wave. */
+      bool full = !hold_ok || tti == 0 || grid_loaded || hold_age >= RS_HOLD_MAX_AGE;
+      int hold_listed = 0;
+#if defined(RS_STAMPS) && defined(RS_STAMPS_HOLD)
+      unsigned long long hs_prev = __builtin_readcyclecounter();
+#define RS_HSTAMP(i) do { if (tid == 0) { unsigned long long n_ = __builtin_readcyclecounter(); sort_sub[i] += n_ - hs_prev; hs_prev = n_; } } while (0)
+#else
+#define RS_HSTAMP(i) do { } while (0)
+#endif
+      if (!full) {
+        const float kTolH = 0x1.ffffcp-1f; /* 1 - 2^-19 */
+        const int q4 = lane & 3, grp = lane >> 2;
+        /* groups of 8 users per lane: one for windows of up to 32 users, two up to 64 (a compile-time fact when the host passed
+         * the batch's longest window) */
+        constexpr int kMaxGrp = (FIXED && RS_JIT_WIN > 0 && RS_JIT_WIN <= 32) ? 1 : 2;
+        const int ngrp = kMaxGrp == 1 ? 1 : (hold_win <= 32 ? 1 : 2);
+        auto quad_max_i = [&](int v) -> int { /* every lane of the quad gets the quad's maximum: quad_perm [1,0,3,2], [2,3,0,1] */
+          int o1 = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
+          v = v > o1 ? v : o1;
+          int o2 = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
+          return v > o2 ? v : o2;
+        };
+        for (int it0 = wave * 64; it0 < n_items; it0 += nt) {
+          const int it_l = it0 + lane;
+          const bool in = it_l < n_items;
+          const int w = in ? (int)cur_bu[it_l] : 0xFFFF;
+          const bool held_bit = ((hold_bits[it0 >> 6] >> lane) & 1ull) != 0ull;
+          const int sg_l = FIXED ? it_l / RS_JIT_R : idiv_small(in ? it_l : 0, R);
+          const bool psi_on = (m->eps_psi[in ? sg_l : 0] & 2) != 0;
+          const bool was_served = w != 0xFFFF && ((hold_served[(w & 2047) >> 5] >> (w & 31)) & 1u) != 0u;
+          const bool need = in && w != 0xFFFF && (!held_bit || (was_served && psi_on));
+          const unsigned long long mk = __ballot(need);
+          if (mk != 0ull) {
+            int slot0 = 0;
+            if (lane == 0) slot0 = atomicAdd(hold_n, __popcll(mk));
+            slot0 = __builtin_amdgcn_readfirstlane(slot0);
+            const int slot = slot0 + __popcll(mk & ((1ull << lane) - 1ull));
+            if (need && slot < RS_HOLD_CAP) hold_list[slot] = (uint16_t)it_l;
+          }
+        }
+        __syncthreads();
+        const int n_list = rs_lds_load(hold_n);
+        hold_listed = n_list;
+        RS_HSTAMP(0);
+        if (n_list > RS_HOLD_CAP) {
+          full = true; /* (too many to list: everything is scanned, as at the start of a run, when all averages are equal) */
+        } else {
+          /* list entry e goes to wave e mod nwaves, quad e / nwaves: every wave gets its share in the same pass */
+          for (int base = 0; base * nwaves < n_list; base += 16) {
+            const int e = (base + grp) * nwaves + wave;
+            const bool on = e < n_list;
+            const int it = on ? (int)hold_list[e] : 0;
+            const int sg = FIXED ? it / RS_JIT_R : idiv_small(it, R), r = it - sg * R;
+            const int ub = m->seg_begin[sg], ue = m->seg_begin[sg + 1];
+            const int bits = m->eps_psi[sg];
+            const float* numtab = (bits & 1) ? s_num32 : m->ones16;
+            const float* rcw = s_rcp32 + m->rcp_off[sg];
+            const uint8_t* rowp = s_cqi + r * Upad;
+            const int wend = (ue + 7) & ~7;
+            const int u0 = (ub & ~7) + q4 * 8 * ngrp;
+            float t1 = 0.0f, t2 = 0.0f; /* my users' largest and second largest stage-1 value */
+            float av[8 * kMaxGrp];
+#pragma unroll
+            for (int g = 0; g < kMaxGrp; ++g) {
+              const int ug = u0 + 8 * g;
+              uint2 cw = make_uint2(0u, 0u);
+              float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+              if (on && g < ngrp && ug < wend) {
+                cw = *(const uint2*)(rowp + ug);
+                ra = *(const float4*)(rcw + ug);
+                rb = *(const float4*)(rcw + ug + 4);
+              }
+              const float rc[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+              const uint32_t cx4 = cw.x << 2, cy4 = cw.y << 2;
+              float nm[8];
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+                nm[k] = *(const float*)((const char*)numtab + (((k < 4 ? cx4 : cy4) >> (8 * (k & 3))) & 0xffu));
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const float a = nm[k] * rc[k]; /* 0 outside the slice: zero reciprocals around it */
+                av[8 * g + k] = a;
+                t2 = fmaxf(t2, fminf(t1, a));
+                t1 = fmaxf(t1, a);
+              }
+            }
+            /* the quad's two largest: (t1, t2) pairs meet in two butterfly steps */
+            float g1 = t1, g2 = t2;
+#pragma unroll
+            for (int step = 0; step < 2; ++step) {
+              const float o1 = __int_as_float(step == 0 ? __builtin_amdgcn_update_dpp(0, __float_as_int(g1), 0xB1, 0xf, 0xf, false)
+                                                        : __builtin_amdgcn_update_dpp(0, __float_as_int(g1), 0x4E, 0xf, 0xf, false));
+              const float o2 = __int_as_float(step == 0 ? __builtin_amdgcn_update_dpp(0, __float_as_int(g2), 0xB1, 0xf, 0xf, false)
+                                                        : __builtin_amdgcn_update_dpp(0, __float_as_int(g2), 0x4E, 0xf, 0xf, false));
+              g2 = fmaxf(fmaxf(g2, o2), fminf(g1, o1));
+              g1 = fmaxf(g1, o1);
+            }
+            /* my users within the tolerance of the window's largest */
+            const float thr = g1 * kTolH;
+            unsigned cm = 0u;
+#pragma unroll
+            for (int k = 0; k < 8 * kMaxGrp; ++k) cm |= (av[k] >= thr && av[k] > 0.0f) ? (1u << k) : 0u;
+            int cnt = __popc(cm);
+            cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, false);
+            cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, false);
+            bool writer = on && cnt == 1 && cm != 0u;
+            int ul = u0 + __ffs((int)cm) - 1; /* (writer: my only survivor) */
+            float la = t1;
+            if (__ballot(on && cnt > 1) != 0ull) {
+              /* several users within the tolerance of each other: the reference's expression, first maximum */
+              int bhi = -1, blo = (int)0x80000000, bu_l = 0;
+              if (on && cnt > 1) {
+                unsigned c2 = cm;
+                while (c2) {
+                  const int j = __ffs((int)c2) - 1;
+                  c2 &= c2 - 1u;
+                  const int u = u0 + j;
+                  const double metric = ((bits & 1) ? s_num[rowp[u]] : 1.0) / ((bits & 2) ? s_avgk[u] : 1.0);
+                  const int hi = __double2hiint(metric), lo = (int)((unsigned)__double2loint(metric) ^ 0x80000000u);
+                  if (hi > bhi || (hi == bhi && lo > blo)) { bhi = hi; blo = lo; bu_l = u; } /* metrics > 0: (high, low unsigned) order */
+                }
+              }
+              const int mhi = quad_max_i(bhi);
+              const int mlo = quad_max_i(bhi == mhi ? blo : (int)0x80000000);
+              const unsigned long long eq = __ballot(on && cnt > 1 && bhi == mhi && blo == mlo);
+              const unsigned quad = (unsigned)(eq >> (lane & ~3)) & 0xfu; /* lanes of my quad that reach the maximum: the lowest wins */
+              if (on && cnt > 1 && (quad & ((1u << q4) - 1u)) == 0u && ((quad >> q4) & 1u)) {
+                writer = true;
+                ul = bu_l;
+                la = numtab[rowp[bu_l]] * rcw[bu_l];
+              }
+            }
+            if (writer) {
+              const int key = rowp[ul];
+              bool held = false;
+              if (!(bits & 2)) {
+                held = true;
+              } else {
+                const double aw = s_avg[ul];
+                const float mu = 0x1p-18f + 2.0f / (1.0f + (float)aw);
+                held = aw >= 64.0 && la >= g1 && g2 * (1.0f + mu) * 1.000001f <= la;
+              }
+              cur_bu[it] = (uint16_t)ul;
+              /* (MaximizeCell rebuilds its records from the winners right before the sort: the sort permutes them in place) */
+              if (SCHED != 9) cur_rec[r * S + sg] = ((uint32_t)key << 16) | ((uint32_t)r << 8) | (uint32_t)sg;
+              if (held) atomicOr(&hold_bits[it >> 6], 1ull << (it & 63));
+              else atomicAnd(&hold_bits[it >> 6], ~(1ull << (it & 63)));
+            }
+          }
+          RS_HSTAMP(1);
+          hold_age += 1;
+        }
+      }
+      if (full) {
+        for (int j0 = wave * 64; j0 < n_items; j0 += nt) {
+          const int j = j0 + lane;
+          bool held = false;
+          if (j < n_items) held = scan_item(j, cur_bu, cur_rec, RsInt<RS_P3_BLOCK_TOP>{});
+          const unsigned long long hm = __ballot(held);
+          if (hold_ok && lane == 0) hold_bits[j0 >> 6] = hm;
+        }
+        hold_age = 0;
+      }
+      hold_full = full;
+#ifdef RS_STAMPS
+      if (tid == 0) sort_sub[6] += (unsigned long long)hold_listed + ((unsigned long long)(full ? 1 : 0) << 32); /* (wave 0's chunk) */
+#endif
+    } else
     if constexpr (SCHED != 11 && !kQSerial) {
       /* fix-up of a speculated TTI: only the items whose speculative winner was served in the previous TTI (listed by the
        * scanning waves) are scanned again, now with the true averages; a list that overflowed means all of them.  One loop
@@ -1338,7 +1581,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       for (int i = tid; i < R * S; i += nt) {
         const int r = SCHED == 10 ? i % R : i / S, sg = SCHED == 10 ? i / R : i % S;
         const int bu = cur_bu[sg * R + r];
-        p.log_keys[((size_t)cell * p.n_ttis + tti) * R * S + r * S + sg] = (cur_rec[i] >> 16) | ((bu == 0xFFFF ? 0u : (uint32_t)bu + 1u) << 8);
+        const uint32_t key = kHoldSched ? (bu == 0xFFFF ? 0u : (uint32_t)s_cqi[r * Upad + bu]) : (cur_rec[i] >> 16);
+        p.log_keys[((size_t)cell * p.n_ttis + tti) * R * S + r * S + sg] = key | ((bu == 0xFFFF ? 0u : (uint32_t)bu + 1u) << 8);
       }
     }
     RS_STAMP(2);
@@ -1364,6 +1608,19 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
          * adaptation.  A phase that meets a barrier every few dozen instructions loses most when the co-resident cell's
          * waves interleave with it (measured with two cells per CU: +5..6 % from the sort's priority alone). */
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (kHoldSched) {
+          if (!hold_full) {
+            /* a TTI that scanned only the listed items: every thread rebuilds the records of the positions it owns in the sort
+             * (the previous sort permuted the array in place) from the winners and the CQI grid */
+            for (int x = tid; x < N; x += nt) {
+              const int r = FIXED ? x / RS_JIT_S : idiv_small(x, S), sg = x - r * S;
+              const int bu = cur_bu[sg * R + r];
+              const uint32_t key = bu == 0xFFFF ? 0u : (uint32_t)s_cqi[r * Upad + bu];
+              s_elems[x] = (key << 16) | ((uint32_t)r << 8) | (uint32_t)sg;
+            }
+            if (EPT == 0) __syncthreads(); /* (the LDS form of the sort reads other positions first) */
+          }
+        }
         if constexpr (EPT > 0) introsort_levels_reg<EPT>(s_elems, N, s_sorted, (int32_t*)sx, m, sort_sub);
         else introsort_loop_levels(s_elems, N, pa, pa + N, sx, sx + N, sx + 2 * N, sx + 3 * N, m);
       }
@@ -1493,6 +1750,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         spec_next = reported && !(((int)(t_next * 1000) - last_sent) >= 40);
       }
     }
+    /* Held winners: the next TTI's quotas need nothing but this TTI's slice offsets (and, with the error model's draws on the
+     * stream, the number of users served): the quota wave, idle during the serial phase, works them out there instead of at the
+     * top of the next TTI, where every wave now has only a few items to scan and the quota wave would be the last to arrive */
+    const bool quota_next = kHoldSched && nwaves >= 2 && tti + 1 < p.n_ttis;
     /* Opt-in (-DRS_COOP_SCAN): MaximizeCell's vector scan with nothing speculated beside it and every wave taking part (the
      * compaction between two vectors is shared, rs_interslice.h); the decisions still fall on wave 0, which keeps the result */
 #ifdef RS_STAMPS
@@ -1525,7 +1786,11 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       int owner = -1;
       int got = 0; /* lane s: RBGs granted to slice s */
       int my_target = 0, my_quota = 0; /* lane s: this TTI's values (the quota wave may overwrite the LDS copies for TTI t+1) */
-      if (kSpecSched) {
+      if (kHoldSched) {
+        hold_served[lane] = 0u; /* (m->hist is free: this TTI's list is consumed, the counting sort is over) */
+        if (lane == 0) *hold_n = 0;
+      }
+      if (kSpecSched || kHoldSched) {
         my_target = m->target[lane];
         my_quota = m->quota[lane];
         /* the other flag set belongs to the NEXT serial phase: its last reader (this TTI's fix-up) is behind a barrier */
@@ -1831,7 +2096,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             my_slice = interslice_maximize_cell<kS, kR>(RS_SCAN_ARGS);
           }
         }
-        if (kSpecSched && spec_next && !p.phy_draws) {
+        if (((kSpecSched && spec_next) || quota_next) && !p.phy_draws) {
           /* slice_rbs_offset_ is final as soon as the RBGs are dealt out (ref: :618-620): the quota wave can start TTI t+1's
            * targets while this wave still looks up the winners and adapts the links */
           if (lane < S) s_sstate[lane] = (double)(my_target - got * G);
@@ -1920,8 +2185,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       served_prev = __popcll(lead_mask);
       /* ref: :618-620 slice_rbs_offset_ = target - final_rbgs*rbg_size */
       if (kTransport && lane < S && !(QUEUE && *q_any == 0))
-        s_sstate[lane] = (double)((kSpecSched ? my_target : m->target[lane]) - got * G);
+        s_sstate[lane] = (double)(((kSpecSched || kHoldSched) ? my_target : m->target[lane]) - got * G);
       if (lane == 0) m->served = served_prev;
+      if (kHoldSched) {
+        if (leader) atomicOr(&hold_served[(owner & 2047) >> 5], 1u << (owner & 31)); /* next TTI: these users' items are scanned again */
+        if (quota_next) { /* slice offsets and the served count are in place: the quota wave may finish TTI t+1's quotas */
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) atomicExch(&fl_cur->greedy_done, 2);
+        }
+      }
       if (kSpecSched && spec_next) {
         /* the allocation is decided: tell the scanning waves who was served (their speculative winners among these need a
          * second look) and let the quota wave start TTI t+1's quotas (slice offsets and the served count are in place) */
@@ -2025,8 +2297,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         size_t row = (size_t)cell * p.n_ttis + tti;
         if (lane < R) p.log_map[row * R + lane] = (int16_t)owner;
         if (lane < S) {
-          if (p.log_quota) p.log_quota[row * S + lane] = (int16_t)(kSpecSched ? my_quota : m->quota[lane]);
-          if (p.log_target) p.log_target[row * S + lane] = (int16_t)(kSpecSched ? my_target : m->target[lane]);
+          if (p.log_quota) p.log_quota[row * S + lane] = (int16_t)((kSpecSched || kHoldSched) ? my_quota : m->quota[lane]);
+          if (p.log_target) p.log_target[row * S + lane] = (int16_t)((kSpecSched || kHoldSched) ? my_target : m->target[lane]);
         }
         if (leader) {
           if (kFlows) { /* two flows of one user may both hold RBGs: the user's row shows their sum */
@@ -2037,6 +2309,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           }
         }
       }
+    }
+    if (quota_next && wave == quota_wave) {
+      /* TTI t+1's draws and remainder rotations need nothing of TTI t (unless the error model's draws, one per UE served, come
+       * first on the shared stream); its targets need the slice offsets wave 0 publishes with the allocation */
+      if (!p.phy_draws) quota_draws(0);
+      const int need_stage = p.phy_draws ? 2 : 1;
+      while (rs_lds_load(&fl_cur->greedy_done) < need_stage) __builtin_amdgcn_s_sleep(RS_SPEC_NAP);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (p.phy_draws) quota_draws(rs_lds_load(&m->served));
+      quota_targets();
     }
     if (kSpecSched && spec_next && wave != 0) {
       /* ---------------- the other waves meanwhile: TTI t+1 as if nobody were served in TTI t ---------------- */
@@ -2108,6 +2390,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     __syncthreads();
     RS_STAMP(8);
     have_spec = kSpecSched && spec_next;
+    have_quota = quota_next;
     served_prev = m->served;
     n_done += 1;
     if (++epoch_pos == p.refresh) { epoch_pos = 0; ++epoch; }

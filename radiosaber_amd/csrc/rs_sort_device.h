@@ -157,7 +157,7 @@ __device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
   return upto_hi & (~0ull << lo);
 }
 
-#ifdef RS_STAMPS
+#if defined(RS_STAMPS) && !defined(RS_STAMPS_HOLD)
 #define RS_SUBSTAMP(i)                                            \
   do {                                                            \
     if (tid == 0) {                                               \

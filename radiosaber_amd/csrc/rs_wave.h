@@ -45,6 +45,19 @@ RS_DEFINE_WAVE_REDUCE(wave_sum, op_add, 0)
 RS_DEFINE_WAVE_REDUCE(wave_max, op_max, (int)0x80000000)
 RS_DEFINE_WAVE_REDUCE(wave_min, op_min, 0x7fffffff)
 
+/* maximum over each 32-lane half of the wave, both halves at once (the ladder stops before row_bcast:31: lanes 31 and 63 hold
+ * their half's maximum).  Every lane of the wave must take part. */
+__device__ __forceinline__ int half_max(int v) {
+  const int identity = (int)0x80000000;
+  RS_DPP_STEP(op_max, 0x111, 0xf, 0xf); /* row_shr:1 */
+  RS_DPP_STEP(op_max, 0x112, 0xf, 0xf); /* row_shr:2 */
+  RS_DPP_STEP(op_max, 0x114, 0xf, 0xe); /* row_shr:4 */
+  RS_DPP_STEP(op_max, 0x118, 0xf, 0xc); /* row_shr:8 */
+  RS_DPP_STEP(op_max, 0x142, 0xa, 0xf); /* row_bcast:15 */
+  const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+  return (threadIdx.x & 32) ? hi : lo;
+}
+
 /* lanes that hold the same BITS-bit value as this lane (valid lanes only): one ballot per bit */
 template <int BITS>
 struct BitBallots {

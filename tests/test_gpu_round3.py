@@ -275,3 +275,50 @@ def test_cpp_multi_gpu_host_reduces_with_rccl_and_matches_the_python_path(rs):
     r = subprocess.run([str(exe), "--cells", "4", "--ttis", "120", "--launches", "1", "--check"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == rs.device_count()
+
+
+# ---------------------------------------------------------------- held winners
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched", [9, 8, 103])
+@pytest.mark.parametrize("case", ["headline", "windows-of-48-and-64", "too-long-for-holding", "psi-0-and-ties", "tiny-and-empty"])
+def test_held_winners_stay_bit_exact(rs, oracle, sched, case):
+    """Shape-specialised kernels of up to 32 RBGs scan only the (slice, RBG) items whose winner can have changed: runs long enough
+    for winners to be held, served, listed and scanned again (CQI epochs of 40 TTIs, several of them), over slice windows of 32,
+    48 and 64 users (one or two groups of 8 users per lane), slices too long for the scheme (it switches itself off), psi = 0
+    slices (winner independent of the averages, exact ties between equal CQIs) and cells with empty / one-user slices."""
+    from test_gpu_parity import _check_batch
+    if case == "headline":
+        _check_batch(rs, oracle, sched, [25] * 20, 25, 4, n_cells=2, n_ttis=250, jit=True, seed=21)
+    elif case == "windows-of-48-and-64":
+        _check_batch(rs, oracle, sched, [40, 33, 56, 7, 49, 50], 25, 4, n_cells=2, n_ttis=170, jit=True, seed=22)
+    elif case == "too-long-for-holding":
+        _check_batch(rs, oracle, sched, [70, 12, 25], 12, 2, n_cells=2, n_ttis=130, jit=True, seed=23)
+    elif case == "psi-0-and-ties":
+        _check_batch(rs, oracle, sched, [25, 25, 9, 30], 25, 4, n_cells=2, n_ttis=170, jit=True, psi=[0, 1, 0, 1], eps=[1, 0, 0, 1], seed=24)
+    else:
+        _check_batch(rs, oracle, sched, [1, 0, 3, 1, 0, 12, 2], 17, 3, n_cells=3, n_ttis=130, jit=True, threads=64, seed=25)
+
+
+@pytest.mark.gpu
+def test_held_winners_across_uneven_launches(rs, oracle):
+    """The held bits live in LDS: every launch starts with a full scan, whatever its length (1-TTI launches, launches that end
+    inside an epoch, launches that span several)."""
+    sc_ues = [25] * 20
+    sc = rs.SliceConfig(sc_ues, weight=[0.05] * 20)
+    R, G, n_cells = 25, 4, 2
+    launches = [1, 2, 37, 41, 80, 3, 60]
+    n_ttis = sum(launches)
+    grids = synth_cqi(31, (n_cells, (n_ttis + 39) // 40, sc.n_users, R), HIST)
+    seeds = np.array([77, 78], np.uint32)
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=9, jit=True)
+    b.seed(seeds)
+    b.upload_cqi_epochs(grids)
+    maps = np.concatenate([b.run_logged(n)["rbg_to_user"] for n in launches], axis=1)
+    st = b.state()
+    b.close()
+    for c in range(n_cells):
+        cell = oracle.Cell(sc_ues, R, G, oracle.SCHED_MAXCELL, weights=[0.05] * 20)
+        logs = cell.run_synth(grids[c], int(seeds[c]), n_ttis)
+        np.testing.assert_array_equal(maps[c], logs["rbg_to_user"])
+        assert st["avg_rate"][c].tobytes() == cell.state()["avg_rate"].tobytes()
