@@ -85,8 +85,12 @@ typedef struct rs_config {
                                    rs_tti_in.hol_delay / prio_has_data (drop-in mode) or from the batch's own queue model
                                    (rs_batch_set_bearers / rs_batch_set_arrivals)                       */
   const int32_t* algo_beta;     /* [S] 0 or 1: with alpha = 1, multiply the metric by the HoL delay  */
-  const int32_t* algo_epsilon;  /* [S] 0 or 1 (pow(x,0)=1, pow(x,1)=x are exact)            */
-  const int32_t* algo_psi;      /* [S] 0 or 1                                               */
+  const int32_t* algo_epsilon;  /* [S] exponent of the rate in pow(se_kbps, epsilon) / pow(avg_kbps, psi) (ref: downlink-transport-
+                                 * scheduler.cpp:690-693).  rs_create (drop-in): any integer in -64..64 -- the host's libm raises
+                                 * the powers (16 numerators per slice once, every user's denominator per call), the device divides
+                                 * and compares exactly.  rs_batch_create: 0 or 1 only (pow(x,0)=1, pow(x,1)=x are exact; the PF
+                                 * averages live on the device, which has no pow())                                        */
+  const int32_t* algo_psi;      /* [S] exponent of the average, same rule                                                  */
   const int32_t* user_to_slice; /* [U] non-decreasing (run-length expansion of ues_per_slice) */
   void* stream;                 /* hipStream_t to launch on, NULL = a stream owned by the context */
 } rs_config;

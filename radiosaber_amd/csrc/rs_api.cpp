@@ -213,6 +213,8 @@ struct rs_batch {
   std::vector<double> weight;
   std::vector<int32_t> eps, psi, u2s, alpha, beta;
   bool any_alpha = false;
+  bool gen_exp = false;      /* drop-in context with an exponent outside {0, 1} (ref: packet-scheduler.h:38-49 takes any int) */
+  double* d_gen_num = nullptr; /* [S][16] pow(kbps[cqi], algo_epsilon[s]), host libm */
   int32_t *d_alpha = nullptr, *d_beta = nullptr;
   int S, U, R, G, sched, n_cells, threads;
   bool direct = false;
@@ -276,8 +278,12 @@ int validate(const rs_config* c, bool direct) {
   for (int s = 0; s < c->n_slices; s++) {
     if ((c->algo_alpha[s] | 1) != 1 || (c->algo_alpha[s] && (!c->algo_beta || (c->algo_beta[s] | 1) != 1)))
       return fail(RS_ERR_INVALID, "slice %d: algo_alpha/algo_beta must be 0 or 1", s);
-    if ((c->algo_epsilon[s] | 1) != 1 || (c->algo_psi[s] | 1) != 1)
-      return fail(RS_ERR_INVALID, "slice %d: algo_epsilon/algo_psi must be 0 or 1", s);
+    /* batches update the PF averages on the device, which has no pow(): exponents 0 and 1 (exact in libm) only; a drop-in context
+     * takes any integers -- the host's libm raises the 16 numerators per slice once and every user's denominator per call */
+    if (!direct && ((c->algo_epsilon[s] | 1) != 1 || (c->algo_psi[s] | 1) != 1))
+      return fail(RS_ERR_INVALID, "slice %d: algo_epsilon/algo_psi must be 0 or 1 in a batch (any integer in a drop-in context)", s);
+    if (c->algo_epsilon[s] < -64 || c->algo_epsilon[s] > 64 || c->algo_psi[s] < -64 || c->algo_psi[s] > 64)
+      return fail(RS_ERR_INVALID, "slice %d: algo_epsilon/algo_psi outside -64..64", s);
   }
   for (int u = 0; u < c->n_users; u++) {
     int s = c->user_to_slice[u];
@@ -398,6 +404,15 @@ int batch_alloc(rs_batch* b) {
     HIP_TRY(hipMalloc(&b->d_tbs_eff, 4 * te.size()));
     HIP_TRY(hipMemcpy(b->d_tbs_eff, te.data(), 4 * te.size(), hipMemcpyHostToDevice));
   }
+  if (b->gen_exp) {
+    /* ref: downlink-transport-scheduler.cpp:688-693  pow(spectralEfficiency * 180000 / 1000, epsilon), with this host's libm --
+     * the library the reference itself calls */
+    std::vector<double> gn((size_t)S * 16, 0.0);
+    for (size_t s = 0; s < S; s++)
+      for (int c = 1; c <= 15; c++) gn[s * 16 + c] = pow(t.kbps[c], b->eps[s]);
+    HIP_TRY(hipMalloc(&b->d_gen_num, 8 * gn.size()));
+    HIP_TRY(hipMemcpy(b->d_gen_num, gn.data(), 8 * gn.size(), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMalloc(&b->d_avg, 8 * cells * U));
   HIP_TRY(hipMalloc(&b->d_tx, 4 * cells * U));
   HIP_TRY(hipMalloc(&b->d_cumb, 8 * cells * U));
@@ -484,6 +499,9 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   b->beta.assign(b->S, 0);
   if (c.algo_beta) b->beta.assign(c.algo_beta, c.algo_beta + b->S);
   for (int s = 0; s < b->S; s++) b->any_alpha |= b->alpha[s] != 0;
+  /* (the per-flow PF scheduler and the NVS sampler do not use the exponents: dl-pf-packet-scheduler.cpp:128-140, nvs :519-520) */
+  for (int s = 0; s < b->S; s++)
+    b->gen_exp |= direct && c.sched != RS_SCHED_PF && c.sched != RS_SCHED_NVS_NONGREEDY && ((b->eps[s] | 1) != 1 || (b->psi[s] | 1) != 1);
   b->u2s.assign(c.user_to_slice, c.user_to_slice + b->U);
   b->cfg.cell.slice_weight = nullptr; b->cfg.cell.algo_alpha = nullptr; b->cfg.cell.algo_beta = nullptr;
   b->cfg.cell.algo_epsilon = nullptr; b->cfg.cell.algo_psi = nullptr; b->cfg.cell.user_to_slice = nullptr;
@@ -568,7 +586,7 @@ void rs_batch_destroy(rs_batch* b) {
   void* ptrs[] = {b->d_tab, b->d_weight, b->d_eps, b->d_psi, b->d_alpha, b->d_beta, b->d_user_slice, b->d_tbs_eff, b->d_avg, b->d_tx, b->d_cumb, b->d_cumr,
                   b->d_sstate, b->d_scal, b->d_epochs, b->d_trace, b->d_user_trace, b->d_err, b->d_slice_bytes, b->d_stamps,
                   b->d_bearer_kind, b->d_arr_off, b->d_arr_time, b->d_arr_nfull, b->d_arr_last, b->d_qi, b->d_bavg, b->d_bcum,
-                  b->d_qflags, b->d_qhol, b->d_epochs_prb, b->d_trace_prb};
+                  b->d_qflags, b->d_qhol, b->d_epochs_prb, b->d_trace_prb, b->d_gen_num};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
@@ -1142,12 +1160,22 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   }
   memset(c->h_in + l.grid + (size_t)n * R, 0, l.slice - (size_t)n * R);
   memcpy(c->h_in + l.avg, in->avg_rate, 8 * (size_t)n);
+  if (b->gen_exp) {
+    /* general exponents: pow(averageRate / 1000.0, psi) with averageRate = 1 + the caller's sum (ref: :681-693), host libm */
+    double* den = (double*)(c->h_in + l.avg);
+    for (int i = 0; i < n; i++) {
+      double k = 1;
+      k += in->avg_rate[i];
+      k /= 1000.0;
+      den[i] = pow(k, b->psi[h_slice[i]]);
+    }
+  }
   /* The metric scan ranks users with an FP32 product first; its error bound needs every factor to be an
    * ordinary FP32 number.  The reference takes any double (downlink-transport-scheduler.cpp:677-713: a non-finite, huge, tiny
    * or negative average simply flows through the division and the strict '>' scan), so inputs outside the safe range switch
    * this call to the exact FP64 scan of every user instead of being rejected.  (The EWMA keeps real averages in [1, ~1e12].) */
-  bool exact_scan = false;
-  {
+  bool exact_scan = b->gen_exp; /* (powers of any size: no FP32 ranking, every user is compared with the reference's expression) */
+  if (!exact_scan) {
     auto ordinary = [](double x, double lo, double hi) { return x >= lo && x <= hi; }; /* false for NaN */
     for (int i = 0; i < n; i++) {
       const double a = in->avg_rate[i];
@@ -1213,6 +1241,8 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   L.draws = dev_in + l.draws;
   L.gate = gate ? (const int32_t*)(dev_in + l.gate) : nullptr;
   L.exact_scan = exact_scan ? 1 : 0;
+  L.gen_exp = b->gen_exp ? 1 : 0;
+  L.gen_num = b->d_gen_num;
   if (b->sched == RS_SCHED_PF) { L.n_seg = (n + RS_PF_SEG - 1) / RS_PF_SEG; L.n_items = R * L.n_seg; }
   L.log_tbs = (int32_t*)(dev_out + l.tbs);
   L.log_uinfo = (int32_t*)(dev_out + l.uinfo);

@@ -214,6 +214,9 @@ struct RsLaunch {
   uint8_t* q_flags;           /* [cells][U] bit 0: prioritized bearer has data, bit 1: user has queued data */
   double* q_hol;              /* [cells][U] head-of-line delay of the slice-priority bearer */
   int32_t exact_scan;        /* drop-in mode: an input lies outside the FP32 filter's safe range -> every user is compared exactly */
+  int32_t gen_exp;           /* drop-in mode: some slice has algo_epsilon / algo_psi outside {0, 1}: `avg` holds pow(avg_kbps, psi) as the
+                              * host's libm gave it, gen_num the numerators, and every user is compared exactly */
+  const double* gen_num;     /* [S][16] pow(eff(cqi) * 180000 / 1000, algo_epsilon of the slice), host libm */
   const int32_t* gate;       /* drop-in mode, optional [U]: m_requiredRBs (sched 7) / dataToTransmit bytes (sched 1); NULL = backlogged */
   int32_t* log_upper;        /* sched 10, drop-in mode: [S][R] (rbg | user << 8), -1 padded; NULL = off */
   const uint8_t* draws;      /* sched 11, drop-in mode: rand() % 4 of the RS_NVS_SAMPLES x U draws, in draw order */

@@ -681,6 +681,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       double k = 1;
       k += a;
       k = div_1000(k);
+      if constexpr (DIRECT) {
+        if (p.gen_exp) k = a; /* general exponents: the caller's block already holds pow(avg_kbps, psi) (host libm) */
+      }
       s_avgk[u] = k;
       const int uo = s_uoff[u];
       /* stage-1 ranking only, never part of a result; psi == 0 slices rank on the numerator */
@@ -831,6 +834,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             double k = 1;
             k += a;
             k = div_1000(k);
+            if constexpr (DIRECT) {
+              if (p.gen_exp) k = a;
+            }
             s_avgk[u] = k;
             const int uo = s_uoff[u];
             float r32 = (uo & 1) ? __builtin_amdgcn_rcpf((float)k) : 1.0f;
@@ -1155,8 +1161,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         bool exact = false; /* `best` is the leader's exact metric */
         int sl_eps = 1, sl_psi = 1;
         int sl_custom = 0; /* 1: alpha slice, 2: alpha slice with the HoL factor */
+        int sl_id = 0;
         if (SCHED != 1) {
           int sl = SCHED == 7 ? (kDirect ? (int)p.user_slice[0] : seg) : seg;
+          sl_id = sl;
           sl_eps = m->eps_psi[sl] & 1;
           sl_psi = (m->eps_psi[sl] >> 1) & 1;
           if (queue_mode_in && (m->eps_psi[sl] & 4)) sl_custom = (SCHED == 7 || (m->eps_psi[sl] & 8) != 0) ? 2 : 1;
@@ -1188,7 +1196,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           /* ref: :688-693  pow(se_kbps, eps) / pow(avg_kbps, psi), eps, psi in {0,1} */
           /* both table reads are issued whatever the slice's exponents are (no branch around an LDS read) */
           const double num_c = s_num[c], den_u = s_avgk[u];
-          const double num = sl_eps ? num_c : 1.0, den = sl_psi ? den_u : 1.0;
+          double num = sl_eps ? num_c : 1.0, den = sl_psi ? den_u : 1.0;
+          if constexpr (DIRECT) {
+            /* pow(se_kbps, epsilon) / pow(avg_kbps, psi) for any integers (ref: :690-693): both powers come from the host's libm
+             * -- 16 numerators per slice at rs_create, the denominator of every user per call -- the device only divides */
+            if (p.gen_exp) { num = p.gen_num[sl_id * 16 + c]; den = den_u; }
+          }
           if (QUEUE && (prio_in[u] & 2) == 0) return -2.0; /* not in UsersToSchedule: below the scan's start value of -1 */
           /* (schedulers 1 and 7 with queues do not come here: serial allocator below) */
           if (sl_custom && prio_in && (prio_in[u] & 1) == 0) return 0.0;
@@ -2017,7 +2030,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
                 valid = valid && metric > 0;
               } else {
                 valid = q_need[u] > 0;
-                const double num = sl_eps ? s_num[cq] : 1.0, den = sl_psi ? s_avgk[u] : 1.0;
+                const double num = p.gen_exp ? p.gen_num[sl7 * 16 + cq] : (sl_eps ? s_num[cq] : 1.0);
+                const double den = p.gen_exp ? s_avgk[u] : (sl_psi ? s_avgk[u] : 1.0);
                 if (!custom7) metric = num / den;
                 else metric = (prio_in && (prio_in[u] & 1) == 0) ? 0.0 : hol_in[u] * num / den;
               }

@@ -1,6 +1,7 @@
 """Round 3: bench.py starting its own ranks, the headline's guards against build switches, arbitrary doubles at the
 drop-in entry point, and the CQI-source bookkeeping the advisor flagged."""
 import json
+import math
 import os
 import subprocess
 import sys
@@ -322,3 +323,92 @@ def test_held_winners_across_uneven_launches(rs, oracle):
         logs = cell.run_synth(grids[c], int(seeds[c]), n_ttis)
         np.testing.assert_array_equal(maps[c], logs["rbg_to_user"])
         assert st["avg_rate"][c].tobytes() == cell.state()["avg_rate"].tobytes()
+
+
+# ---------------------------------------------------------------- pow() with any integer exponents (drop-in mode)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched", [9, 8, 10, 101, 103])
+@pytest.mark.parametrize("custom", [False, True])
+def test_drop_in_general_integer_exponents(rs, oracle, sched, custom):
+    """ref: downlink-transport-scheduler.cpp:690-693 evaluates pow(se_kbps, epsilon) / pow(avg_kbps, psi) for ANY integers
+    (packet-scheduler.h:38-49).  A drop-in context takes them: the host's libm (the one the reference and the oracle call) raises
+    the 16 numerators per slice at rs_create and every user's denominator per call, the device divides and compares exactly.
+    Batches (PF averages updated on the device) keep exponents 0 / 1 and say so."""
+    ues = [7, 9, 4, 8, 6, 5]
+    alpha = [0, 1, 1, 1, 1, 0] if custom else [0] * 6
+    beta = [0, 0, 1, 1, 1, 0] if custom else [0] * 6
+    eps = [2, 1, 3, -1, 0, 5]
+    psi = [1, 2, -2, 3, 2, 0]
+    S, R, G = len(ues), 25, 4
+    w = [1.0 / S] * S
+    sc = rs.SliceConfig(ues, weight=w, algo_alpha=alpha, algo_beta=beta, algo_epsilon=eps, algo_psi=psi)
+    U = sc.n_users
+    ts = rs.TtiScheduler(sc, R, G, sched=sched)
+    cell = oracle.Cell(ues, R, G, sched, weights=w, epsilon=eps, psi=psi, alpha=alpha, beta=beta)
+    rng = np.random.default_rng(50 + sched)
+    differs = 0
+    for it in range(12):
+        cqi = synth_cqi(1500 + it, (U, R), HIST)
+        avg = np.exp(rng.uniform(np.log(1.0), np.log(5e7), U)) if it % 3 else rng.choice([1.0, 98000.0, 1e5], U)  # ties too
+        hol = rng.uniform(1e-5, 0.2, U)
+        prio = (rng.random(U) < 0.8).astype(np.uint8)
+        r0, r1 = int(rng.integers(0, 2**31 - 1)), int(rng.integers(0, 2**31 - 1))
+        cell.set_cqi(cqi)
+        if custom:
+            cell.set_queue_state(hol, prio)
+        out = cell.new_out()
+        assert cell.allocate(avg, r0, r1, out) == 0
+        kw = dict(hol_delay=hol, prio_has_data=prio) if custom else {}
+        res = ts.schedule_tti(cqi, avg, r0, r1, **kw)
+        np.testing.assert_array_equal(res.rbg_to_user, out.rbg_to_user, err_msg=f"it {it}")
+        np.testing.assert_array_equal(res.quota_rbgs, out.quota_rbgs)
+        np.testing.assert_array_equal(res.user_nprb, out.user_nprb)
+        np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits)
+        # the exponents matter: the plain PF metric would have chosen differently
+        if sched == 9 and it == 1 and not custom:
+            sc1 = rs.SliceConfig(ues, weight=w)
+            t1 = rs.TtiScheduler(sc1, R, G, sched=sched)
+            differs += int((t1.schedule_tti(cqi, avg, r0, r1).rbg_to_user != res.rbg_to_user).any())
+            t1.close()
+    ts.close()
+    if sched == 9 and not custom:
+        assert differs, "exponents (2, 1, 3, -1, 0, 5) / (1, 2, -2, 3, 2, 0) chose like (1, 1): the test does not exercise them"
+    # a batch keeps the restriction and says why
+    with pytest.raises(rs.RadioSaberError, match="0 or 1 in a batch"):
+        rs.BatchScheduler(sc, R, G, 1, sched=sched)
+
+
+@pytest.mark.gpu
+def test_drop_in_nvs_general_exponents(rs, oracle):
+    """sched 7 with exponents outside {0, 1} (downlink-nvs-scheduler.cpp:360-390: the same pow expression), with and without the
+    m_requiredRBs gate."""
+    ues, R, G = [8, 6, 9], 25, 4
+    eps, psi = [3, -1, 2], [2, 2, -1]
+    sc = rs.SliceConfig(ues, weight=[0.3, 0.3, 0.4], algo_epsilon=eps, algo_psi=psi)
+    ts = rs.TtiScheduler(sc, R, G, sched=7)
+    kb = np.asarray(rs.link_tables()["kbps"])
+    rng = np.random.default_rng(8)
+    first = np.concatenate([[0], np.cumsum(ues)])
+    for it in range(9):
+        s = it % 3
+        n = ues[s]
+        ids = np.arange(first[s], first[s] + n, dtype=np.int32)
+        cqi = synth_cqi(1700 + it, (n, R), HIST)
+        avg = np.exp(rng.uniform(np.log(1.0), np.log(5e7), n))
+        need = rng.integers(0, 40, n).astype(np.int32) if it % 2 else None
+        res = ts.schedule_tti(cqi, avg, user_id=ids, **({"required_rbs": need} if need is not None else {}))
+        # libm's pow, element by element: numpy's vectorised power is a different implementation (last-bit differences)
+        num = np.array([[math.pow(float(kb[c]), eps[s]) for c in row] for row in cqi])
+        den = np.array([math.pow((1.0 + float(a)) / 1000.0, psi[s]) for a in avg])
+        met = num / den[:, None]
+        left = need.copy() if need is not None else np.full(n, 1 << 30)
+        want = np.full(R, -1)
+        for r in range(R):
+            ok = left > 0
+            if ok.any():
+                k = int(np.flatnonzero(ok)[np.argmax(met[ok, r])])
+                want[r] = ids[k]
+                left[k] -= G
+        np.testing.assert_array_equal(res.rbg_to_user, want, err_msg=f"it {it}")
+    ts.close()
