@@ -283,6 +283,12 @@ int rs_trace_load_dir(const char* dir, int32_t n_traces, int32_t n_rows, int32_t
  * downlink-packet-scheduler.cpp:221-265; rbg_to_user then holds flow ids 2 * user + bearer and DoStopSchedule credits whole
  * transport blocks, dl-pf-packet-scheduler.cpp:60-125).  The applications themselves stay outside: the caller hands in every
  * bearer's arrival bursts.
+ * Restriction: a batch's band is exactly n_rbgs * rbg_size PRBs.  The reference's wideband CQI behind m_requiredRBs
+ * (packet-scheduler.cpp:321-327) runs over cqiFeedbacks.size() = every PRB of the band, including the nb_rbs % rbg_size
+ * trailing PRBs that are never allocated (25 PRBs with RBGs of 2, 50 with 3, 75 with 4); a batch has no such PRBs, so scheduler 7
+ * with queues matches the reference on bands whose PRB count is a multiple of the RBG size -- every shipped configuration
+ * (100 MHz: 512 PRBs in RBGs of 8; the trace grid).
+ * Round 3: a launch keeps the bearers' hot words in LDS (156 B per user) when the cell still fits the CU's 160 KB, else in HBM.
  * ------------------------------------------------------------------------------------------ */
 /* bearer_kind [U][2], index = bearer priority (RadioBearer::GetPriority, radio-bearer.cpp:88-97): 0 none, 1 InfiniteBuffer
  * (always has packets, dataToTransmit 1e8), 2 finite MAC queue.  Every user needs at least one bearer.  Before the first run. */
