@@ -220,7 +220,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #elif defined(RS_HOLD_ALWAYS)
   constexpr bool kHoldSched = FIXED && !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
 #else
-  constexpr bool kHoldSched = FIXED && RS_JIT_R <= 32 && !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
+  /* (MaximizeCell's kernel carries the sort and is register-bound: with slice windows above 32 users the listed items' scan keeps
+   * 16 products per lane and spills -- 28.3 against 29.4 M TTIs/s at 50 UEs per slice -- so it holds winners up to 32 only) */
+  constexpr bool kHoldSched = FIXED && RS_JIT_R <= 32 && !DIRECT && !QUEUE &&
+                              (SCHED == 8 || SCHED == 101 || SCHED == 103 || (SCHED == 9 && RS_JIT_WIN > 0 && RS_JIT_WIN <= 32));
 #endif
 #ifdef RS_NO_SPEC
   constexpr bool kSpecSched = false;
@@ -361,16 +364,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #endif
   unsigned long long* const hold_bits = (unsigned long long*)(lds + o.items + ((2 * o.n_items + 7) & ~7));
   uint32_t* const hold_served = (uint32_t*)m->hist; /* [64] */
-  uint16_t* const hold_list = m->hist + 128;        /* RS_HOLD_CAP entries: the items to scan again */
-  int32_t* const hold_n = &m->spec[0].n_fix;
-#define RS_HOLD_CAP 896
+  uint16_t* const hold_list = m->hist + 128;        /* 64 entries per wave: the items a wave scans again */
   int hold_win = 0; /* the longest 8-aligned slice window: 32 or 64 lanes per listed item (longer: no held winners) */
   if (kHoldSched) {
     int w = 0;
     if (lane < S && m->seg_begin[lane + 1] > m->seg_begin[lane]) w = ((m->seg_begin[lane + 1] + 7) & ~7) - (m->seg_begin[lane] & ~7);
     hold_win = wave_max(w);
   }
-  const bool hold_ok = kHoldSched && o.n_items >= 8 && hold_win > 0 && hold_win <= 64 && U <= 2048 &&
+  /* (one word of held bits per wave and 64 * nwaves items, behind the winners: it must fit the second winner buffer's place) */
+  const bool hold_ok = kHoldSched && hold_win > 0 && hold_win <= 64 && U <= 2048 &&
+                       8 * nwaves * ((o.n_items + 64 * nwaves - 1) / (64 * nwaves)) + 8 <= 2 * o.n_items &&
                        (!(FIXED && RS_JIT_WIN > 0) || hold_win <= RS_JIT_WIN);
   int hold_age = 0;
 
@@ -1400,8 +1403,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     if constexpr (kHoldSched) {
       /* ---- held winners: scan only what can have changed ---- */
       /* The items to scan again -- winner not held, or served in the previous TTI (a psi = 0 slice ignores the averages) -- are
-       * listed (one ballot + one LDS atomic per wave; a served user leads many RBGs of ONE slice, so the items cluster: wave-
-       * private lists left some wave with two passes in most TTIs) and, after a barrier, dealt out evenly: FOUR LANES PER ITEM,
+       * packed into a wave-private list (items are dealt to the waves round robin: no shared list, no atomics, no workgroup
+       * barrier) and scanned FOUR LANES PER ITEM,
        * 8 (or 16) users of the slice's zero-padded window per lane: the stage-1 products as in scan_item, the window's two
        * largest by two-step butterflies inside the lane quad, then the lane that holds the only user within 2^-19 of the
        * largest writes the winner (no division); several such users are compared exactly, ascending, strict '>'.
@@ -1427,36 +1430,28 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           int o2 = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
           return v > o2 ? v : o2;
         };
-        for (int it0 = wave * 64; it0 < n_items; it0 += nt) {
-          const int it_l = it0 + lane;
+        uint16_t* const wl = hold_list + wave * 64; /* this wave's list */
+        for (int k0 = 0; k0 * nwaves < n_items; k0 += 64) {
+          /* items are dealt to the waves round robin (item = k * nwaves + wave): the items a served user leads are neighbours
+           * (one slice, many RBGs), so every wave gets its share of them and one pass of 16 normally does */
+          const int it_l = (k0 + lane) * nwaves + wave;
           const bool in = it_l < n_items;
           const int w = in ? (int)cur_bu[it_l] : 0xFFFF;
-          const bool held_bit = ((hold_bits[it0 >> 6] >> lane) & 1ull) != 0ull;
+          const bool held_bit = ((hold_bits[(k0 >> 6) * nwaves + wave] >> lane) & 1ull) != 0ull;
           const int sg_l = FIXED ? it_l / RS_JIT_R : idiv_small(in ? it_l : 0, R);
           const bool psi_on = (m->eps_psi[in ? sg_l : 0] & 2) != 0;
           const bool was_served = w != 0xFFFF && ((hold_served[(w & 2047) >> 5] >> (w & 31)) & 1u) != 0u;
           const bool need = in && w != 0xFFFF && (!held_bit || (was_served && psi_on));
           const unsigned long long mk = __ballot(need);
-          if (mk != 0ull) {
-            int slot0 = 0;
-            if (lane == 0) slot0 = atomicAdd(hold_n, __popcll(mk));
-            slot0 = __builtin_amdgcn_readfirstlane(slot0);
-            const int slot = slot0 + __popcll(mk & ((1ull << lane) - 1ull));
-            if (need && slot < RS_HOLD_CAP) hold_list[slot] = (uint16_t)it_l;
-          }
-        }
-        __syncthreads();
-        const int n_list = rs_lds_load(hold_n);
-        hold_listed = n_list;
-        RS_HSTAMP(0);
-        if (n_list > RS_HOLD_CAP) {
-          full = true; /* (too many to list: everything is scanned, as at the start of a run, when all averages are equal) */
-        } else {
-          /* list entry e goes to wave e mod nwaves, quad e / nwaves: every wave gets its share in the same pass */
-          for (int base = 0; base * nwaves < n_list; base += 16) {
-            const int e = (base + grp) * nwaves + wave;
-            const bool on = e < n_list;
-            const int it = on ? (int)hold_list[e] : 0;
+          const int n_list = __popcll(mk);
+          hold_listed += n_list;
+          if (need) wl[__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)it_l;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          RS_HSTAMP(0);
+          for (int base = 0; base < n_list; base += 16) {
+            const bool on = base + grp < n_list;
+            const int it = on ? (int)wl[base + grp] : 0;
             const int sg = FIXED ? it / RS_JIT_R : idiv_small(it, R), r = it - sg * R;
             const int ub = m->seg_begin[sg], ue = m->seg_begin[sg + 1];
             const int bits = m->eps_psi[sg];
@@ -1550,21 +1545,26 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               cur_bu[it] = (uint16_t)ul;
               /* (MaximizeCell rebuilds its records from the winners right before the sort: the sort permutes them in place) */
               if (SCHED != 9) cur_rec[r * S + sg] = ((uint32_t)key << 16) | ((uint32_t)r << 8) | (uint32_t)sg;
-              if (held) atomicOr(&hold_bits[it >> 6], 1ull << (it & 63));
-              else atomicAnd(&hold_bits[it >> 6], ~(1ull << (it & 63)));
+              /* (item = k * nwaves + wave: bit k & 63 of this wave's word k >> 6; the quads of one wave write it side by side) */
+              const int kk = FIXED ? it / (RS_JIT_NT / 64) : idiv_small(it, nwaves);
+              unsigned long long* const word = &hold_bits[(kk >> 6) * nwaves + wave];
+              if (held) atomicOr(word, 1ull << (kk & 63));
+              else atomicAnd(word, ~(1ull << (kk & 63)));
             }
           }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
           RS_HSTAMP(1);
-          hold_age += 1;
         }
+        hold_age += 1;
       }
       if (full) {
-        for (int j0 = wave * 64; j0 < n_items; j0 += nt) {
-          const int j = j0 + lane;
+        for (int k0 = 0; k0 * nwaves < n_items; k0 += 64) { /* the same dealing of the items as above */
+          const int j = (k0 + lane) * nwaves + wave;
           bool held = false;
           if (j < n_items) held = scan_item(j, cur_bu, cur_rec, RsInt<RS_P3_BLOCK_TOP>{});
           const unsigned long long hm = __ballot(held);
-          if (hold_ok && lane == 0) hold_bits[j0 >> 6] = hm;
+          if (hold_ok && lane == 0) hold_bits[(k0 >> 6) * nwaves + wave] = hm;
         }
         hold_age = 0;
       }
@@ -1800,8 +1800,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       int got = 0; /* lane s: RBGs granted to slice s */
       int my_target = 0, my_quota = 0; /* lane s: this TTI's values (the quota wave may overwrite the LDS copies for TTI t+1) */
       if (kHoldSched) {
-        hold_served[lane] = 0u; /* (m->hist is free: this TTI's list is consumed, the counting sort is over) */
-        if (lane == 0) *hold_n = 0;
+        hold_served[lane] = 0u; /* (m->hist is free: this TTI's lists are consumed, the counting sort is over) */
       }
       if (kSpecSched || kHoldSched) {
         my_target = m->target[lane];
