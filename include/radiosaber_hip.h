@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 8 /* 8: rs_jit_selfcheck_queue; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
+#define RS_ABI_VERSION 8 /* 8: rs_jit_selfcheck_queue, rs_config.synthetic_exp, any integer algo_epsilon / algo_psi in drop-in contexts; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
                             6: rs_tti_in.required_rbs / data_to_transmit (the gates of schedulers 7 and 1 in the drop-in mode);
                             5: per-PRB batch sources (rs_batch_upload_cqi_epochs_prb, rs_batch_set_trace_prb);
                             4: finite queues in batches (rs_batch_set_bearers, rs_batch_set_arrivals, rs_batch_read_bearer_state, rs_internet_flow_arrivals);
@@ -93,6 +93,11 @@ typedef struct rs_config {
   const int32_t* algo_psi;      /* [S] exponent of the average, same rule                                                  */
   const int32_t* user_to_slice; /* [U] non-decreasing (run-length expansion of ues_per_slice) */
   void* stream;                 /* hipStream_t to launch on, NULL = a stream owned by the context */
+  int32_t synthetic_exp;        /* 0 (as shipped), or 1 = the reference built with FIRST_SYNTHETIC_EXP / SECOND_SYNTHETIC_EXP
+                                 * (CONFIG/global_config:57-58): schedulers 7, 8, 9, 10, 101, 103 size a transport block PRB by
+                                 * PRB, each with the MCS of its own CQI (downlink-transport-scheduler.cpp:653-659,
+                                 * downlink-nvs-scheduler.cpp:336-342; the PDCCH record keeps the EESM MCS); schedulers 1 and 11 have
+                                 * no such branch and ignore it.  (ABI 8)                                                      */
 } rs_config;
 
 const char* rs_last_error(void);   /* thread-local message of the last failing call */

@@ -73,6 +73,10 @@ void DownlinkGpuNVSScheduler::RBsAllocation() {
     cfg.algo_psi = psi_.data();
     cfg.user_to_slice = user_to_slice_.data();
     cfg.stream = NULL;
+    cfg.synthetic_exp = 0;
+#if defined(FIRST_SYNTHETIC_EXP) || defined(SECOND_SYNTHETIC_EXP)
+    cfg.synthetic_exp = 1; /* downlink-nvs-scheduler.cpp:336-342 (the sampler of :405-528 has no such branch: ignored there) */
+#endif
     ctx_ = rs_create(&cfg);
     if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
     nb_rbs_ = nb_rbs;

@@ -73,6 +73,10 @@ void DownlinkGpuScheduler::LazyCreate(int nb_rbs, int rbg_size) {
   cfg.algo_psi = psi_.data();
   cfg.user_to_slice = user_to_slice_.data();
   cfg.stream = NULL;
+  cfg.synthetic_exp = 0;
+#if defined(FIRST_SYNTHETIC_EXP) || defined(SECOND_SYNTHETIC_EXP)
+  cfg.synthetic_exp = 1; /* the parent's transport block, :653-659 */
+#endif
   ctx_ = rs_create(&cfg);
   if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
   nb_rbs_ = nb_rbs;

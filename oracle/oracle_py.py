@@ -80,6 +80,7 @@ def lib():
         L.rso_cell_set_cqi_prb.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         L.rso_cell_set_queue_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint8)]
         L.rso_cell_set_last_update.argtypes = [C.c_void_p, C.c_double]
+        L.rso_cell_set_synthetic_exp.argtypes = [C.c_void_p, C.c_int]
         L.rso_cell_set_avg_rate.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.rso_cell_set_second_bearer_avg.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.rso_cell_step.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(_TtiOut)]
@@ -241,6 +242,9 @@ class Cell:
         a = np.ascontiguousarray(prb, np.uint8)
         assert a.shape == (self.U, self.R * self.rbg_size)
         lib().rso_cell_set_cqi_prb(self.h, _p(a, C.c_uint8))
+
+    def set_synthetic_exp(self, on=True):
+        lib().rso_cell_set_synthetic_exp(self.h, 1 if on else 0)
 
     def set_queue_state(self, hol, prio_has_data):
         h = np.ascontiguousarray(hol, np.float64)

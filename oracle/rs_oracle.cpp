@@ -270,6 +270,7 @@ void rso_subopt(const double* eff, const int* quota_in, int R, int S, int* rbg_t
 
 struct rso_cell {
   int S, U, R, rbg_size, sched;
+  int synthetic = 0; /* the reference's FIRST/SECOND_SYNTHETIC_EXP transport block (rso_cell_set_synthetic_exp) */
   std::vector<double> w;
   std::vector<int> alpha, beta, eps, psi, u2s;
   /* per-bearer PF state (ref: flows/radio-bearer.h:81-85) */
@@ -353,6 +354,7 @@ void rso_cell_set_user_cqi(rso_cell* c, int user, const uint8_t* row) {
   memcpy(&c->cqi[(size_t)user * c->R], row, c->R);
 }
 void rso_cell_set_last_update(rso_cell* c, double t) { c->last_update.assign(c->U, t); }
+void rso_cell_set_synthetic_exp(rso_cell* c, int on) { c->synthetic = on ? 1 : 0; }
 /* queue state the customised (alpha = 1) slice metrics read: downlink-transport-scheduler.cpp:694-711 */
 void rso_cell_set_queue_state(rso_cell* c, const double* hol, const uint8_t* prio_has_data) {
   c->hol.assign(hol, hol + c->U);
@@ -420,6 +422,21 @@ double slice_metric(const rso_cell* c, int slice, double se, double avg_rate, in
 /* link adaptation tail shared by all schedulers
  * (ref: downlink-transport-scheduler.cpp:630-674, downlink-nvs-scheduler.cpp:313-357,
  *  downlink-packet-scheduler.cpp:268-322): per user, PRBs in RBG-ascending order. */
+/* the reference's FIRST_SYNTHETIC_EXP / SECOND_SYNTHETIC_EXP build (CONFIG/global_config:57-58, off as shipped): the transport
+ * block "as if the user can have multiple mcs" -- every allocated PRB with the MCS of its own CQI
+ * (ref: downlink-transport-scheduler.cpp:653-659, downlink-nvs-scheduler.cpp:336-342; the per-flow PF scheduler and the NVS sampler
+ * have no such branch) */
+static bool synthetic_tb(const rso_cell* c) {
+  return c->synthetic && (c->sched == RSO_SCHED_NVS || c->sched == RSO_SCHED_SEQUENTIAL || c->sched == RSO_SCHED_MAXCELL ||
+                          c->sched == RSO_SCHED_SUBOPT || c->sched == RSO_SCHED_VOGEL || c->sched == RSO_SCHED_UPPERBOUND);
+}
+static int synthetic_tbs_bits(const uint8_t* prb, int n) {
+  int tbs = 0;
+  for (int i = 0; i < n; i++) /* GetTBSizeFromMCS(GetMCSFromCQI(GetCQIFromSinr(estimatedSinrValues[i])), 1) */
+    tbs += rso_tbs_bits(kCqiToMcs[rso_cqi_from_sinr(kSinrForCqi[prb[i] - 1]) - 1], 1);
+  return tbs;
+}
+
 void link_adaptation(const rso_cell* c, const int* rbg_to_user, rso_tti_out* out) {
   const int U = c->U, R = c->R, G = c->rbg_size;
   for (int u = 0; u < U; u++) {
@@ -437,7 +454,7 @@ void link_adaptation(const rso_cell* c, const int* rbg_to_user, rso_tti_out* out
     out->user_nprb[u] = (int)prb.size();
     out->user_final_cqi[u] = fc;
     out->user_mcs[u] = mcs;
-    out->user_tbs_bits[u] = rso_tbs_bits(mcs, (int)prb.size());
+    out->user_tbs_bits[u] = synthetic_tb(c) ? synthetic_tbs_bits(prb.data(), (int)prb.size()) : rso_tbs_bits(mcs, (int)prb.size());
   }
 }
 
@@ -457,7 +474,7 @@ void link_adaptation_lists(const rso_cell* c, const std::vector<std::vector<int>
     out->user_nprb[u] = (int)prb.size();
     out->user_final_cqi[u] = fc;
     out->user_mcs[u] = mcs;
-    out->user_tbs_bits[u] = rso_tbs_bits(mcs, (int)prb.size());
+    out->user_tbs_bits[u] = synthetic_tb(c) ? synthetic_tbs_bits(prb.data(), (int)prb.size()) : rso_tbs_bits(mcs, (int)prb.size());
   }
 }
 

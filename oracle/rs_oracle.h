@@ -115,6 +115,10 @@ void rso_cell_set_user_cqi(rso_cell* c, int user, const uint8_t* cqi_row);
 void rso_cell_set_cqi_prb(rso_cell* c, const uint8_t* cqi_prb);
 /* bearer creation instant (RadioBearer ctor -> ResetTransmittedBytes: lastUpdate = Now) */
 void rso_cell_set_last_update(rso_cell* c, double t);
+/* the reference built with FIRST_SYNTHETIC_EXP / SECOND_SYNTHETIC_EXP (CONFIG/global_config:57-58, off as shipped): schedulers 7, 8,
+ * 9, 10, 101, 103 size the transport block PRB by PRB, each with the MCS of its own CQI
+ * (downlink-transport-scheduler.cpp:653-659, downlink-nvs-scheduler.cpp:336-342) */
+void rso_cell_set_synthetic_exp(rso_cell* c, int on);
 /* alpha != 0 slices: head-of-line delay and "prioritized bearer has data" per user */
 void rso_cell_set_queue_state(rso_cell* c, const double* hol, const uint8_t* prio_has_data);
 /* one TTI of DoSchedule(): EWMA update at time `now`, RBsAllocation with the two rand() values,

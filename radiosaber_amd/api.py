@@ -42,7 +42,7 @@ class _Config(C.Structure):
                 ("slice_weight", C.POINTER(C.c_double)), ("algo_alpha", C.POINTER(C.c_int32)),
                 ("algo_beta", C.POINTER(C.c_int32)), ("algo_epsilon", C.POINTER(C.c_int32)),
                 ("algo_psi", C.POINTER(C.c_int32)), ("user_to_slice", C.POINTER(C.c_int32)),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("synthetic_exp", C.c_int32)]
 
 
 class _BatchConfig(C.Structure):
@@ -362,7 +362,7 @@ class SliceConfig:
 class _CfgHolder:
     """Keeps the numpy arrays a C rs_config points at alive."""
 
-    def __init__(self, slices: SliceConfig, n_rbgs, rbg_size, sched, device, stream):
+    def __init__(self, slices: SliceConfig, n_rbgs, rbg_size, sched, device, stream, synthetic_exp=False):
         self.w = np.ascontiguousarray(slices.weight, np.float64)
         self.a = np.ascontiguousarray(slices.algo_alpha, np.int32)
         self.b = np.ascontiguousarray(slices.algo_beta, np.int32)
@@ -372,7 +372,7 @@ class _CfgHolder:
         self.c = _Config(slices.n_slices, slices.n_users, n_rbgs, rbg_size, sched, device,
                          _p(self.w, C.c_double), _p(self.a, C.c_int32), _p(self.b, C.c_int32),
                          _p(self.e, C.c_int32), _p(self.p, C.c_int32), _p(self.u2s, C.c_int32),
-                         C.c_void_p(stream or 0))
+                         C.c_void_p(stream or 0), int(bool(synthetic_exp)))
 
 
 @dataclass
@@ -392,9 +392,9 @@ class TtiScheduler:
     """Drop-in mode: RBsAllocation() of one TTI on the GPU (rs_create / rs_schedule_tti)."""
 
     def __init__(self, slices: SliceConfig, n_rbgs: int, rbg_size: int, sched: int = RS_SCHED_MAXCELL,
-                 device: int = 0, stream: Optional[int] = None):
+                 device: int = 0, stream: Optional[int] = None, synthetic_exp: bool = False):
         self.slices, self.R, self.rbg_size, self.sched = slices, n_rbgs, rbg_size, sched
-        self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream)
+        self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream, synthetic_exp)
         self._h = lib().rs_create(C.byref(self._cfg.c))
         if not self._h:
             raise RadioSaberError(-1, lib().rs_last_error().decode())
@@ -472,10 +472,11 @@ class BatchScheduler:
     def __init__(self, slices: SliceConfig, n_rbgs: int, rbg_size: int, n_cells: int,
                  sched: int = RS_SCHED_MAXCELL, device: int = 0, first_tti: int = 100, cqi_refresh: int = 40,
                  phy_error_draws: bool = False, threads_per_cell: int = 0, stream: Optional[int] = None,
-                 jit: bool = False):
+                 jit: bool = False, synthetic_exp: bool = False):
+        """synthetic_exp: the reference built with FIRST/SECOND_SYNTHETIC_EXP (transport blocks PRB by PRB; rs_config.synthetic_exp)."""
         self.slices, self.R, self.rbg_size, self.sched, self.n_cells = slices, n_rbgs, rbg_size, sched, n_cells
         self.S, self.U = slices.n_slices, slices.n_users
-        self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream)
+        self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream, synthetic_exp)
         bc = _BatchConfig(self._cfg.c, n_cells, first_tti, cqi_refresh, int(phy_error_draws), threads_per_cell,
                           int(jit))
         self._h = lib().rs_batch_create(C.byref(bc))

@@ -213,6 +213,7 @@ struct rs_batch {
   std::vector<double> weight;
   std::vector<int32_t> eps, psi, u2s, alpha, beta;
   bool any_alpha = false;
+  bool synthetic = false;    /* rs_config.synthetic_exp */
   bool gen_exp = false;      /* drop-in context with an exponent outside {0, 1} (ref: packet-scheduler.h:38-49 takes any int) */
   double* d_gen_num = nullptr; /* [S][16] pow(kbps[cqi], algo_epsilon[s]), host libm */
   int32_t *d_alpha = nullptr, *d_beta = nullptr;
@@ -270,6 +271,7 @@ int validate(const rs_config* c, bool direct) {
   if (c->n_rbgs < 1 || c->n_rbgs > RS_MAX_RBGS) return fail(RS_ERR_INVALID, "n_rbgs %d outside 1..%d", c->n_rbgs, RS_MAX_RBGS);
   if (c->rbg_size < 1 || c->rbg_size > 8) return fail(RS_ERR_INVALID, "rbg_size %d outside 1..8", c->rbg_size);
   if (c->n_rbgs * c->rbg_size > 512) return fail(RS_ERR_INVALID, "more than 512 PRBs (reference get_rbg_size throws)");
+  if ((c->synthetic_exp | 1) != 1) return fail(RS_ERR_INVALID, "synthetic_exp %d is not 0 or 1 (an rs_config of an older ABI? it gained the field in ABI 8)", c->synthetic_exp);
   if (c->sched != RS_SCHED_PF && c->sched != RS_SCHED_NVS && c->sched != RS_SCHED_SEQUENTIAL && c->sched != RS_SCHED_MAXCELL &&
       c->sched != RS_SCHED_VOGEL && c->sched != RS_SCHED_SUBOPT && c->sched != RS_SCHED_UPPERBOUND && c->sched != RS_SCHED_NVS_NONGREEDY)
     return fail(RS_ERR_INVALID, "sched %d not supported (1, 7, 8, 9, 10, 11, 101, 103)", c->sched);
@@ -367,6 +369,11 @@ int batch_alloc(rs_batch* b) {
     t.mcs_of_cqi[c] = kCqiToMcs[c - 1];
     t.itbs_of_cqi[c] = kMcsToItbs[kCqiToMcs[c - 1]];
     t.tbs1_of_cqi[c] = kTbs[0][kMcsToItbs[kCqiToMcs[c - 1]]];
+    /* ref: downlink-transport-scheduler.cpp:643-658 with AMCModule.cpp:253-268: the PRB's SINR is the table value of its CQI, and
+     * the CQI read back from it counts the thresholds at or below it */
+    int rt = 1;
+    while (rt <= 14 && kSinrForCqi[rt] <= kSinrForCqi[c - 1]) rt++;
+    t.tbs1_syn[c] = kTbs[0][kMcsToItbs[kCqiToMcs[rt - 1]]];
   }
   /* AMCModule.cpp:313-315 reads TransportBlockSizeTable[-1][itbs] when nbRBs > 110 and nbRBs % 5 == 0.
    * In the as-shipped -O0 build McsToItbs[29] sits 128 bytes in front of the table, so
@@ -446,6 +453,7 @@ int batch_alloc(rs_batch* b) {
   L.alpha = b->d_alpha; L.beta = b->d_beta;
   L.user_slice = b->d_user_slice;
   L.tbs_eff = b->d_tbs_eff;
+  L.synthetic = b->synthetic ? 1 : 0;
   L.avg = b->d_avg; L.tx_bytes = b->d_tx; L.cum_bytes = b->d_cumb; L.cum_rbs = b->d_cumr;
   L.slice_state = b->d_sstate; L.scal = b->d_scal; L.err = b->d_err; L.stamps = b->d_stamps;
   carve_lds(b, &L);
@@ -498,6 +506,7 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   b->alpha.assign(c.algo_alpha, c.algo_alpha + b->S);
   b->beta.assign(b->S, 0);
   if (c.algo_beta) b->beta.assign(c.algo_beta, c.algo_beta + b->S);
+  b->synthetic = c.synthetic_exp != 0;
   for (int s = 0; s < b->S; s++) b->any_alpha |= b->alpha[s] != 0;
   /* (the per-flow PF scheduler and the NVS sampler do not use the exponents: dl-pf-packet-scheduler.cpp:128-140, nvs :519-520) */
   for (int s = 0; s < b->S; s++)

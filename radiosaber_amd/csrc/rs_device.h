@@ -51,7 +51,7 @@ struct RsMisc {
   int32_t n_level[48];           /* level-synchronous introsort: live sub-ranges per recursion level */
   uint16_t hist[64 * 16];        /* counting sort: per 64-element chunk, per key */
   int32_t mcs_of_cqi[16];
-  int32_t itbs_of_cqi[16];
+  int32_t tbs1_of_cqi[16];       /* TBS bits of ONE PRB at a CQI (the synthetic-experiment transport block) */
   int32_t served;
   int32_t nvs_slice;
   int32_t pad[2];
@@ -160,6 +160,8 @@ struct RsTables {
   int32_t itbs_of_cqi[16];
   int32_t tbs_row_m1[28]; /* the reference's T[-1][itbs] at -O0 (see rs_kernels.hip)  */
   int32_t tbs1_of_cqi[16]; /* TBS bits of one PRB at a CQI (GetTBSizeFromMCS(mcs), AMCModule.cpp:299-303): m_requiredRBs */
+  int32_t tbs1_syn[16];    /* the synthetic-experiment build's bits of one PRB reported at a CQI:
+                            * GetTBSizeFromMCS(GetMCSFromCQI(GetCQIFromSinr(GetSinrFromCQI(cqi))), 1), downlink-transport-scheduler.cpp:656-658 */
 };
 
 /* per-cell scalar state that survives between launches */
@@ -214,6 +216,7 @@ struct RsLaunch {
   uint8_t* q_flags;           /* [cells][U] bit 0: prioritized bearer has data, bit 1: user has queued data */
   double* q_hol;              /* [cells][U] head-of-line delay of the slice-priority bearer */
   int32_t exact_scan;        /* drop-in mode: an input lies outside the FP32 filter's safe range -> every user is compared exactly */
+  int32_t synthetic;         /* rs_config.synthetic_exp: transport blocks PRB by PRB (schedulers 7, 8, 9, 10, 101, 103) */
   int32_t gen_exp;           /* drop-in mode: some slice has algo_epsilon / algo_psi outside {0, 1}: `avg` holds pow(avg_kbps, psi) as the
                               * host's libm gave it, gen_num the numerators, and every user is compared exactly */
   const double* gen_num;     /* [S][16] pow(eff(cqi) * 180000 / 1000, algo_epsilon of the slice), host libm */

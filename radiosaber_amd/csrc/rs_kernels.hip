@@ -300,7 +300,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     s_x[tid] = tab->eesm_x[tid];
     s_num32[tid] = (float)((SCHED == 1 || SCHED == 11) ? tab->pfnum[tid] : tab->kbps[tid]);
     m->mcs_of_cqi[tid] = tab->mcs_of_cqi[tid];
-    m->itbs_of_cqi[tid] = tab->itbs_of_cqi[tid];
+    m->tbs1_of_cqi[tid] = tab->tbs1_syn[tid];
     m->ones16[tid] = 1.0f;
     m->eff16[tid] = tab->eff[tid];
   }
@@ -1695,16 +1695,18 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         for (int y = f; y < x && leader; ++y) leader = ent_user[y] != u;
         if (!leader) continue;
         double sum = 0;
-        int nprb = 0;
+        int nprb = 0, syn_bits = 0; /* syn_bits: the synthetic-experiment transport block, every PRB at its own CQI (:653-659) */
         for (int y = x; y < f + q; ++y) {
           if (ent_user[y] != u) continue;
           const int r2 = (int)((s_sorted[y] >> 8) & 63u);
           if (per_prb) {
             const uint8_t* pr = prb_ptr(u, r2);
-            for (int g = 0; g < G; ++g) sum += s_e[pr[g]];
+            for (int g = 0; g < G; ++g) { sum += s_e[pr[g]]; syn_bits += m->tbs1_of_cqi[pr[g]]; }
           } else {
-            const double ev = s_e[s_cqi[r2 * Upad + u]];
+            const int cq = s_cqi[r2 * Upad + u];
+            const double ev = s_e[cq];
             for (int g = 0; g < G; ++g) sum += ev;
+            syn_bits += G * m->tbs1_of_cqi[cq];
           }
           nprb += G;
         }
@@ -1717,7 +1719,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           for (int t = 1; t <= 13; ++t) fcqi += (xm <= s_x[t]) ? 1 : 0;
         }
         const int mcs = m->mcs_of_cqi[fcqi];
-        const int tbs = s_tbs[(nprb / G) * 16 + fcqi];
+        const int tbs = p.synthetic ? syn_bits : s_tbs[(nprb / G) * 16 + fcqi];
         int bytes = tbs / 8;
         if (bytes > 100000000) bytes = 100000000;
         if (bytes > 0) {
@@ -2252,6 +2254,29 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           }
           nprb += G;
         }
+        /* the synthetic-experiment build (rs_config.synthetic_exp; ref: :653-659, nvs :336-342): the transport block adds up every
+         * allocated PRB at the MCS of its own CQI.  Every RBG lane works out its RBG's bits, the leaders add up their lanes
+         * (integers: any order). */
+        int syn_bits = 0;
+        if (p.synthetic && (SCHED == 7 || kTransport)) {
+          int t1 = 0;
+          if (lane < R && owner >= 0) {
+            if (per_prb) {
+              const uint8_t* pr = prb_ptr(owner, lane);
+              for (int k = 0; k < G; ++k) t1 += m->tbs1_of_cqi[pr[k]];
+            } else {
+              t1 = G * m->tbs1_of_cqi[col[lane * Upad]];
+            }
+          }
+          unsigned long long ms = leader ? same : 0ull;
+          while (__ballot(ms != 0ull) != 0ull) {
+            const bool more = ms != 0ull;
+            const int r2 = more ? __ffsll((long long)ms) - 1 : 0;
+            ms &= ms - 1;
+            const int v = __shfl(t1, r2, 64);
+            if (more) syn_bits += v;
+          }
+        }
         if (leader) {
           const double x = sum / (double)nprb;
           if (x == 0) {
@@ -2262,7 +2287,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             for (int k = 1; k <= 13; ++k) fcqi += (x <= xthr_k[k - 1]) ? 1 : 0; /* thresholds: wave-uniform, read before the TTI loop */
           }
           mcs = m->mcs_of_cqi[fcqi];
-          tbs = s_tbs[(nprb / G) * 16 + fcqi];
+          tbs = (p.synthetic && (SCHED == 7 || kTransport)) ? syn_bits : s_tbs[(nprb / G) * 16 + fcqi];
           /* DoStopSchedule, ref: :170-221 (bytes = bits/8, capped by dataToTransmit = 1e8) */
           int bytes = tbs / 8;
           if (bytes > 100000000) bytes = 100000000;

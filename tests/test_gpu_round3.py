@@ -412,3 +412,81 @@ def test_drop_in_nvs_general_exponents(rs, oracle):
                 left[k] -= G
         np.testing.assert_array_equal(res.rbg_to_user, want, err_msg=f"it {it}")
     ts.close()
+
+
+# ---------------------------------------------------------------- the reference's synthetic-experiment transport block
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched", [9, 8, 7, 10, 103, 1])
+@pytest.mark.parametrize("jit", [False, True])
+def test_synthetic_exp_transport_block(rs, oracle, sched, jit):
+    """FIRST_SYNTHETIC_EXP / SECOND_SYNTHETIC_EXP (CONFIG/global_config:57-58, off as shipped): DownlinkTransportScheduler and the
+    NVS scheduler size the transport block PRB by PRB, each with the MCS of its own CQI (downlink-transport-scheduler.cpp:653-659,
+    downlink-nvs-scheduler.cpp:336-342); the per-flow PF scheduler has no such branch (the flag changes nothing there).  Whole TTI
+    loops (the grant feeds the PF average, so the trajectories differ from the as-shipped build's) on per-RBG and per-PRB sources."""
+    ues, R, G, n_cells, n_ttis = [6] * 8, 25, 4, 2, 90
+    sc = rs.SliceConfig(ues, weight=[0.125] * 8)
+    U = sc.n_users
+    grids = synth_cqi(60 + sched, (n_cells, (n_ttis + 39) // 40, U, R), HIST)
+    seeds = np.array([5, 9], np.uint32)
+    tbs = {}
+    for syn in (True, False):
+        b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=jit, synthetic_exp=syn)
+        b.seed(seeds)
+        b.upload_cqi_epochs(grids)
+        got = b.run_logged(n_ttis)
+        st = b.state()
+        b.close()
+        tbs[syn] = got["tbs_bits"]
+        for c in range(n_cells):
+            cell = oracle.Cell(ues, R, G, sched, weights=[0.125] * 8)
+            cell.set_synthetic_exp(syn)
+            logs = cell.run_synth(grids[c], int(seeds[c]), n_ttis)
+            np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"], err_msg=f"synthetic {syn} cell {c}")
+            np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"])
+            assert st["avg_rate"][c].tobytes() == cell.state()["avg_rate"].tobytes()
+    if sched == 1:
+        np.testing.assert_array_equal(tbs[True], tbs[False])  # no synthetic branch in DownlinkPacketScheduler::RBsAllocation
+    else:
+        assert (tbs[True] != tbs[False]).any()
+    # per-PRB reports: every PRB at its own CQI
+    prb = np.repeat(grids, G, axis=3).astype(np.int16)
+    prb[..., 1::G] = np.clip(prb[..., 1::G] + synth_cqi(3, prb[..., 1::G].shape, HIST).astype(np.int16) % 3 - 1, 1, 15)
+    prb = prb.astype(np.uint8)
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=jit, synthetic_exp=True)
+    b.seed(seeds)
+    b.upload_cqi_epochs_prb(prb)
+    got = b.run_logged(n_ttis)
+    b.close()
+    for c in range(n_cells):
+        cell = oracle.Cell(ues, R, G, sched, weights=[0.125] * 8)
+        cell.set_synthetic_exp(True)
+        logs = cell.run_synth(prb[c], int(seeds[c]), n_ttis, per_prb=True)
+        np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"])
+        np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"])
+
+
+@pytest.mark.gpu
+def test_synthetic_exp_drop_in(rs, oracle):
+    """the same through rs_schedule_tti (what integration/downlink-gpu-scheduler.cpp passes when the reference tree defines
+    FIRST_SYNTHETIC_EXP / SECOND_SYNTHETIC_EXP)"""
+    ues, R, G = [7, 5, 6], 25, 4
+    sc = rs.SliceConfig(ues, weight=[0.3, 0.3, 0.4])
+    U = sc.n_users
+    rng = np.random.default_rng(4)
+    for sched in (9, 10):
+        ts = rs.TtiScheduler(sc, R, G, sched=sched, synthetic_exp=True)
+        cell = oracle.Cell(ues, R, G, sched, weights=[0.3, 0.3, 0.4])
+        cell.set_synthetic_exp(True)
+        for it in range(6):
+            cqi = synth_cqi(300 + it, (U, R), HIST)
+            avg = np.exp(rng.uniform(np.log(1e3), np.log(1e7), U))
+            r0, r1 = int(rng.integers(0, 2**31 - 1)), int(rng.integers(0, 2**31 - 1))
+            cell.set_cqi(cqi)
+            out = cell.new_out()
+            assert cell.allocate(avg, r0, r1, out) == 0
+            res = ts.schedule_tti(cqi, avg, r0, r1)
+            np.testing.assert_array_equal(res.rbg_to_user, out.rbg_to_user)
+            np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits)
+            np.testing.assert_array_equal(res.user_mcs, out.user_mcs)  # the PDCCH record keeps the EESM MCS
+        ts.close()

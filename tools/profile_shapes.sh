@@ -1,0 +1,31 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): PMC passes for every workload of DESIGN.md section 6's table, so that each number there
+# has a keyed, source-hash-matching entry in profiles/traffic.json and profiles/inst_counts.json.
+# Per shape three rocprofv3 runs of bench.py, each counter set in its own pass (no tracing beside --pmc):
+#   FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY
+# then HERE: python tools/summarize_shapes.py
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+shape() { # tag, bench args...
+  local tag=$1; shift
+  for pass in fetch write insts; do
+    case $pass in
+      fetch) pmc="FETCH_SIZE";;
+      write) pmc="WRITE_SIZE";;
+      insts) pmc="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY";;
+    esac
+    rm -rf $R/gpurun_out/ps_${tag}_$pass
+    rocprofv3 --pmc $pmc --output-format csv -d $R/gpurun_out/ps_${tag}_$pass -- python3 $R/bench.py --no-cpu-baseline --no-r64 --steps 3 --warmup 1 --ttis 2000 "$@" > $R/gpurun_out/ps_${tag}_$pass.log 2>&1
+  done
+  grep '^{' $R/gpurun_out/ps_${tag}_insts.log | tail -1 | cut -c1-140
+}
+shape s9_r25
+shape s9_r64 --rbgs 64 --rbg-size 8
+shape s9_u1000 --ues-per-slice 50
+shape s8_r25 --sched 8
+shape s8_r64 --sched 8 --rbgs 64 --rbg-size 8
+shape s8_u1000 --sched 8 --ues-per-slice 50
+shape s1_r25 --sched 1
+shape s1_u1000 --sched 1 --ues-per-slice 50
+shape s7_r25 --sched 7
+shape s7_u1000 --sched 7 --ues-per-slice 50
