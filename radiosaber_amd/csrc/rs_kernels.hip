@@ -220,10 +220,11 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #elif defined(RS_HOLD_ALWAYS)
   constexpr bool kHoldSched = FIXED && !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
 #else
-  /* (MaximizeCell's kernel carries the sort and is register-bound: with slice windows above 32 users the listed items' scan keeps
-   * 16 products per lane and spills -- 28.3 against 29.4 M TTIs/s at 50 UEs per slice -- so it holds winners up to 32 only) */
+  /* (MaximizeCell's kernel carries the sort and is register-bound: it holds winners only when the host passed the batch's longest
+   * slice window, so that the listed items' scan keeps 8 products per lane up to 32-user windows -- 16 above: 30.2 against 29.3 M
+   * TTIs/s at 50 UEs per slice with the round-robin dealing, 28.3 against 29.4 with 64-item chunks) */
   constexpr bool kHoldSched = FIXED && RS_JIT_R <= 32 && !DIRECT && !QUEUE &&
-                              (SCHED == 8 || SCHED == 101 || SCHED == 103 || (SCHED == 9 && RS_JIT_WIN > 0 && RS_JIT_WIN <= 32));
+                              (SCHED == 8 || SCHED == 101 || SCHED == 103 || (SCHED == 9 && RS_JIT_WIN > 0 && RS_JIT_WIN <= 64));
 #endif
 #ifdef RS_NO_SPEC
   constexpr bool kSpecSched = false;
