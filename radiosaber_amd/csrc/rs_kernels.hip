@@ -586,6 +586,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   }
   bool have_spec = false; /* this TTI's EWMA, metric scan and quotas were prepared during the previous TTI's serial phase */
   bool have_quota = false; /* held winners: this TTI's quotas were worked out by the quota wave during the previous TTI's serial phase */
+  bool have_ewma = false;  /* held winners: ... and so were the PF averages and terms (decay by the idle waves, served users by wave 0) */
+  int pre_listed = -1;     /* held winners: this wave's list for this TTI was packed during the previous TTI's serial phase (-1: no) */
   for (int tti = 0; tti < p.n_ttis; ++tti) {
     RS_STAMP(11);
     auto prb_ptr = [&](int user, int r2) -> const uint8_t* { /* the G PRBs of RBG r2 as `user` reported them */
@@ -646,6 +648,24 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     const int n_items_rt = o.n_items;
     uint16_t* const cur_bu = s_best_user + ((kSpecSched && (tti & 1)) ? n_items_rt : 0);
     uint16_t* const nxt_bu = s_best_user + ((kSpecSched && !(tti & 1)) ? n_items_rt : 0);
+    /* held winners: pack the items of chunk k0 that this wave has to scan again into its list (item = k * nwaves + wave: the
+     * items a served user leads are neighbours -- one slice, many RBGs -- so every wave gets its share); returns their number */
+    uint16_t* const hold_wl = hold_list + wave * 64;
+    auto hold_pack = [&](int k0) -> int {
+      const int it_l = (k0 + lane) * nwaves + wave;
+      const bool in = it_l < n_items_rt;
+      const int w = in ? (int)cur_bu[it_l] : 0xFFFF;
+      const bool held_bit = ((hold_bits[(k0 >> 6) * nwaves + wave] >> lane) & 1ull) != 0ull;
+      const int sg_l = FIXED ? it_l / RS_JIT_R : idiv_small(in ? it_l : 0, R);
+      const bool psi_on = (m->eps_psi[in ? sg_l : 0] & 2) != 0;
+      const bool was_served = w != 0xFFFF && ((hold_served[(w & 2047) >> 5] >> (w & 31)) & 1u) != 0u;
+      const bool need = in && w != 0xFFFF && (!held_bit || (was_served && psi_on));
+      const unsigned long long mk = __ballot(need);
+      if (need) hold_wl[__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)it_l;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      return __popcll(mk);
+    };
     /* sched 9 scans s_sorted in the serial phase, so the next TTI's records can go straight to s_elems; the policies that read
      * the records themselves (8, 101, 103) alternate between s_elems and the otherwise unused s_sorted */
     constexpr bool kAltRec = kSpecSched && SCHED != 9;
@@ -810,12 +830,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       }
       __syncthreads();
     } else
-    if (!have_spec) {
+    if (!have_spec && !have_ewma) {
       const bool do_ewma = !kDirect && !(t == last_update);
       const double dt = t - last_update;
       auto ewma_user = [&](int u, int ku) {
         double a = s_avg[u];
-        if (kSpecSched && a < 1) a = 1; /* a speculative update leaves the unclamped product behind (see the serial phase) */
+        if ((kSpecSched || kHoldSched) && a < 1) a = 1; /* an update prepared in the serial phase leaves the unclamped product behind */
         if (do_ewma) {
           int txb = s_tx[u];
           if (kCumRegs) {
@@ -885,6 +905,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
       }
       last_update = t;
+      /* (the barrier that ends the EWMA phase also separates the CQI refresh from the scans that read the grid: a TTI whose
+       * averages were prepared beforehand still needs it when P0 loaded a grid -- round 2's speculation never prepared such a TTI) */
+      if (grid_loaded) __syncthreads();
     }
     RS_STAMP(0);
 
@@ -1431,24 +1454,11 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           int o2 = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
           return v > o2 ? v : o2;
         };
-        uint16_t* const wl = hold_list + wave * 64; /* this wave's list */
+        uint16_t* const wl = hold_wl; /* this wave's list */
         for (int k0 = 0; k0 * nwaves < n_items; k0 += 64) {
-          /* items are dealt to the waves round robin (item = k * nwaves + wave): the items a served user leads are neighbours
-           * (one slice, many RBGs), so every wave gets its share of them and one pass of 16 normally does */
-          const int it_l = (k0 + lane) * nwaves + wave;
-          const bool in = it_l < n_items;
-          const int w = in ? (int)cur_bu[it_l] : 0xFFFF;
-          const bool held_bit = ((hold_bits[(k0 >> 6) * nwaves + wave] >> lane) & 1ull) != 0ull;
-          const int sg_l = FIXED ? it_l / RS_JIT_R : idiv_small(in ? it_l : 0, R);
-          const bool psi_on = (m->eps_psi[in ? sg_l : 0] & 2) != 0;
-          const bool was_served = w != 0xFFFF && ((hold_served[(w & 2047) >> 5] >> (w & 31)) & 1u) != 0u;
-          const bool need = in && w != 0xFFFF && (!held_bit || (was_served && psi_on));
-          const unsigned long long mk = __ballot(need);
-          const int n_list = __popcll(mk);
+          /* (a one-chunk shape: the list may have been packed in the previous TTI's serial phase already) */
+          const int n_list = (pre_listed >= 0 && k0 == 0) ? pre_listed : hold_pack(k0);
           hold_listed += n_list;
-          if (need) wl[__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)it_l;
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
           RS_HSTAMP(0);
           for (int base = 0; base < n_list; base += 16) {
             const bool on = base + grp < n_list;
@@ -1570,6 +1580,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         hold_age = 0;
       }
       hold_full = full;
+      pre_listed = -1;
 #ifdef RS_STAMPS
       if (tid == 0) sort_sub[6] += (unsigned long long)hold_listed + ((unsigned long long)(full ? 1 : 0) << 32); /* (wave 0's chunk) */
 #endif
@@ -1770,6 +1781,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
      * stream, the number of users served): the quota wave, idle during the serial phase, works them out there instead of at the
      * top of the next TTI, where every wave now has only a few items to scan and the quota wave would be the last to arrive */
     const bool quota_next = kHoldSched && nwaves >= 2 && tti + 1 < p.n_ttis;
+    /* ... and so are the other waves: they apply the next TTI's EWMA decay to every user ((1 - beta) * avg exactly, as if nobody
+     * were served; wave 0 adds beta * rate for the users it served once its link adaptation knows their bytes -- the reference's
+     * sum of two rounded products, as in round 2's speculation) and, once the served set is published, pack their lists of items
+     * to scan again.  The top of the next TTI is then one pass over those lists. */
+#ifdef RS_HOLD_NO_EARLY
+    const bool ewma_next = false;
+#else
+    const bool ewma_next = quota_next;
+#endif
     /* Opt-in (-DRS_COOP_SCAN): MaximizeCell's vector scan with nothing speculated beside it and every wave taking part (the
      * compaction between two vectors is shared, rs_interslice.h); the decisions still fall on wave 0, which keeps the result */
 #ifdef RS_STAMPS
@@ -2308,7 +2328,23 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               atomicAdd((unsigned long long*)&p.cum_rbs[(size_t)cell * U + owner], (unsigned long long)nprb);
             }
           }
-          if (kSpecSched && spec_next) tbs_bytes_next = bytes;
+          if ((kSpecSched && spec_next) || (kHoldSched && ewma_next)) tbs_bytes_next = bytes;
+        }
+      }
+      if (kHoldSched && ewma_next) {
+        /* the exact EWMA of the served users for TTI t+1, on top of the decay the other waves applied (all of them first) */
+        while (rs_lds_load(&fl_cur->ctr_p1) < nwaves - 1) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (leader) {
+          const double t_next = t + 0.001;
+          const double dt_next = t_next - t; /* Now - m_lastUpdate of the next update: m_lastUpdate is this TTI's time */
+          double a = s_avg[owner];
+          const double rate = (double)(tbs_bytes_next * 8) / dt_next;
+          const double beta = 0.02;
+          a = a + (beta * rate);
+          if (a < 1) a = 1;
+          s_avg[owner] = a;
+          pf_terms(owner, a);
         }
       }
       if (kSpecSched && spec_next) {
@@ -2349,6 +2385,19 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
       }
     }
+    if (kHoldSched && ewma_next && wave != 0) {
+      const int nsp = nt - 64, me = tid - 64;
+      for (int u = me; u < U; u += nsp) {
+        double a = s_avg[u];
+        if (a < 1) a = 1;
+        const double beta = 0.02;
+        const double us = (1 - beta) * a;
+        s_avg[u] = us; /* unclamped: a served user's exact update adds beta * rate to it */
+        pf_terms(u, us < 1 ? 1.0 : us);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) atomicAdd(&fl_cur->ctr_p1, 1);
+    }
     if (quota_next && wave == quota_wave) {
       /* TTI t+1's draws and remainder rotations need nothing of TTI t (unless the error model's draws, one per UE served, come
        * first on the shared stream); its targets need the slice offsets wave 0 publishes with the allocation */
@@ -2359,6 +2408,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       if (p.phy_draws) quota_draws(rs_lds_load(&m->served));
       quota_targets();
     }
+#ifndef RS_HOLD_NO_PRELIST
+    if (kHoldSched && ewma_next && wave != 0 && hold_ok && n_items_rt <= 64 * nwaves) {
+      /* my list for TTI t+1 (the held bits, the winners and -- once wave 0 has published it -- the served set are what the top
+       * of TTI t+1 would read; if that TTI turns out to scan everything, the list is simply not used) */
+      while (rs_lds_load(&fl_cur->greedy_done) < 2) __builtin_amdgcn_s_sleep(RS_SPEC_NAP);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      pre_listed = hold_pack(0);
+    }
+#endif
     if (kSpecSched && spec_next && wave != 0) {
       /* ---------------- the other waves meanwhile: TTI t+1 as if nobody were served in TTI t ---------------- */
       const int nsp = nt - 64, me = tid - 64; /* scanning threads and my index among them */
@@ -2430,6 +2488,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     RS_STAMP(8);
     have_spec = kSpecSched && spec_next;
     have_quota = quota_next;
+    have_ewma = kHoldSched && ewma_next;
     served_prev = m->served;
     n_done += 1;
     if (++epoch_pos == p.refresh) { epoch_pos = 0; ++epoch; }
@@ -2461,12 +2520,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       const long long b = (long long)cum_b[ku] + (v & RS_TX_BYTES_MASK), r = (long long)cum_r[ku] + ((v >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK);
       if (b != 0) p.cum_bytes[(size_t)cell * U + u] += b;
       if (r != 0) p.cum_rbs[(size_t)cell * U + u] += r;
-      p.avg[(size_t)cell * U + u] = (kSpecSched && s_avg[u] < 1) ? 1.0 : s_avg[u];
+      p.avg[(size_t)cell * U + u] = ((kSpecSched || kHoldSched) && s_avg[u] < 1) ? 1.0 : s_avg[u];
       p.tx_bytes[(size_t)cell * U + u] = v ? (v | RS_TX_COUNTED) : 0;
     }
   }
   for (int u = tid; u < U && !kCumRegs; u += nt) {
-    p.avg[(size_t)cell * U + u] = (kSpecSched && s_avg[u] < 1) ? 1.0 : s_avg[u];
+    p.avg[(size_t)cell * U + u] = ((kSpecSched || kHoldSched) && s_avg[u] < 1) ? 1.0 : s_avg[u];
     p.tx_bytes[(size_t)cell * U + u] = s_tx[u];
   }
   if (tid < S) p.slice_state[(size_t)cell * S + tid] = s_sstate[tid];
