@@ -651,17 +651,17 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     /* held winners: pack the items of chunk k0 that this wave has to scan again into its list (item = k * nwaves + wave: the
      * items a served user leads are neighbours -- one slice, many RBGs -- so every wave gets its share); returns their number */
     uint16_t* const hold_wl = hold_list + wave * 64;
-    auto hold_pack = [&](int k0) -> int {
-      const int it_l = (k0 + lane) * nwaves + wave;
+    auto hold_pack = [&](int k0, int for_wave) -> int { /* for_wave: whose items (wave 1 also packs wave 0's in the serial phase) */
+      const int it_l = (k0 + lane) * nwaves + for_wave;
       const bool in = it_l < n_items_rt;
       const int w = in ? (int)cur_bu[it_l] : 0xFFFF;
-      const bool held_bit = ((hold_bits[(k0 >> 6) * nwaves + wave] >> lane) & 1ull) != 0ull;
+      const bool held_bit = ((hold_bits[(k0 >> 6) * nwaves + for_wave] >> lane) & 1ull) != 0ull;
       const int sg_l = FIXED ? it_l / RS_JIT_R : idiv_small(in ? it_l : 0, R);
       const bool psi_on = (m->eps_psi[in ? sg_l : 0] & 2) != 0;
       const bool was_served = w != 0xFFFF && ((hold_served[(w & 2047) >> 5] >> (w & 31)) & 1u) != 0u;
       const bool need = in && w != 0xFFFF && (!held_bit || (was_served && psi_on));
       const unsigned long long mk = __ballot(need);
-      if (need) hold_wl[__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)it_l;
+      if (need) hold_list[for_wave * 64 + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)it_l;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       return __popcll(mk);
@@ -1457,7 +1457,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         uint16_t* const wl = hold_wl; /* this wave's list */
         for (int k0 = 0; k0 * nwaves < n_items; k0 += 64) {
           /* (a one-chunk shape: the list may have been packed in the previous TTI's serial phase already) */
-          const int n_list = (pre_listed >= 0 && k0 == 0) ? pre_listed : hold_pack(k0);
+          const int n_list = (pre_listed >= 0 && k0 == 0) ? pre_listed : hold_pack(k0, wave);
           hold_listed += n_list;
           RS_HSTAMP(0);
           for (int base = 0; base < n_list; base += 16) {
@@ -1784,11 +1784,17 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     /* ... and so are the other waves: they apply the next TTI's EWMA decay to every user ((1 - beta) * avg exactly, as if nobody
      * were served; wave 0 adds beta * rate for the users it served once its link adaptation knows their bytes -- the reference's
      * sum of two rounded products, as in round 2's speculation) and, once the served set is published, pack their lists of items
-     * to scan again.  The top of the next TTI is then one pass over those lists. */
-#ifdef RS_HOLD_NO_EARLY
+     * to scan again.  The top of the next TTI is then one pass over those lists.
+     * Same-box A/B (512 cells, 25 RBGs): GreedyByRow 94.8 against 93.4 M TTIs/s (its TTI is short: the top of the TTI is a large
+     * share), MaximizeCell 32.86 against 33.16 -- the waves that work beside wave 0 slow its greedy scan and link adaptation by
+     * what the shorter top saves, as round 2 found for its speculation -- so: GreedyByRow only (-DRS_HOLD_EARLY_ALL: every
+     * scheduler that holds winners; -DRS_HOLD_NO_EARLY: none). */
+#if defined(RS_HOLD_NO_EARLY)
     const bool ewma_next = false;
-#else
+#elif defined(RS_HOLD_EARLY_ALL)
     const bool ewma_next = quota_next;
+#else
+    const bool ewma_next = quota_next && SCHED == 8;
 #endif
     /* Opt-in (-DRS_COOP_SCAN): MaximizeCell's vector scan with nothing speculated beside it and every wave taking part (the
      * compaction between two vectors is shared, rs_interslice.h); the decisions still fall on wave 0, which keeps the result */
@@ -2414,7 +2420,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
        * of TTI t+1 would read; if that TTI turns out to scan everything, the list is simply not used) */
       while (rs_lds_load(&fl_cur->greedy_done) < 2) __builtin_amdgcn_s_sleep(RS_SPEC_NAP);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      pre_listed = hold_pack(0);
+      pre_listed = hold_pack(0, wave);
+      /* wave 0 is busy until the TTI ends: wave 1 packs its list too (the count travels in an LDS word) */
+      if (wave == 1) {
+        const int n0 = hold_pack(0, 0);
+        if (lane == 0) m->pad[1] = n0;
+      }
     }
 #endif
     if (kSpecSched && spec_next && wave != 0) {
@@ -2489,6 +2500,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     have_spec = kSpecSched && spec_next;
     have_quota = quota_next;
     have_ewma = kHoldSched && ewma_next;
+    /* (the packing condition is the same on every wave: wave 0 learns here that wave 1 packed its list) */
+    if (wave == 0 && kHoldSched && ewma_next && hold_ok && n_items_rt <= 64 * nwaves) {
+#ifndef RS_HOLD_NO_PRELIST
+      pre_listed = rs_lds_load(&m->pad[1]);
+#endif
+    }
     served_prev = m->served;
     n_done += 1;
     if (++epoch_pos == p.refresh) { epoch_pos = 0; ++epoch; }

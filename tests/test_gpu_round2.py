@@ -304,7 +304,7 @@ def test_drop_in_gates_of_schedulers_7_and_1(rs, oracle):
                                    # round 2's metric scan (every item every TTI) and its speculative forms, behind -DRS_NO_HOLD since round 3
                                    "-DRS_NO_HOLD", "-DRS_NO_HOLD -DRS_GREEDY_VECTOR -DRS_SPEC_WITH_VECTOR", "-DRS_NO_HOLD -DRS_NO_SPEC",
                                    "-DRS_NO_HOLD -DRS_COOP_SCAN -DRS_GREEDY_VECTOR -DRS_NO_SPEC", "-DRS_NO_HOLD -DRS_GREEDY_SERIAL -DRS_SPEC_EWMA_ONLY",
-                                   "-DRS_HOLD_MAX_AGE=3", "-DRS_HOLD_ALWAYS", "-DRS_HOLD_ALWAYS -DRS_GREEDY_VECTOR", "-DRS_HOLD_NO_EARLY", "-DRS_HOLD_NO_PRELIST"])
+                                   "-DRS_HOLD_MAX_AGE=3", "-DRS_HOLD_ALWAYS", "-DRS_HOLD_ALWAYS -DRS_GREEDY_VECTOR", "-DRS_HOLD_EARLY_ALL", "-DRS_HOLD_EARLY_ALL -DRS_HOLD_NO_PRELIST"])
 def test_opt_in_kernel_variants_stay_bit_exact(rs, oracle, extra, monkeypatch):
     """Build options of the shape-specialised kernel (RS_JIT_EXTRA, part of the kernel cache key) that force what the default
     picks by shape: the vector form of the MaximizeCell scan (whole vectors of records decided by a fixed-point iteration,
