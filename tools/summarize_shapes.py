@@ -18,7 +18,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 G = ROOT / "gpurun_out"
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-tags = sorted({Path(p).name[3:-11] for p in glob.glob(str(G / "ps_*_insts.log"))})
+tags = sorted({Path(p).name[3:-len("_insts.log")] for p in glob.glob(str(G / "ps_*_insts.log"))})
 tf, inf = ROOT / "profiles" / "traffic.json", ROOT / "profiles" / "inst_counts.json"
 traffic = json.loads(tf.read_text()) if tf.exists() else {}
 insts = json.loads(inf.read_text()) if inf.exists() else {}
