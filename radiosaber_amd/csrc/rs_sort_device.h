@@ -308,6 +308,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
         }
       }
       __syncthreads();
+#ifdef RS_TAIL_ROUND_ROBIN
       /* my share: entries wave, wave + nwaves, ... (lane t fetches the t-th of them), packed side by side while they fit */
       int n_mine = 0; /* entries j = wave + t * nwaves below n_alive (no division: nwaves is a run-time value) */
 #pragma unroll
@@ -325,6 +326,42 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
         } while (t < n_mine);
         finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth);
       }
+#else
+      /* Every wave reads the whole list (at most RS_WAVE_FINISH_MAX * nwaves <= 32 entries, lane j = entry j), ranks the entries
+       * by length and takes them in a zigzag over the waves (rank 0..nwaves-1 -> wave 0..nwaves-1, the next nwaves backwards, ...):
+       * a wave with two entries gets a long and a short one, which usually fit its 64 lanes together -- entries that do not fit
+       * are finished one after the other, and with the entries dealt out in list order one wave of the eight did that in about
+       * half of the sorts (two of ~10 sub-ranges of 20-60 elements each on one wave).  Any assignment is correct: the
+       * sub-ranges are disjoint. */
+      const int ent_l = lane < n_alive ? cuts[lane] : 0;
+      const int len_l = lane < n_alive ? (ent_l >> 16) - (ent_l & 0xffff) : -1;
+      int rank = 0;
+      for (int j = 0; j < n_alive; ++j) {
+        const int lj = __builtin_amdgcn_readlane(len_l, j);
+        rank += (lj > len_l || (lj == len_l && j < lane)) ? 1 : 0;
+      }
+      int blk = 0, posn = rank; /* rank = blk * nwaves + posn without a division (nwaves is a run-time value) */
+#pragma unroll
+      for (int q = 1; q < RS_WAVE_FINISH_MAX; ++q)
+        if (rank >= q * nwaves) { blk = q; posn = rank - q * nwaves; }
+      const int to_wave = (blk & 1) ? nwaves - 1 - posn : posn;
+      unsigned long long mine = __ballot(lane < n_alive && to_wave == wave);
+      while (mine != 0ull) {
+        int fb = 0, lb = 0, l0 = 0, used = 0;
+        unsigned long long rest = mine;
+        while (rest != 0ull) { /* pack what fits side by side (in list order; whatever does not fit waits for the next call) */
+          const int j = __ffsll((long long)rest) - 1;
+          rest &= rest - 1ull;
+          const int ent = __builtin_amdgcn_readlane(ent_l, j);
+          const int f = ent & 0xffff, l = ent >> 16;
+          if (used + (l - f) > 64) continue;
+          if (lane >= used && lane < used + (l - f)) { fb = f; lb = used; l0 = l; }
+          used += l - f;
+          mine &= ~(1ull << j);
+        }
+        finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth);
+      }
+#endif
       __syncthreads();
       break;
     }
