@@ -308,7 +308,14 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
         }
       }
       __syncthreads();
+      /* (same-box A/B, 512 cells: the zigzag below 33.17 against 32.99 M TTIs/s at 500 records, one position per lane; at 1 280
+       * records -- up to 32 entries to rank -- 13.30 against 13.49: list order there) */
 #ifdef RS_TAIL_ROUND_ROBIN
+      constexpr bool kZigzag = false;
+#else
+      constexpr bool kZigzag = EPT == 1;
+#endif
+      if constexpr (!kZigzag) {
       /* my share: entries wave, wave + nwaves, ... (lane t fetches the t-th of them), packed side by side while they fit */
       int n_mine = 0; /* entries j = wave + t * nwaves below n_alive (no division: nwaves is a run-time value) */
 #pragma unroll
@@ -326,7 +333,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
         } while (t < n_mine);
         finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth);
       }
-#else
+      } else {
       /* Every wave reads the whole list (at most RS_WAVE_FINISH_MAX * nwaves <= 32 entries, lane j = entry j), ranks the entries
        * by length and takes them in a zigzag over the waves (rank 0..nwaves-1 -> wave 0..nwaves-1, the next nwaves backwards, ...):
        * a wave with two entries gets a long and a short one, which usually fit its 64 lanes together -- entries that do not fit
@@ -361,7 +368,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
         }
         finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth);
       }
-#endif
+      }
       __syncthreads();
       break;
     }
