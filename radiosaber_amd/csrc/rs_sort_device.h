@@ -147,9 +147,6 @@ __device__ void introsort_loop_levels(uint32_t* v, int N, uint16_t* posA, uint16
  * 64-position chunk per i).  Every lane of a sub-range reads the three median samples itself, so
  * the pivot is known without a publishing step; three workgroup barriers per level.
  */
-#ifndef RS_WAVE_FINISH_MAX
-#define RS_WAVE_FINISH_MAX 4 /* sub-ranges per wave at which the last levels go to single waves */
-#endif
 __device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
   /* bits [lo, hi) of a 64-bit mask, 0 <= lo, hi <= 64 */
   if (hi <= lo) return 0ull;
@@ -260,6 +257,14 @@ __device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* 
 template <int EPT>
 __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t* cuts, Misc* m,
                                      unsigned long long* sub, int seg_len = 0) {
+  /* sub-ranges per wave at which the last levels go to single waves (same-box A/B, 512 cells: one position per lane -- 500 records --
+   * 33.38 M TTIs/s with 2 against 33.18 with 4 and 32.70 with 1; three positions per lane -- 1 280 records -- 13.24 with 2 against 13.41
+   * with 4) */
+#ifdef RS_WAVE_FINISH_MAX
+  constexpr int kFinishMax = RS_WAVE_FINISH_MAX;
+#else
+  constexpr int kFinishMax = EPT == 1 ? 2 : 4;
+#endif
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
 #ifdef RS_STAMPS
   unsigned long long sub_prev = __builtin_readcyclecounter();
@@ -292,7 +297,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     const int n_alive = m->n_level[level]; /* complete: the previous level ended with a barrier */
     if (n_alive == 0) break;
     /* (a first level that fills every lane -- UpperBound's row of short vectors at one position per lane -- stays a workgroup level) */
-    if (depth != 0 && n_alive <= RS_WAVE_FINISH_MAX * nwaves && (level > 0 || EPT > 1 || n_alive == 1)) {
+    if (depth != 0 && n_alive <= kFinishMax * nwaves && (level > 0 || EPT > 1 || n_alive == 1)) {
       /* few sub-ranges left, none longer than 64: their first positions publish them, every wave takes its share and
        * finishes them alone (finish_subranges_on_wave) */
 #pragma unroll
@@ -319,7 +324,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       /* my share: entries wave, wave + nwaves, ... (lane t fetches the t-th of them), packed side by side while they fit */
       int n_mine = 0; /* entries j = wave + t * nwaves below n_alive (no division: nwaves is a run-time value) */
 #pragma unroll
-      for (int t = 0; t < RS_WAVE_FINISH_MAX; ++t) n_mine += wave + t * nwaves < n_alive ? 1 : 0;
+      for (int t = 0; t < kFinishMax; ++t) n_mine += wave + t * nwaves < n_alive ? 1 : 0;
       const int my_ent = lane < n_mine ? cuts[wave + lane * nwaves] : 0;
       for (int t = 0; t < n_mine;) {
         int fb = 0, lb = 0, l0 = 0, used = 0;
@@ -334,7 +339,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
         finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth);
       }
       } else {
-      /* Every wave reads the whole list (at most RS_WAVE_FINISH_MAX * nwaves <= 32 entries, lane j = entry j), ranks the entries
+      /* Every wave reads the whole list (at most kFinishMax * nwaves <= 32 entries, lane j = entry j), ranks the entries
        * by length and takes them in a zigzag over the waves (rank 0..nwaves-1 -> wave 0..nwaves-1, the next nwaves backwards, ...):
        * a wave with two entries gets a long and a short one, which usually fit its 64 lanes together -- entries that do not fit
        * are finished one after the other, and with the entries dealt out in list order one wave of the eight did that in about
@@ -349,7 +354,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       }
       int blk = 0, posn = rank; /* rank = blk * nwaves + posn without a division (nwaves is a run-time value) */
 #pragma unroll
-      for (int q = 1; q < RS_WAVE_FINISH_MAX; ++q)
+      for (int q = 1; q < kFinishMax; ++q)
         if (rank >= q * nwaves) { blk = q; posn = rank - q * nwaves; }
       const int to_wave = (blk & 1) ? nwaves - 1 - posn : posn;
       unsigned long long mine = __ballot(lane < n_alive && to_wave == wave);
