@@ -424,6 +424,16 @@ def main():
             b64.close()
             line["value_r64"] = args.cells * args.ttis / (float(np.mean(ms64)) / 1e3)
             line["us_per_tti_per_cell_r64"] = float(np.mean(ms64)) * 1e3 / args.ttis
+            # the same two records for that shape: nominal (algorithmic) rate and what the PMC passes saw move
+            key = f"sched{args.sched}_S{S}_U{U}_R64_cells{args.cells}"
+            b64_tti = algorithmic_bytes_per_tti(U, 64, S)
+            ach64 = b64_tti * line["value_r64"] / 1e9
+            ent, stale = recorded("traffic.json")
+            line["roofline_r64"] = {"bound": "hbm", "achieved": ach64, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach64 / HBM_PEAK_GBS,
+                                    "algorithmic_bytes_per_cell_tti": b64_tti,
+                                    "traffic_bytes_per_cell_tti": ent["hbm_bytes_per_cell_tti"] if ent else None,
+                                    "traffic_stale": stale,
+                                    "traffic_source": f"profiles/traffic.json[{key}]@{ent.get('commit', '?')}" if ent else None}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, slices, seeds)
         print(json.dumps(line), flush=True)
