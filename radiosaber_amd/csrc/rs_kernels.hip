@@ -1460,6 +1460,14 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           const int n_list = (pre_listed >= 0 && k0 == 0) ? pre_listed : hold_pack(k0, wave);
           hold_listed += n_list;
           RS_HSTAMP(0);
+          /* issue priority of the pass (same-box A/B, 512 cells): GreedyByRow 101.4 against 99.7 M TTIs/s at priority 1 -- the
+           * co-resident cell is mostly in its one-wave serial phase, which runs at 3 anyway; MaximizeCell 32.8 against 33.7 -- there
+           * the pass would take issue slots from the co-resident cell's sort levels (priority 1, a barrier every few dozen
+           * instructions) */
+#ifndef RS_HOLD_PRIO
+#define RS_HOLD_PRIO (SCHED == 8 ? 1 : 0)
+#endif
+          if (RS_HOLD_PRIO) __builtin_amdgcn_s_setprio(RS_HOLD_PRIO);
           for (int base = 0; base < n_list; base += 16) {
             const bool on = base + grp < n_list;
             const int it = on ? (int)wl[base + grp] : 0;
@@ -1509,10 +1517,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               g1 = fmaxf(g1, o1);
             }
             /* my users within the tolerance of the window's largest */
-            const float thr = g1 * kTolH;
+            /* (an all-zero window -- only an empty slice, which is never listed -- gets an unreachable threshold instead of a
+             * second comparison per user) */
+            const float thr = g1 > 0.0f ? g1 * kTolH : __builtin_inff();
             unsigned cm = 0u;
 #pragma unroll
-            for (int k = 0; k < 8 * kMaxGrp; ++k) cm |= (av[k] >= thr && av[k] > 0.0f) ? (1u << k) : 0u;
+            for (int k = 0; k < 8 * kMaxGrp; ++k) cm |= av[k] >= thr ? (1u << k) : 0u;
             int cnt = __popc(cm);
             cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, false);
             cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, false);
@@ -1565,6 +1575,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
+          if (RS_HOLD_PRIO) __builtin_amdgcn_s_setprio(0);
           RS_HSTAMP(1);
         }
         hold_age += 1;
