@@ -11,6 +11,7 @@
  */
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1063,12 +1064,27 @@ struct rs_ctx {
   /* zero-copy: the kernel reads the pinned input block and writes the pinned output block itself (a few KB over the host
    * link inside one launch) instead of two hipMemcpyAsync around it; RS_DROPIN_COPY=1 restores the copies */
   uint8_t *z_in = nullptr, *z_out = nullptr; /* device-side addresses of h_in / h_out; null: copy path */
+  /* RS_DROPIN_TIMING=1: host-side breakdown of the calls (prepare / enqueue / wait / unpack), printed by rs_destroy.
+   * (Polling hipStreamQuery instead of hipStreamSynchronize was measured: no faster, the runtime already waits actively.) */
+  bool timing = false;
+  double t_prep = 0, t_enq = 0, t_wait = 0, t_unpack = 0;
+  long n_calls = 0;
 };
 
 namespace {
 struct CtxLayout {
   size_t grid, slice, avg, hol, prio, gate, draws, prb, in_total, tbs, uinfo, map, quota, target, upper, out_total;
 };
+/* first CQI outside 1..15, or null: a branch-free pass (vectorised by the compiler: 12.5 KB per call at 500 UEs x 25 RBGs),
+ * the offender is only looked for when there is one */
+const uint8_t* first_bad_cqi(const uint8_t* q, size_t n) {
+  unsigned bad = 0;
+  for (size_t i = 0; i < n; i++) bad |= (unsigned)((uint8_t)(q[i] - 1) > 14);
+  if (!bad) return nullptr;
+  for (size_t i = 0; i < n; i++)
+    if (q[i] < 1 || q[i] > 15) return q + i;
+  return nullptr;
+}
 CtxLayout ctx_layout(int n, int R, int S, int G, bool with_draws) {
   CtxLayout l;
   l.grid = 0;
@@ -1120,11 +1136,16 @@ rs_ctx* rs_create(const rs_config* cfg) {
     }
   }
   if (!ok) { fail(RS_ERR_HIP, "allocation of the staging blocks failed"); rs_destroy(c); return nullptr; }
+  const char* tm = getenv("RS_DROPIN_TIMING");
+  c->timing = tm && tm[0] == '1';
   return c;
 }
 
 void rs_destroy(rs_ctx* c) {
   if (!c) return;
+  if (c->timing && c->n_calls)
+    fprintf(stderr, "rs_schedule_tti x %ld: prepare %.2f us, enqueue %.2f us, wait %.2f us, unpack %.2f us per call\n", c->n_calls,
+            c->t_prep / c->n_calls, c->t_enq / c->n_calls, c->t_wait / c->n_calls, c->t_unpack / c->n_calls);
   if (c->b && c->b->stream) (void)hipStreamSynchronize(c->b->stream);
   if (c->d_in) (void)hipFree(c->d_in);
   if (c->d_out) (void)hipFree(c->d_out);
@@ -1137,6 +1158,8 @@ void rs_destroy(rs_ctx* c) {
 int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   if (!c || !in || !out) return fail(RS_ERR_INVALID, "null argument");
   rs_batch* b = c->b;
+  using clk = std::chrono::steady_clock;
+  const clk::time_point t0 = c->timing ? clk::now() : clk::time_point();
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   const int n = in->n_users, R = b->R, S = b->S;
   if (n < 1 || n > b->U) return fail(RS_ERR_INVALID, "n_users %d outside 1..%d", n, b->U);
@@ -1156,15 +1179,13 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   size_t in_bytes = l.prb; /* the per-PRB block travels only when given */
   if (in->cqi_prb) {
     const size_t np = (size_t)n * R * G;
-    for (size_t i = 0; i < np; i++)
-      if (in->cqi_prb[i] < 1 || in->cqi_prb[i] > 15) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", in->cqi_prb[i]);
+    if (const uint8_t* bad = first_bad_cqi(in->cqi_prb, np)) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", *bad);
     memcpy(c->h_in + l.prb, in->cqi_prb, np);
     for (int i = 0; i < n; i++)
       for (int r = 0; r < R; r++) c->h_in[l.grid + (size_t)i * R + r] = in->cqi_prb[((size_t)i * R + r) * G];
     in_bytes = l.prb + np;
   } else {
-    for (int i = 0; i < n * R; i++)
-      if (in->cqi[i] < 1 || in->cqi[i] > 15) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", in->cqi[i]);
+    if (const uint8_t* bad = first_bad_cqi(in->cqi, (size_t)n * R)) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", *bad);
     memcpy(c->h_in + l.grid, in->cqi, (size_t)n * R);
   }
   memset(c->h_in + l.grid + (size_t)n * R, 0, l.slice - (size_t)n * R);
@@ -1224,6 +1245,7 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
     else memset(c->h_in + l.prio, 1, (size_t)n);
   }
   hipStream_t st = b->stream;
+  const clk::time_point t1 = c->timing ? clk::now() : clk::time_point();
   /* per-PRB reports and queue state are read again and again inside the TTI: those calls keep the device copies */
   const bool zc = c->z_in != nullptr && !in->cqi_prb && !b->any_alpha;
   uint8_t* const dev_in = zc ? c->z_in : c->d_in;
@@ -1263,7 +1285,9 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   /* direct mode: the kernel clears its per-user outputs itself and reads the single grid on every call */
   HIP_TRY(rs_launch_cells(&L, b->threads, st));
   if (!zc) HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, l.out_total, hipMemcpyDeviceToHost, st));
+  const clk::time_point t2 = c->timing ? clk::now() : clk::time_point();
   HIP_TRY(hipStreamSynchronize(st));
+  const clk::time_point t3 = c->timing ? clk::now() : clk::time_point();
   const int16_t* h_map = (const int16_t*)(c->h_out + l.map);
   const int16_t* h_quota = (const int16_t*)(c->h_out + l.quota);
   const int16_t* h_target = (const int16_t*)(c->h_out + l.target);
@@ -1294,6 +1318,15 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
     if (out->user_final_cqi) out->user_final_cqi[i] = (ui >> 16) & 0xFF;
     if (out->user_mcs) out->user_mcs[i] = (ui >> 24) & 0xFF;
     out->user_tbs_bits[i] = h_tbs[i];
+  }
+  if (c->timing) {
+    const clk::time_point t4 = clk::now();
+    auto us = [](clk::time_point a, clk::time_point b2) { return std::chrono::duration<double, std::micro>(b2 - a).count(); };
+    c->t_prep += us(t0, t1);
+    c->t_enq += us(t1, t2);
+    c->t_wait += us(t2, t3);
+    c->t_unpack += us(t3, t4);
+    c->n_calls++;
   }
   return RS_OK;
 }

@@ -1,0 +1,74 @@
+/* Latency of the drop-in entry point from C++ (no Python in the loop): rs_schedule_tti per call, host buffers in and out.
+ * Build: g++ -O2 -std=c++17 -Iinclude tools/dropin_latency.cpp -Lradiosaber_amd -lradiosaber_hip -Wl,-rpath,'$ORIGIN/../radiosaber_amd' -o tools/dropin_latency
+ * Run on a GPU box: tools/dropin_latency [calls] */
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "radiosaber_hip.h"
+
+static double run(int ues_per_slice, int R, int G, int sched, int calls) {
+  const int S = 20, U = S * ues_per_slice;
+  std::vector<double> w(S, 0.05);
+  std::vector<int32_t> zero(S, 0), one(S, 1), u2s(U);
+  for (int i = 0; i < U; i++) u2s[i] = i / ues_per_slice;
+  rs_config cfg{};
+  cfg.n_slices = S;
+  cfg.n_users = U;
+  cfg.n_rbgs = R;
+  cfg.rbg_size = G;
+  cfg.sched = sched;
+  cfg.device = 0;
+  cfg.slice_weight = w.data();
+  cfg.algo_alpha = zero.data();
+  cfg.algo_beta = zero.data();
+  cfg.algo_epsilon = one.data();
+  cfg.algo_psi = one.data();
+  cfg.user_to_slice = u2s.data();
+  rs_ctx* c = rs_create(&cfg);
+  if (!c) { fprintf(stderr, "rs_create: %s\n", rs_last_error()); exit(1); }
+  std::mt19937 g(1);
+  std::vector<uint8_t> cqi((size_t)U * R);
+  std::vector<double> avg(U);
+  for (auto& x : cqi) x = 1 + g() % 15;
+  for (auto& x : avg) x = 1e4 + g() % 1000000;
+  std::vector<int32_t> map(R), tbs(U), nprb(U), fcqi(U), mcs(U), tgt(S), quo(S);
+  rs_tti_in in{};
+  in.n_users = U;
+  in.cqi = cqi.data();
+  in.avg_rate = avg.data();
+  rs_tti_out out{};
+  out.rbg_to_user = map.data();
+  out.user_tbs_bits = tbs.data();
+  out.user_nprb = nprb.data();
+  out.user_final_cqi = fcqi.data();
+  out.user_mcs = mcs.data();
+  out.target_rbs = tgt.data();
+  out.quota_rbgs = quo.data();
+  long long sum = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = -50; i < calls; i++) {
+    if (i == 0) t0 = std::chrono::steady_clock::now();
+    in.rand0 = 123 + i;
+    in.rand1 = 456 + i;
+    avg[(i + 50) % U] += 1000; /* inputs change call to call */
+    if (rs_schedule_tti(c, &in, &out) != RS_OK) { fprintf(stderr, "rs_schedule_tti: %s\n", rs_last_error()); exit(1); }
+    sum += map[0] + tbs[map[0] < 0 ? 0 : map[0]];
+  }
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / calls;
+  rs_destroy(c);
+  printf("sched %d, %d UEs x %d RBGs: %.1f us per rs_schedule_tti (checksum %lld)\n", sched, U, R, us, sum);
+  return us;
+}
+
+int main(int argc, char** argv) {
+  const int calls = argc > 1 ? atoi(argv[1]) : 2000;
+  run(5, 64, 8, RS_SCHED_MAXCELL, calls);
+  run(25, 25, 4, RS_SCHED_MAXCELL, calls);
+  run(25, 64, 8, RS_SCHED_MAXCELL, calls);
+  run(25, 25, 4, RS_SCHED_SEQUENTIAL, calls);
+  run(25, 25, 4, RS_SCHED_PF, calls);
+  return 0;
+}
