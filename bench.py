@@ -31,6 +31,10 @@ The JSON line also carries
                   `traffic_source`) say what actually moves;
   roofline_issue  what really bounds the kernel: wave-instructions per cell-TTI (SQ_INSTS_* from profiles/inst_counts.json,
                   tools/pmc_insts.sh) x this run's TTIs/s against the chip's VALU issue rate;
+  roofline.streamed   the same batch with `cqi_refresh = 1` -- a new CQI grid from HBM every TTI, SURVEY 8d's "streamed-CQI" mode:
+                  the one figure of the line where moved bytes ~ algorithmic bytes, i.e. real bytes / real time (N = 1 only;
+                  a bounded set of epochs cycles, larger than the 256 MiB Infinity Cache; `--cqi-refresh R` runs the MAIN batch
+                  in that mode, which is how tools/profile_streamed.sh takes its PMC passes);
   value_r64       the same batch on the as-shipped 64-RBG grid (N = 1 only);
   cpu_baseline    the CPU oracle (oracle/, the bit-exact restatement of the reference) timed on this box's host cores with
                   OpenMP over independent cells (rank 0, N = 1 only).
@@ -167,12 +171,31 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def _profiler_in_environment():
+    """rocprofv3 (or another rocprofiler-sdk tool) is preloaded into this process: its library has initialised the GPU here."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    if "rocprofiler" in pre or "rocprof" in pre:
+        return "LD_PRELOAD=" + pre
+    for k in os.environ:
+        if k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")):
+            return k
+    return None
+
+
 def _launch_own_ranks(n):
     """`python bench.py --gpus N` (N > 1) without a launcher: N fresh rank processes under torch.distributed.run, started as a
     CHILD of this process (never exec: a process that replaces itself after touching the GPU takes the box down; this parent
     has not touched HIP, and still does not exec).  stdout of the children is relayed: the one JSON line of rank 0 goes to
     stdout, anything else to stderr.  Returns the children's exit code."""
     import subprocess
+    prof = _profiler_in_environment()
+    if prof:
+        # the profiler's preloaded library has already initialised the GPU in THIS process: starting the ranks from here is
+        # the hop this pool forbids.  Profile one rank, or start the ranks under the launcher and profile inside it.
+        print(f"bench.py: refusing to start {n} ranks from a process a profiler is loaded into ({prof}): profile a single "
+              "rank (`rocprofv3 ... -- python3 bench.py`), or run `python -m torch.distributed.run ... bench.py --gpus N` "
+              "yourself", file=sys.stderr)
+        return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
     env = dict(os.environ)
@@ -227,6 +250,10 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="workgroup size per cell (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-r64", action="store_true", help="skip the extra 64-RBG measurement (value_r64)")
+    ap.add_argument("--cqi-refresh", type=int, default=40,
+                    help="TTIs between two CQI grids (reference: 40, enb-mac-entity.cc:38).  1 = streamed-CQI mode: a new grid "
+                         "from HBM every TTI; the epochs then cycle through a bounded set (rs_batch_config.cqi_epoch_wrap)")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the extra streamed-CQI measurement (roofline.streamed)")
     ap.add_argument("--no-jit", action="store_true", help="use the kernels built into the library instead of the "
                     "shape-specialised one compiled at create time")
     ap.add_argument("--allow-variant", action="store_true",
@@ -282,9 +309,18 @@ def main():
     slices = rs.SliceConfig([args.ues_per_slice] * S, weight=[1.0 / S] * S)
     want_jit = not args.no_jit
 
-    def make_batch(n_rbgs, rbg_size, launches, ttis):
+    EPOCH_BYTES_CAP = 8 << 30  # HBM spent on CQI epochs before they start to cycle (far beyond the 256 MiB Infinity Cache)
+
+    def make_batch(n_rbgs, rbg_size, launches, ttis, refresh=40):
+        need = (launches * ttis + refresh - 1) // refresh
+        stride = (U * n_rbgs + 15) // 16 * 16
+        n_epochs = need
+        wrap = False
+        if refresh != 40 and need * args.cells * stride > EPOCH_BYTES_CAP:
+            n_epochs, wrap = max(2, EPOCH_BYTES_CAP // (args.cells * stride)), True
         b = rs.BatchScheduler(slices, n_rbgs, rbg_size, args.cells, sched=args.sched, device=local_rank,
-                              threads_per_cell=args.threads, jit=want_jit)
+                              threads_per_cell=args.threads, jit=want_jit, cqi_refresh=refresh, cqi_epoch_wrap=wrap)
+        b.n_epochs_resident, b.epoch_stride = n_epochs, stride
         code, msg = b.jit_status()
         ok = (not want_jit) or code == 1
         if world > 1:
@@ -303,11 +339,11 @@ def main():
                              "rerun with --no-jit to measure the built-in kernels on purpose")
         # cell ids are global: rank r owns cells [r*cells, (r+1)*cells); seeds and CQI grids are keyed on them
         b.seed(sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, args.cells)))
-        b.synthesize_cqi(0x5AB3, (launches * ttis + 39) // 40,  # generated on the device, stay in HBM
+        b.synthesize_cqi(0x5AB3, n_epochs,  # generated on the device, stay in HBM
                          first_cell=sharding.first_cell_for_rank(rank, world, args.cells))
         return b
 
-    batch = make_batch(R, args.rbg_size, args.steps + args.warmup, args.ttis)
+    batch = make_batch(R, args.rbg_size, args.steps + args.warmup, args.ttis, args.cqi_refresh)
     seeds = sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, args.cells))
 
     def sync_all():
@@ -323,10 +359,16 @@ def main():
     ms = batch.run_timed(args.ttis, args.steps)  # K launches, HIP events on the launch stream
     sync_all()
     wall = time.perf_counter() - t0
+    rank_kernel_ms = [float(np.mean(ms))]
     if world > 1:
         tw = torch.tensor([wall], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
+        # every rank's mean launch duration (HIP events), so that a straggler GPU shows in the line
+        km = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        km[rank] = float(np.mean(ms))
+        dist.all_reduce(km, op=dist.ReduceOp.SUM)
+        rank_kernel_ms = [round(float(x), 4) for x in km.tolist()]
 
     # final aggregation: per-slice cumulative bytes, reduced over the GPUs (RCCL over xGMI)
     slice_bytes = torch.zeros(S, dtype=torch.int64, device="cuda")
@@ -338,6 +380,7 @@ def main():
     sharding.all_reduce_slice_bytes(slice_bytes, dist if world > 1 else None)
     total_bytes = int(slice_bytes.sum().item())
     kernel_name = batch.kernel_name
+    batch_epochs = batch.n_epochs_resident
     batch.close()
 
     if rank == 0:
@@ -346,11 +389,12 @@ def main():
         launch_s = float(np.mean(ms)) / 1e3
         b_tti = algorithmic_bytes_per_tti(U, R, S)
         achieved = b_tti * args.cells * args.ttis / launch_s / 1e9
-        key = f"sched{args.sched}_S{S}_U{U}_R{R}_cells{args.cells}"
+        main_key = key = f"sched{args.sched}_S{S}_U{U}_R{R}_cells{args.cells}" + ("" if args.cqi_refresh == 40 else f"_refresh{args.cqi_refresh}")
         src_hash = rs.device_source_hash()  # identity of the kernel sources inside the library that just ran
 
-        def recorded(fname):
+        def recorded(fname, key=None):
             """Entry of profiles/<fname> for this workload + whether it was recorded on other kernel code than this run's."""
+            key = key or main_key
             f = ROOT / "profiles" / fname
             ent = json.loads(f.read_text()).get(key) if f.exists() else None
             if not ent:
@@ -380,7 +424,8 @@ def main():
             "config": {"workload": f"sched={args.sched} ({'RadioSaber/MaximizeCell' if args.sched == 9 else 'see --sched'}), "
                                    f"{args.cells} independent cells per GPU x ({S} slices x {args.ues_per_slice} UEs "
                                    f"= {U} UEs x {R} RBGs), {args.ttis} TTIs per step, CQI i.i.d. from the trace "
-                                   f"histogram redrawn every 40 TTIs (BASELINE.json configs[3]; configs[4] at 8 GPUs)",
+                                   f"histogram redrawn every {args.cqi_refresh} TTIs (BASELINE.json configs[3]; configs[4] at 8 GPUs)",
+                       "cqi_refresh": args.cqi_refresh, "cqi_epochs_resident": batch_epochs,
                        "cells_per_gpu": args.cells, "ttis_per_step": args.ttis, "slices": S, "ues": U, "rbgs": R,
                        "sched": args.sched, "parallelism": f"cells sharded over {world} GPU(s), no data-path collective"},
             "us_per_tti_per_cell": launch_s / args.ttis * 1e6,
@@ -390,13 +435,14 @@ def main():
             "rccl_version": _rccl_version(torch) if (world > 1 and backend == "nccl") else None,
             "jit_extra": jit_extra, "jit_env": jit_env,
             "kernel_ms_per_launch": [round(float(x), 4) for x in ms],
+            "kernel_ms_mean_per_rank": rank_kernel_ms,
             "total_slice_bytes": total_bytes,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_stale": traffic_stale,
                          "traffic_frac_of_peak": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "algorithmic_bytes_per_cell_tti": b_tti,
-                         "resident_bytes_per_cell_tti": resident_bytes_per_tti(U, R, S, args.ttis),
+                         "resident_bytes_per_cell_tti": resident_bytes_per_tti(U, R, S, args.ttis, args.cqi_refresh),
                          "note": "achieved/frac use SURVEY 8d's streamed-CQI bytes as the contract asks; the kernel keeps the "
                                  "grid in LDS between refreshes, so `traffic` (PMC) is what moves and the kernel is "
                                  "issue/latency-bound: see roofline_issue",
@@ -416,6 +462,31 @@ def main():
                 "source": f"profiles/inst_counts.json[{key}]@{ent.get('commit', '?')} source_hash {ent.get('source_hash', 'none')} "
                           "(SQ_INSTS_* per cell-TTI from tools/pmc_insts.sh, phase shares from tools/phase_stamps.py; counts "
                           "are per build, the rate is this run's)"}
+        if world == 1 and not args.no_streamed and args.cqi_refresh != 1:
+            # SURVEY 8(d) asks for both modes: the same cells with a new CQI grid from HBM EVERY TTI (cqi_refresh = 1), where the
+            # bytes the kernel moves are ~ the algorithmic bytes: the one roofline figure of this line that is real bytes / real time
+            st_ttis = min(args.ttis, 2000)
+            bs = make_batch(R, args.rbg_size, 4, st_ttis, refresh=1)
+            bs.run(st_ttis)
+            ms_s = bs.run_timed(st_ttis, 3)
+            st_epochs, st_stride = bs.n_epochs_resident, bs.epoch_stride
+            bs.close()
+            st_value = args.cells * st_ttis / (float(np.mean(ms_s)) / 1e3)
+            skey = f"sched{args.sched}_S{S}_U{U}_R{R}_cells{args.cells}_refresh1"
+            ent, stale = recorded("traffic.json", skey)
+            moved = ent["hbm_bytes_per_cell_tti"] if ent else None
+            line["roofline"]["streamed"] = {
+                "value": st_value, "unit": "TTIs/s", "us_per_tti_per_cell": float(np.mean(ms_s)) * 1e3 / st_ttis,
+                "achieved_gbs": b_tti * st_value / 1e9, "frac": b_tti * st_value / 1e9 / HBM_PEAK_GBS,
+                "traffic": moved * args.cells * st_ttis if moved else None, "traffic_bytes_per_cell_tti": moved,
+                "traffic_gbs": moved * st_value / 1e9 if moved else None,
+                "traffic_frac_of_peak": moved * st_value / 1e9 / HBM_PEAK_GBS if moved else None,
+                "traffic_stale": stale,
+                "traffic_source": f"profiles/traffic.json[{skey}]@{ent.get('commit', '?')}" if ent else None,
+                "epochs_resident": st_epochs, "epoch_bytes_resident": st_epochs * args.cells * st_stride,
+                "ttis_per_launch": st_ttis, "launches": 3,
+                "note": "cqi_refresh = 1: every TTI loads its grid from HBM (epochs cycle through a set larger than the Infinity "
+                        "Cache); achieved_gbs = algorithmic bytes x this rate, traffic_* = PMC bytes of the same mode"}
         if world == 1 and not args.no_r64 and (R, args.rbg_size) != (64, 8):
             # the as-shipped grid: 100 MHz = 512 PRBs = 64 RBGs of 8 (SURVEY 8d asks for it beside the headline)
             b64 = make_batch(64, 8, 4, args.ttis)
@@ -428,7 +499,7 @@ def main():
             key = f"sched{args.sched}_S{S}_U{U}_R64_cells{args.cells}"
             b64_tti = algorithmic_bytes_per_tti(U, 64, S)
             ach64 = b64_tti * line["value_r64"] / 1e9
-            ent, stale = recorded("traffic.json")
+            ent, stale = recorded("traffic.json", key)
             line["roofline_r64"] = {"bound": "hbm", "achieved": ach64, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach64 / HBM_PEAK_GBS,
                                     "algorithmic_bytes_per_cell_tti": b64_tti,
                                     "traffic_bytes_per_cell_tti": ent["hbm_bytes_per_cell_tti"] if ent else None,

@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 8 /* 8: rs_jit_selfcheck_queue, rs_config.synthetic_exp, any integer algo_epsilon / algo_psi in drop-in contexts; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
+#define RS_ABI_VERSION 9 /* 9: rs_create_checked / rs_batch_create_checked (RS_CREATE / RS_BATCH_CREATE: the caller's ABI version and struct size are
+                            checked), rs_batch_config.cqi_epoch_wrap / queue_state_lds, threads_per_cell up to 1024 with jit, rs_jit_selfcheck_untuned;
+                            8: rs_jit_selfcheck_queue, rs_config.synthetic_exp, any integer algo_epsilon / algo_psi in drop-in contexts; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
                             6: rs_tti_in.required_rbs / data_to_transmit (the gates of schedulers 7 and 1 in the drop-in mode);
                             5: per-PRB batch sources (rs_batch_upload_cqi_epochs_prb, rs_batch_set_trace_prb);
                             4: finite queues in batches (rs_batch_set_bearers, rs_batch_set_arrivals, rs_batch_read_bearer_state, rs_internet_flow_arrivals);
@@ -101,6 +103,11 @@ typedef struct rs_config {
 } rs_config;
 
 const char* rs_last_error(void);   /* thread-local message of the last failing call */
+/* The structs of this header grow at their ends from one ABI version to the next, and the plain create functions below read them
+ * with THIS library's layout.  A caller that may meet a library of another version either compares rs_abi_version() with the
+ * RS_ABI_VERSION it was compiled with before creating anything, or creates through RS_CREATE / RS_BATCH_CREATE
+ * (rs_create_checked / rs_batch_create_checked), which pass the caller's version and struct size and are refused with
+ * RS_ERR_INVALID on any mismatch -- nothing is inferred from field values. */
 int rs_abi_version(void);
 int rs_device_count(void);         /* number of HIP devices (0 when none)           */
 
@@ -128,6 +135,8 @@ typedef struct rs_ctx rs_ctx;
 
 /* replaces the scheduler constructor + ENodeB::SetDLScheduler (ref: src/device/ENodeB.cpp:303-391) */
 rs_ctx* rs_create(const rs_config* cfg);
+rs_ctx* rs_create_checked(const rs_config* cfg, int abi_version, size_t cfg_size);
+#define RS_CREATE(cfg) rs_create_checked((cfg), RS_ABI_VERSION, sizeof(rs_config))
 void rs_destroy(rs_ctx* ctx);
 
 /* What RBsAllocation() sees on entry (ref: GetUsersToSchedule(): packet-scheduler.h:88-123):
@@ -207,15 +216,26 @@ typedef struct rs_batch_config {
   int32_t phy_error_draws;   /* 1: consume one rand() per UE served in the previous TTI, as the
                                 reference's PHY error model does on the shared libc stream
                                 (ref: src/phy/wideband-cqi-eesm-error-model.cpp:69)              */
-  int32_t threads_per_cell;  /* workgroup size, multiple of 64 in [64,512]; 0 = default: 512, or 256
-                                once the batch puts 4 or more cells on every CU                  */
+  int32_t threads_per_cell;  /* workgroup size, multiple of 64 in [64,512] ([64,1024] with jit = 1: the built-in kernels
+                                are bounded at 512); 0 = default: 512, 256 once the batch puts 4 or more cells on
+                                every CU, 640 for a shape-specialised MaximizeCell batch of 1 025..1 280 sort records
+                                (the 64-RBG grid: two sort positions per lane on every wave)                      */
   int32_t jit;               /* 1: compile the cell kernel for this batch's exact shape at create time
                                 (hiprtc, ~2 s, cached per process); results are identical, the built-in
                                 kernels are used if the compilation fails (rs_batch_jit_status tells).  0: built-in kernels.
                                 The environment variable RS_JIT=0|1 overrides.                    */
+  int32_t cqi_epoch_wrap;    /* epoch sources (upload / synthesize): 0 = running past the last epoch is RS_ERR_RANGE;
+                                1 = the epochs cycle (epoch index modulo n_epochs) -- a bounded set of grids serves a
+                                run of any length, e.g. the streamed-CQI measurement with cqi_refresh = 1 (ABI 9)  */
+  int32_t queue_state_lds;   /* queue model: where the bearers' hot words (156 B per user) live during a launch.
+                                0 = automatic: LDS when the cell still fits the CU's 160 KB, except when that is what
+                                takes the cell over 80 KB (one cell per CU instead of two) in a batch of more cells
+                                than CUs; 1 = LDS whenever it fits; -1 = HBM (ABI 9)                              */
 } rs_batch_config;
 
 rs_batch* rs_batch_create(const rs_batch_config* cfg);
+rs_batch* rs_batch_create_checked(const rs_batch_config* cfg, int abi_version, size_t cfg_size);
+#define RS_BATCH_CREATE(cfg) rs_batch_create_checked((cfg), RS_ABI_VERSION, sizeof(rs_batch_config))
 void rs_batch_destroy(rs_batch* b);
 
 /* per-cell libc-compatible rand() streams: srand(seed[c]) then rand_skip[c] values discarded
@@ -350,8 +370,9 @@ int rs_batch_read_state(rs_batch* b, double* avg_rate, int64_t* cum_bytes, int64
 /* the simulated clock of every cell (ref: src/core/eventScheduler/simulator.cc:117-126): t [n_cells] = time stamp of the next
  * TTI, last_update [n_cells] = RadioBearer::m_lastUpdate; either may be NULL */
 int rs_batch_read_clock(rs_batch* b, double* t, double* last_update);
-/* 1: the shape-specialised (hiprtc) kernel is in use; 0: it was not asked for; -1: it was asked for and could not be
- * built -- the built-in kernels run instead and msg receives the reason */
+/* 1: the shape-specialised (hiprtc) kernel is in use (msg is empty, or says that the untuned variant had to be built);
+ * 0: it was not asked for; -1: it was asked for and could not be built -- the built-in kernels run instead and msg
+ * receives the reason */
 int rs_batch_jit_status(rs_batch* b, char* msg, size_t msglen);
 /* per-slice cumulative bytes summed over the batch's cells, reduced on the device into
  * d_out[S] (device pointer, uint64) on the batch's stream -- the vector the multi-GPU run
@@ -362,6 +383,10 @@ int rs_batch_slice_bytes(rs_batch* b, uint64_t* h_out /* [S] */);
  * code object size or a negative value with the compiler log in err */
 int rs_jit_selfcheck(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, char* err,
                      size_t errlen);
+/* the same without the internal -mllvm tuning options: the build the library falls back to (and reports through
+ * rs_batch_jit_status: return value 1 with a non-empty message) when hiprtc refuses them */
+int rs_jit_selfcheck_untuned(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, char* err,
+                             size_t errlen);
 /* the same for the queue-model kernel (the code object rs_batch_set_bearers switches a batch to; schedulers 1, 7, 8, 9, 101, 103) */
 int rs_jit_selfcheck_queue(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, char* err,
                            size_t errlen);

@@ -93,7 +93,7 @@ class GpuDownlinkScheduler {
     c.algo_epsilon = eps_.data();
     c.algo_psi = psi_.data();
     c.user_to_slice = user_to_slice_.data();
-    ctx_ = rs_create(&c);
+    ctx_ = RS_CREATE(&c); /* rs_create behind the ABI-version + struct-size check */
     if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
   }
   ~GpuDownlinkScheduler() { rs_destroy(ctx_); }

@@ -45,7 +45,7 @@ void DL_GPU_PF_PacketScheduler::RBsAllocation() {
     cfg.user_to_slice = u2s.data();
     cfg.stream = NULL;
     cfg.synthetic_exp = 0; /* DownlinkPacketScheduler::RBsAllocation has no synthetic-experiment branch */
-    ctx_ = rs_create(&cfg);
+    ctx_ = RS_CREATE(&cfg);
     if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
     nb_rbs_ = nb_rbs;
   }

@@ -77,7 +77,7 @@ void DownlinkGpuNVSScheduler::RBsAllocation() {
 #if defined(FIRST_SYNTHETIC_EXP) || defined(SECOND_SYNTHETIC_EXP)
     cfg.synthetic_exp = 1; /* downlink-nvs-scheduler.cpp:336-342 (the sampler of :405-528 has no such branch: ignored there) */
 #endif
-    ctx_ = rs_create(&cfg);
+    ctx_ = RS_CREATE(&cfg);
     if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
     nb_rbs_ = nb_rbs;
   }

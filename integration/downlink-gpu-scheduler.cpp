@@ -77,7 +77,7 @@ void DownlinkGpuScheduler::LazyCreate(int nb_rbs, int rbg_size) {
 #if defined(FIRST_SYNTHETIC_EXP) || defined(SECOND_SYNTHETIC_EXP)
   cfg.synthetic_exp = 1; /* the parent's transport block, :653-659 */
 #endif
-  ctx_ = rs_create(&cfg);
+  ctx_ = RS_CREATE(&cfg);
   if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
   nb_rbs_ = nb_rbs;
   rbg_size_ = rbg_size;

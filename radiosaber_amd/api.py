@@ -48,7 +48,11 @@ class _Config(C.Structure):
 class _BatchConfig(C.Structure):
     _fields_ = [("cell", _Config), ("n_cells", C.c_int32), ("first_tti", C.c_int32),
                 ("cqi_refresh", C.c_int32), ("phy_error_draws", C.c_int32),
-                ("threads_per_cell", C.c_int32), ("jit", C.c_int32)]
+                ("threads_per_cell", C.c_int32), ("jit", C.c_int32),
+                ("cqi_epoch_wrap", C.c_int32), ("queue_state_lds", C.c_int32)]
+
+
+RS_ABI_VERSION = 9  # the include/radiosaber_hip.h these ctypes structs mirror; passed to the *_checked create functions
 
 
 class _TtiIn(C.Structure):
@@ -89,6 +93,7 @@ ABI_SYMBOLS = [
     "rs_batch_upload_cqi_epochs_prb", "rs_batch_set_trace_prb",
     "rs_batch_set_bearers", "rs_batch_set_arrivals", "rs_batch_read_bearer_state", "rs_internet_flow_arrivals",
     "rs_device_source_hash",
+    "rs_create_checked", "rs_batch_create_checked", "rs_jit_selfcheck_untuned",
 ]
 
 _lib = None
@@ -113,6 +118,11 @@ def lib():
     L.rs_set_slice_offset.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.rs_batch_create.restype = C.c_void_p
     L.rs_batch_create.argtypes = [C.POINTER(_BatchConfig)]
+    L.rs_create_checked.restype = C.c_void_p
+    L.rs_create_checked.argtypes = [C.POINTER(_Config), C.c_int, C.c_size_t]
+    L.rs_batch_create_checked.restype = C.c_void_p
+    L.rs_batch_create_checked.argtypes = [C.POINTER(_BatchConfig), C.c_int, C.c_size_t]
+    L.rs_jit_selfcheck_untuned.argtypes = [C.c_int] * 6 + [C.c_char_p, C.c_size_t]
     L.rs_batch_destroy.argtypes = [C.c_void_p]
     L.rs_batch_seed.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
     L.rs_batch_upload_cqi_epochs.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32]
@@ -182,11 +192,11 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-def jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCHED_MAXCELL, queues=False):
+def jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCHED_MAXCELL, queues=False, untuned=False):
     """Compile the shape-specialised kernel for one shape (hiprtc, no GPU needed); returns the code size.  queues=True: the
-    queue-model kernel of the shape."""
+    queue-model kernel of the shape.  untuned=True: without the -mllvm tuning options (the library's fallback build)."""
     buf = C.create_string_buffer(4096)
-    fn = lib().rs_jit_selfcheck_queue if queues else lib().rs_jit_selfcheck
+    fn = lib().rs_jit_selfcheck_queue if queues else (lib().rs_jit_selfcheck_untuned if untuned else lib().rs_jit_selfcheck)
     n = fn(n_slices, n_users, n_rbgs, rbg_size, threads, sched, buf, 4096)
     if n < 0:
         raise RadioSaberError(n, buf.value.decode(errors="replace"))
@@ -395,7 +405,7 @@ class TtiScheduler:
                  device: int = 0, stream: Optional[int] = None, synthetic_exp: bool = False):
         self.slices, self.R, self.rbg_size, self.sched = slices, n_rbgs, rbg_size, sched
         self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream, synthetic_exp)
-        self._h = lib().rs_create(C.byref(self._cfg.c))
+        self._h = lib().rs_create_checked(C.byref(self._cfg.c), RS_ABI_VERSION, C.sizeof(_Config))
         if not self._h:
             raise RadioSaberError(-1, lib().rs_last_error().decode())
 
@@ -472,14 +482,15 @@ class BatchScheduler:
     def __init__(self, slices: SliceConfig, n_rbgs: int, rbg_size: int, n_cells: int,
                  sched: int = RS_SCHED_MAXCELL, device: int = 0, first_tti: int = 100, cqi_refresh: int = 40,
                  phy_error_draws: bool = False, threads_per_cell: int = 0, stream: Optional[int] = None,
-                 jit: bool = False, synthetic_exp: bool = False):
-        """synthetic_exp: the reference built with FIRST/SECOND_SYNTHETIC_EXP (transport blocks PRB by PRB; rs_config.synthetic_exp)."""
+                 jit: bool = False, synthetic_exp: bool = False, cqi_epoch_wrap: bool = False, queue_state_lds: int = 0):
+        """synthetic_exp: the reference built with FIRST/SECOND_SYNTHETIC_EXP (transport blocks PRB by PRB; rs_config.synthetic_exp).
+        cqi_epoch_wrap: the uploaded / synthesized epochs cycle instead of ending the run.  queue_state_lds: 0 auto, 1 LDS, -1 HBM."""
         self.slices, self.R, self.rbg_size, self.sched, self.n_cells = slices, n_rbgs, rbg_size, sched, n_cells
         self.S, self.U = slices.n_slices, slices.n_users
         self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream, synthetic_exp)
         bc = _BatchConfig(self._cfg.c, n_cells, first_tti, cqi_refresh, int(phy_error_draws), threads_per_cell,
-                          int(jit))
-        self._h = lib().rs_batch_create(C.byref(bc))
+                          int(jit), int(bool(cqi_epoch_wrap)), int(queue_state_lds))
+        self._h = lib().rs_batch_create_checked(C.byref(bc), RS_ABI_VERSION, C.sizeof(_BatchConfig))
         if not self._h:
             raise RadioSaberError(-1, lib().rs_last_error().decode())
 

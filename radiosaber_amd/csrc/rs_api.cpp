@@ -29,7 +29,8 @@
 extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_t stream);
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes);
 struct RsJitKernel;
-extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, int queue, int win, char* err, size_t errlen);
+extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, int qmode, int win, char* err, size_t errlen);
+extern "C" int rs_jit_is_untuned(const RsJitKernel* k);
 extern "C" hipError_t rs_jit_launch(RsJitKernel* k, const RsLaunch* p, hipStream_t stream);
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,
                                       uint64_t seed, int64_t first_cell, const uint32_t* cdf16, hipStream_t stream);
@@ -247,6 +248,7 @@ struct rs_batch {
   unsigned long long* d_stamps = nullptr;
   /* finite queues (rs_batch_set_bearers / rs_batch_set_arrivals) */
   bool queues = false;
+  int qmode = 2;             /* rs_carve's `queue` argument once the queue model is on: 2 = bearers' hot words in LDS when they fit, 3 = in HBM */
   uint8_t* d_bearer_kind = nullptr;
   int64_t* d_arr_off = nullptr;
   double* d_arr_time = nullptr;
@@ -315,7 +317,7 @@ int slice_window(const rs_batch* b) {
 void carve_lds(rs_batch* b, RsLaunch* L) {
   /* (drop-in contexts of schedulers 1 and 7 carry the gate scratch too: rs_tti_in.required_rbs / data_to_transmit) */
   const bool gate_scratch = b->direct && (b->sched == RS_SCHED_PF || b->sched == RS_SCHED_NVS);
-  const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads, b->queues ? 2 : (gate_scratch ? 1 : 0));
+  const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads, b->queues ? b->qmode : (gate_scratch ? 1 : 0));
   L->Upad = c.Upad;
   L->nvs_seg = c.nvs_seg;
   L->off_avgk = c.off_avgk; L->off_rcp = c.off_rcp; L->off_tab = c.off_tab; L->off_slice = c.off_slice;
@@ -449,6 +451,7 @@ int batch_alloc(rs_batch* b) {
   L.sched = b->sched;
   L.n_cells = b->n_cells;
   L.refresh = b->cfg.cqi_refresh;
+  L.epoch_wrap = b->cfg.cqi_epoch_wrap ? 1 : 0;
   L.phy_draws = b->cfg.phy_error_draws;
   L.tab = b->d_tab; L.weight = b->d_weight; L.eps = b->d_eps; L.psi = b->d_psi;
   L.alpha = b->d_alpha; L.beta = b->d_beta;
@@ -479,7 +482,18 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
       cus = prop.multiProcessorCount;
     threads = (!direct && cfg->n_cells >= 4 * cus) ? 256 : 512;
   }
-  if (threads % 64 || threads < 64 || threads > 512) { fail(RS_ERR_INVALID, "threads_per_cell %d", threads); return nullptr; }
+  int want_jit = cfg->jit;
+  if (const char* e = getenv("RS_JIT")) want_jit = atoi(e);
+  /* the kernels built into the library are bounded at 512 threads; a shape-specialised build takes up to 1 024 (the 64-RBG
+   * grid runs 640: two sort positions per lane instead of three on half of the waves) */
+  const int max_threads = (want_jit && !direct) ? 1024 : 512;
+  if (threads % 64 || threads < 64 || threads > max_threads) {
+    fail(RS_ERR_INVALID, "threads_per_cell %d (a multiple of 64 in 64..%d%s)", threads, max_threads,
+         max_threads == 512 ? "; up to 1024 with jit = 1" : "");
+    return nullptr;
+  }
+  if ((cfg->cqi_epoch_wrap | 1) != 1) { fail(RS_ERR_INVALID, "cqi_epoch_wrap %d is not 0 or 1", cfg->cqi_epoch_wrap); return nullptr; }
+  if (cfg->queue_state_lds < -1 || cfg->queue_state_lds > 1) { fail(RS_ERR_INVALID, "queue_state_lds %d outside -1..1", cfg->queue_state_lds); return nullptr; }
   if (cfg->cell.sched == RS_SCHED_UPPERBOUND) {
     /* the per-slice sorts use the register form of the sort emulation: at most four array positions per thread */
     const int N = cfg->cell.n_rbgs * cfg->cell.n_slices;
@@ -516,15 +530,18 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   b->cfg.cell.slice_weight = nullptr; b->cfg.cell.algo_alpha = nullptr; b->cfg.cell.algo_beta = nullptr;
   b->cfg.cell.algo_epsilon = nullptr; b->cfg.cell.algo_psi = nullptr; b->cfg.cell.user_to_slice = nullptr;
   if (batch_alloc(b)) { rs_batch_destroy(b); return nullptr; }
-  int want_jit = cfg->jit;
-  if (const char* e = getenv("RS_JIT")) want_jit = atoi(e);
   if (want_jit && !direct) {
     /* failure is not an error of this call: the built-in kernels stay in use and the batch keeps the reason
      * (rs_batch_jit_status); rs_last_error() is left alone */
     b->jit_wanted = true;
     b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, slice_window(b), b->jit_msg, sizeof b->jit_msg);
-    if (b->jit) b->jit_msg[0] = 0;
+    if (b->jit) snprintf(b->jit_msg, sizeof b->jit_msg, "%s", rs_jit_is_untuned(b->jit) ? "in use, built WITHOUT the -mllvm tuning options (hiprtc refused them): a few per cent slower" : "");
     else if (!b->jit_msg[0]) snprintf(b->jit_msg, sizeof b->jit_msg, "hiprtc build failed");
+    if (!b->jit && b->threads > 512) { /* nothing else can launch this workgroup size */
+      fail(RS_ERR_INVALID, "threads_per_cell %d needs the shape-specialised kernel, which could not be built: %s", b->threads, b->jit_msg);
+      rs_batch_destroy(b);
+      return nullptr;
+    }
   }
   return b;
 }
@@ -589,6 +606,17 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
 extern "C" {
 
 rs_batch* rs_batch_create(const rs_batch_config* cfg) { return batch_new(cfg, false); }
+
+/* the same behind a deterministic layout check: the caller passes the ABI version and the struct size IT was compiled with
+ * (RS_BATCH_CREATE in the header does); a caller built against another layout is refused instead of being read field-shifted */
+rs_batch* rs_batch_create_checked(const rs_batch_config* cfg, int abi_version, size_t cfg_size) {
+  if (abi_version != RS_ABI_VERSION || cfg_size != sizeof(rs_batch_config)) {
+    fail(RS_ERR_INVALID, "ABI mismatch: caller was built against ABI %d with an rs_batch_config of %zu bytes, this library is ABI %d with %zu bytes",
+         abi_version, cfg_size, RS_ABI_VERSION, sizeof(rs_batch_config));
+    return nullptr;
+  }
+  return rs_batch_create(cfg);
+}
 
 void rs_batch_destroy(rs_batch* b) {
   if (!b) return;
@@ -844,15 +872,27 @@ int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
   }
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   /* validate the queue model's LDS carve and build its kernel BEFORE the batch changes: on failure it stays as it was */
+  /* Where the bearers' hot words live (RS_QSTATE_BYTES_PER_USER per user).  LDS when they fit the CU's 160 KB -- measured on
+   * exp-customize-20slices x 512 cells (profiles/r03_queue_mode.md) -- unless that is what pushes the cell over 80 KB while the
+   * batch has more cells than the chip has CUs: then residency would halve the cells per CU, and the words stay in HBM.
+   * rs_batch_config.queue_state_lds overrides (1: LDS whenever it fits, -1: HBM). */
+  int qmode = 2;
   {
-    const RsCarve qc = rs_carve(b->S, b->U, b->R, b->sched, b->threads, 2);
+    const RsCarve lds_c = rs_carve(b->S, b->U, b->R, b->sched, b->threads, 2), hbm_c = rs_carve(b->S, b->U, b->R, b->sched, b->threads, 3);
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, b->cfg.cell.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const bool halves = lds_c.q_lds && lds_c.lds_bytes > 80 * 1024 && hbm_c.lds_bytes <= 80 * 1024 && b->n_cells > cus;
+    if (b->cfg.queue_state_lds < 0 || (b->cfg.queue_state_lds == 0 && halves)) qmode = 3;
+    const RsCarve qc = qmode == 2 ? lds_c : hbm_c;
     if (qc.lds_bytes > 160 * 1024) return fail(RS_ERR_INVALID, "cell needs %d B of LDS with the queue model (> 160 KiB)", qc.lds_bytes);
   }
   RsJitKernel* qjit = nullptr;
   char qmsg[sizeof b->jit_msg] = {0};
   if (b->jit_wanted) { /* the shape-specialised kernel of the queue model is a different code object */
-    qjit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 1, slice_window(b), qmsg, sizeof qmsg);
+    qjit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, qmode, slice_window(b), qmsg, sizeof qmsg);
     if (!qjit && !qmsg[0]) snprintf(qmsg, sizeof qmsg, "hiprtc build of the queue-model kernel failed");
+    if (!qjit && b->threads > 512) return fail(RS_ERR_INVALID, "threads_per_cell %d needs the shape-specialised queue-model kernel: %s", b->threads, qmsg);
   }
   const size_t n = (size_t)b->n_cells * 2 * U;
   if (!b->d_bearer_kind) {
@@ -872,6 +912,7 @@ int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
   HIP_TRY(hipMemcpy(b->d_bavg, avg.data(), 8 * n, hipMemcpyHostToDevice));
   /* commit: mode, carve and kernel together (the queue = 0 kernel must never run with queue arguments) */
   b->queues = true;
+  b->qmode = qmode;
   carve_lds(b, &b->base); /* schedulers 1 and 7 keep per-bearer scratch in LDS in this mode */
   if (b->jit_wanted) {
     b->jit = qjit; /* nullptr: the built-in queue kernels run, rs_batch_jit_status says why */
@@ -1108,6 +1149,15 @@ CtxLayout ctx_layout(int n, int R, int S, int G, bool with_draws) {
 }  // namespace
 
 extern "C" {
+
+rs_ctx* rs_create_checked(const rs_config* cfg, int abi_version, size_t cfg_size) {
+  if (abi_version != RS_ABI_VERSION || cfg_size != sizeof(rs_config)) {
+    fail(RS_ERR_INVALID, "ABI mismatch: caller was built against ABI %d with an rs_config of %zu bytes, this library is ABI %d with %zu bytes",
+         abi_version, cfg_size, RS_ABI_VERSION, sizeof(rs_config));
+    return nullptr;
+  }
+  return rs_create(cfg);
+}
 
 rs_ctx* rs_create(const rs_config* cfg) {
   rs_batch_config bc;
@@ -1427,7 +1477,7 @@ int rs_trace_load_dir(const char* dir, int32_t n_traces, int32_t n_rows, int32_t
 
 int rs_lds_bytes_per_cell(int n_slices, int n_users, int n_rbgs, int sched, int threads) {
   if (n_slices < 1 || n_slices > RS_MAX_SLICES || n_users < 1 || n_users > RS_MAX_USERS || n_rbgs < 1 || n_rbgs > RS_MAX_RBGS ||
-      threads < 64 || threads > 512 || threads % 64)
+      threads < 64 || threads > 1024 || threads % 64)
     return fail(RS_ERR_INVALID, "bad shape");
   return rs_carve(n_slices, n_users, n_rbgs, sched, threads).lds_bytes;
 }

@@ -93,6 +93,7 @@ constexpr int rs_nvs_scratch_bytes(int U, int R) {
 /* queue != 0: schedulers 1 and 7 allocate RBG by RBG on one wave (the per-flow "satisfied" break / the m_requiredRBs gate) and
  * keep per-bearer scratch in LDS: grant1 i32[U] | data0 i32[U] | data1 i32[U] | need i32[U] | flags u8[2U]  (queue = 1: only
  * that -- the drop-in contexts' gate scratch).
+ * queue = 3: the queue model with the bearers' words in HBM (the host's choice when LDS residency would halve the cells per CU).
  * queue = 2: the batch runs the queue model (finite MAC queues, two bearers per user) and, when the cell still fits the CU's
  * 160 KB, keeps the bearers' hot words in LDS for the whole launch instead of reading and writing them in HBM every TTI
  * (RS_QSTATE_BYTES_PER_USER per user at off_qstate, q_lds = 1; round 3, profiles/r03_queue_mode.md):
@@ -189,6 +190,7 @@ struct RsLaunch {
   int32_t sched;
   int32_t n_cells, n_ttis;
   int32_t refresh, phy_draws;
+  int32_t epoch_wrap;        /* 1: the epoch grids cycle (epoch index modulo n_epochs) instead of ending the run */
   int32_t direct;            /* 1: rs_schedule_tti -- avg/rand given, no EWMA, no clock */
   int32_t rand0, rand1;      /* direct mode */
   /* configuration (device pointers) */

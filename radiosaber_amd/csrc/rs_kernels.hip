@@ -126,6 +126,9 @@ __device__ __forceinline__ double rs_div_1000(double x) {
 #ifndef RS_JIT_WIN
 #define RS_JIT_WIN 0 /* shape-specialised build: the longest 8-aligned slice window of the batch (0: not known at compile time) */
 #endif
+#ifndef RS_JIT_QMODE
+#define RS_JIT_QMODE 2 /* shape-specialised queue-model build: rs_carve's `queue` argument (2: bearers' hot words in LDS when they fit, 3: in HBM) */
+#endif
 
 template <int SCHED, int EPT, bool FIXED, bool DIRECT, bool QUEUE = false>
 __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* lds) {
@@ -145,7 +148,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * (bit 0: the prioritized bearer has data; queue model only, bit 1: the user has any queued data = is in UsersToSchedule) */
   /* The queue model's per-bearer words (RS_QSTATE_BYTES_PER_USER per user) stay in LDS for the whole launch when the carve has
    * room (q_lds; a compile-time fact in a shape-specialised build, so its pointers are plain LDS pointers), else in HBM. */
-  constexpr RsCarve kCvQ = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, QUEUE ? 2 : 0);
+  constexpr RsCarve kCvQ = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, QUEUE ? RS_JIT_QMODE : 0);
   const bool q_lds = QUEUE && (FIXED ? kCvQ.q_lds != 0 : p.q_lds != 0);
   const int qU = FIXED ? RS_JIT_U : p.U;
   unsigned char* const qs = lds + (FIXED ? kCvQ.off_qstate : p.off_qstate);
@@ -167,7 +170,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   const int nt = FIXED ? RS_JIT_NT : (int)blockDim.x;
   const int lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
   const int S = FIXED ? RS_JIT_S : p.S, U = FIXED ? RS_JIT_U : p.U, R = FIXED ? RS_JIT_R : p.R, G = FIXED ? RS_JIT_G : p.G;
-  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, QUEUE ? 2 : 0);
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, QUEUE ? RS_JIT_QMODE : 0);
   /* byte offsets of the LDS arrays: constants in a shape-specialised build */
   struct Offs { int avgk, rcp, tab, slice, tx, misc, tbs, elems, sorted, items, sortx, cqi, queue, Upad, n_seg, n_items; };
   const Offs o = FIXED ? Offs{kCv.off_avgk, kCv.off_rcp, kCv.off_tab, kCv.off_slice, kCv.off_tx, kCv.off_misc, kCv.off_tbs,
@@ -218,12 +221,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #if defined(RS_NO_HOLD)
   constexpr bool kHoldSched = false;
 #elif defined(RS_HOLD_ALWAYS)
-  constexpr bool kHoldSched = FIXED && !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
+  constexpr bool kHoldSched = FIXED && RS_JIT_NT <= 512 && !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
 #else
   /* (MaximizeCell's kernel carries the sort and is register-bound: it holds winners only when the host passed the batch's longest
    * slice window, so that the listed items' scan keeps 8 products per lane up to 32-user windows -- 16 above: 30.2 against 29.3 M
    * TTIs/s at 50 UEs per slice with the round-robin dealing, 28.3 against 29.4 with 64-item chunks) */
-  constexpr bool kHoldSched = FIXED && RS_JIT_R <= 32 && !DIRECT && !QUEUE &&
+  constexpr bool kHoldSched = FIXED && RS_JIT_R <= 32 && RS_JIT_NT <= 512 && !DIRECT && !QUEUE &&
                               (SCHED == 8 || SCHED == 101 || SCHED == 103 || (SCHED == 9 && RS_JIT_WIN > 0 && RS_JIT_WIN <= 64));
 #endif
 #ifdef RS_NO_SPEC
@@ -363,6 +366,11 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #ifndef RS_HOLD_MAX_AGE
 #define RS_HOLD_MAX_AGE 40 /* TTIs a held winner is trusted without a full scan (the margin below is sized for it) */
 #endif
+  /* m->hist is shared by phases that never overlap: the counting sort (its histogram), then -- serial phase and top of the next
+   * TTI -- the held winners' served map (hist[0..127]) and per-wave lists (64 entries per wave from hist[128]), the speculation's
+   * served map + fix list, the queue model's per-slice words.  The lists must fit behind the map: */
+  static_assert(!kHoldSched || 128 + 64 * (RS_JIT_NT / 64) <= (int)(sizeof(RsMisc::hist) / sizeof(uint16_t)),
+                "held winners: the per-wave lists in RsMisc::hist are sized for at most 14 waves");
   unsigned long long* const hold_bits = (unsigned long long*)(lds + o.items + ((2 * o.n_items + 7) & ~7));
   uint32_t* const hold_served = (uint32_t*)m->hist; /* [64] */
   uint16_t* const hold_list = m->hist + 128;        /* 64 entries per wave: the items a wave scans again */
@@ -395,6 +403,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   if (!kDirect && p.cqi_mode == RS_CQI_EPOCHS) {
     epoch = n_done / p.refresh;
     epoch_pos = (int)(n_done - epoch * p.refresh);
+    if (p.epoch_wrap) epoch %= p.n_epochs; /* the uploaded grids cycle (rs_batch_config.cqi_epoch_wrap) */
   }
   /* EESM decision thresholds X[1..13] as wave-uniform values for the whole launch (13 scalar register pairs when they fit) */
   double xthr_k[13];
@@ -2519,7 +2528,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
     served_prev = m->served;
     n_done += 1;
-    if (++epoch_pos == p.refresh) { epoch_pos = 0; ++epoch; }
+    if (++epoch_pos == p.refresh) {
+      epoch_pos = 0;
+      if (++epoch == p.n_epochs && p.epoch_wrap) epoch = 0;
+    }
     if (!kDirect) t += 0.001; /* ref: src/core/eventScheduler/simulator.cc:117-126 */
   }
 
@@ -2598,9 +2610,14 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
 #ifndef RS_JIT_QUEUE
 #define RS_JIT_QUEUE 0
 #endif
-/* shape-specialised entry point compiled at run time (rs_jit.cpp): static LDS of exactly the carve's size */
-extern "C" __global__ void __launch_bounds__(RS_JIT_NT, 4) rs_cell_kernel_jit(RsLaunch p) {
-  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_QUEUE != 0 ? 2 : 0);
+/* shape-specialised entry point compiled at run time (rs_jit.cpp): static LDS of exactly the carve's size.  RS_JIT_WPE = waves
+ * per SIMD the register allocation must leave room for (4: 128 VGPRs, two 512-thread cells per CU; rs_jit.cpp passes 5 for the
+ * 640-thread cells of the 64-RBG grid: two cells = 20 waves per CU) */
+#ifndef RS_JIT_WPE
+#define RS_JIT_WPE 4
+#endif
+extern "C" __global__ void __launch_bounds__(RS_JIT_NT, RS_JIT_WPE) rs_cell_kernel_jit(RsLaunch p) {
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_QUEUE != 0 ? RS_JIT_QMODE : 0);
   __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
   constexpr int kEpt = (RS_JIT_SCHED != 9 && RS_JIT_SCHED != 10) ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);
   rs_cell_body<RS_JIT_SCHED, kEpt, true, false, RS_JIT_QUEUE != 0>(p, lds);

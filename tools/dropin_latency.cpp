@@ -27,7 +27,7 @@ static double run(int ues_per_slice, int R, int G, int sched, int calls) {
   cfg.algo_epsilon = one.data();
   cfg.algo_psi = one.data();
   cfg.user_to_slice = u2s.data();
-  rs_ctx* c = rs_create(&cfg);
+  rs_ctx* c = RS_CREATE(&cfg);
   if (!c) { fprintf(stderr, "rs_create: %s\n", rs_last_error()); exit(1); }
   std::mt19937 g(1);
   std::vector<uint8_t> cqi((size_t)U * R);

@@ -9,7 +9,13 @@
 #include <cstdint>
 #include <vector>
 #include <algorithm>
+#ifndef RS_WAVE_FINISH_MAX
+#define RS_WAVE_FINISH_MAX 4 /* the task form's hand-over to the packed single-wave finish (the product's kFinishMax at EPT > 1) */
+#endif
 #include "rs_sort_tasks.h"
+#ifdef MB_HYBRID /* round 4: workgroup levels until every sub-range fits MB_HYBRID registers per lane, then tasks (make_hybrid.py) */
+#include "rs_sort_hybrid_gen.h"
+#endif
 
 #ifndef MB_N
 #define MB_N 500
@@ -41,7 +47,11 @@ __global__ void __launch_bounds__(MB_NT) bench(const uint32_t* recs, int n_prob_
       unsigned long long t0 = __builtin_readcyclecounter();
       __builtin_amdgcn_s_setprio(1);
       if (V == 0) introsort_levels_reg<kEpt>(s_elems, MB_N, s_sorted, s_cuts, &misc, nullptr);
+#ifdef MB_HYBRID
+      else introsort_levels_hybrid<kEpt, MB_HYBRID>(s_elems, MB_N, s_sorted, s_cuts, &misc, sub);
+#else
       else introsort_tasks<8, kEpt>(s_elems, MB_N, s_sorted, s_cuts, &misc, 0, sub);
+#endif
       unsigned long long t1 = __builtin_readcyclecounter();
       if (r == 0 && blockIdx.x == 0)
         for (int i = tid; i < MB_N; i += MB_NT) out_loop[(size_t)p * MB_N + i] = s_elems[i];
@@ -79,7 +89,13 @@ int main(int argc, char** argv) {
   (void)hipMalloc(&d_cyc, 8192 * 8);
   (void)hipMemcpy(d_recs, recs.data(), recs.size() * 4, hipMemcpyHostToDevice);
   const int reps = 20;
+#ifdef MB_HYBRID
+  const char* names[] = {"workgroup levels", "hybrid -> tasks"};
+  printf("N = %d records, %d threads, hybrid hand-over at K <= %d registers per lane\n", MB_N, MB_NT, MB_HYBRID);
+#else
   const char* names[] = {"workgroup levels", "task per wave"};
+  printf("N = %d records, %d threads\n", MB_N, MB_NT);
+#endif
   for (int blocks : {256, 512, 1024})
     for (int v = 0; v < 2; ++v) {
       (void)hipMemset(d_sorted, 0, recs.size() * 4);

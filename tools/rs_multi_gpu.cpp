@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
     bc.cell.slice_weight = weight.data(); bc.cell.algo_alpha = zeros.data(); bc.cell.algo_beta = zeros.data();
     bc.cell.algo_epsilon = ones.data(); bc.cell.algo_psi = ones.data(); bc.cell.user_to_slice = u2s.data();
     bc.n_cells = cells; bc.first_tti = 100; bc.cqi_refresh = 40; bc.phy_error_draws = 0; bc.threads_per_cell = 0; bc.jit = 1;
-    batch[d] = rs_batch_create(&bc);
+    batch[d] = RS_BATCH_CREATE(&bc);
     if (!batch[d]) { fprintf(stderr, "rs_batch_create on device %d: %s\n", d, rs_last_error()); return 2; }
     /* global cell ids d*cells .. : the sharding rule of radiosaber_amd/sharding.py (seed.h commonSeed[0] = 805290992) */
     std::vector<uint32_t> seeds(cells);
