@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define RS_ABI_VERSION 9 /* 9: rs_create_checked / rs_batch_create_checked (RS_CREATE / RS_BATCH_CREATE: the caller's ABI version and struct size are
-                            checked), rs_batch_config.cqi_epoch_wrap / queue_state_lds, threads_per_cell up to 1024 with jit, rs_jit_selfcheck_untuned;
+                            checked), rs_batch_config.cqi_epoch_wrap / queue_state_lds, threads_per_cell up to 1024 with jit, rs_jit_selfcheck_untuned, rs_batch_write_state;
                             8: rs_jit_selfcheck_queue, rs_config.synthetic_exp, any integer algo_epsilon / algo_psi in drop-in contexts; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
                             6: rs_tti_in.required_rbs / data_to_transmit (the gates of schedulers 7 and 1 in the drop-in mode);
                             5: per-PRB batch sources (rs_batch_upload_cqi_epochs_prb, rs_batch_set_trace_prb);
@@ -367,6 +367,10 @@ int rs_batch_run_timed(rs_batch* b, int32_t n_ttis, int32_t launches, float* ms_
  * slice_state [n_cells][S] (slice_rbs_offset_, or slice_ewma_time_ for NVS) */
 int rs_batch_read_state(rs_batch* b, double* avg_rate, int64_t* cum_bytes, int64_t* cum_rbs,
                         double* slice_state);
+/* the inverse for what a restart (or a test) sets: avg_rate [n_cells][U] (every value >= 1, the EWMA's clamp) and
+ * slice_state [n_cells][S]; either may be NULL = left alone.  Between launches only; not with the queue model (one average per
+ * bearer there).  (ABI 9) */
+int rs_batch_write_state(rs_batch* b, const double* avg_rate, const double* slice_state);
 /* the simulated clock of every cell (ref: src/core/eventScheduler/simulator.cc:117-126): t [n_cells] = time stamp of the next
  * TTI, last_update [n_cells] = RadioBearer::m_lastUpdate; either may be NULL */
 int rs_batch_read_clock(rs_batch* b, double* t, double* last_update);

@@ -11,7 +11,7 @@ from pathlib import Path
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-LIB = HERE / "librs_oracle.so"
+LIB = Path(os.environ.get("RS_ORACLE_LIB", HERE / "librs_oracle.so"))  # (tools/sanitize_cpu.sh points this at the ASan/UBSan build)
 REF_DIR = HERE / "_ref"
 
 SCHED_PF, SCHED_NVS, SCHED_SEQUENTIAL, SCHED_MAXCELL, SCHED_VOGEL, SCHED_UPPERBOUND, SCHED_NVS_NONGREEDY = 1, 7, 8, 9, 103, 10, 11

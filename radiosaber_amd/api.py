@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "rs_batch_upload_cqi_epochs_prb", "rs_batch_set_trace_prb",
     "rs_batch_set_bearers", "rs_batch_set_arrivals", "rs_batch_read_bearer_state", "rs_internet_flow_arrivals",
     "rs_device_source_hash",
-    "rs_create_checked", "rs_batch_create_checked", "rs_jit_selfcheck_untuned",
+    "rs_create_checked", "rs_batch_create_checked", "rs_jit_selfcheck_untuned", "rs_batch_write_state",
 ]
 
 _lib = None
@@ -153,6 +153,7 @@ def lib():
     L.rs_batch_run_timed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     L.rs_batch_read_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    L.rs_batch_write_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rs_batch_slice_bytes_device.argtypes = [C.c_void_p, C.c_void_p]
     L.rs_batch_slice_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.rs_jit_selfcheck.argtypes = [C.c_int] * 6 + [C.c_char_p, C.c_size_t]
@@ -588,6 +589,15 @@ class BatchScheduler:
         _check(lib().rs_batch_read_state(self._h, _p(avg, C.c_double), _p(cb, C.c_int64), _p(cr, C.c_int64),
                                          _p(sl, C.c_double)))
         return {"avg_rate": avg, "cum_bytes": cb, "cum_rbs": cr, "slice_state": sl}
+
+    def write_state(self, avg_rate=None, slice_state=None):
+        """Set the PF averages [n_cells][U] (>= 1) and / or the slice state [n_cells][S] between launches (rs_batch_write_state)."""
+        a = None if avg_rate is None else np.ascontiguousarray(avg_rate, np.float64)
+        s = None if slice_state is None else np.ascontiguousarray(slice_state, np.float64)
+        assert a is None or a.shape == (self.n_cells, self.U)
+        assert s is None or s.shape == (self.n_cells, self.S)
+        _check(lib().rs_batch_write_state(self._h, _p(a, C.c_double) if a is not None else None,
+                                          _p(s, C.c_double) if s is not None else None))
 
     # ---- finite queues (SURVEY 8f N3) ----
     def set_bearers(self, bearer_kind):

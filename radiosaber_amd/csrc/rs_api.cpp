@@ -856,6 +856,23 @@ int rs_batch_read_state(rs_batch* b, double* avg, int64_t* cum_bytes, int64_t* c
   return RS_OK;
 }
 
+/* the inverse of rs_batch_read_state for the two arrays a restart needs set: PF averages (RadioBearer::m_averageTransmissionRate,
+ * ref: src/flows/radio-bearer.cpp:54 starts them at 100 000) and slice_rbs_offset_ / slice_ewma_time_ */
+int rs_batch_write_state(rs_batch* b, const double* avg, const double* slice_state) {
+  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  if (b->direct) return fail(RS_ERR_INVALID, "drop-in contexts take the averages per call");
+  if (b->queues) return fail(RS_ERR_STATE, "the queue model keeps one average per bearer: not settable through this call");
+  const size_t n = (size_t)b->n_cells * b->U;
+  if (avg)
+    for (size_t i = 0; i < n; i++)
+      if (!(avg[i] >= 1.0) || !(avg[i] <= 1e300)) return fail(RS_ERR_INVALID, "avg_rate[%zu] = %g: the EWMA keeps averages at or above 1 (radio-bearer.cpp:160-162)", i, avg[i]);
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (avg) HIP_TRY(hipMemcpy(b->d_avg, avg, 8 * n, hipMemcpyHostToDevice));
+  if (slice_state) HIP_TRY(hipMemcpy(b->d_sstate, slice_state, 8 * (size_t)b->n_cells * b->S, hipMemcpyHostToDevice));
+  return RS_OK;
+}
+
 /* ---- finite queues ---- */
 int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
   if (!b || !bearer_kind) return fail(RS_ERR_INVALID, "null argument");

@@ -185,28 +185,52 @@ def test_held_winners_long_run_uneven_launches(rs, oracle, sched):
 @pytest.mark.parametrize("sched", [9, 8])
 def test_held_winners_age_cap_ends_the_holds(rs, oracle, sched):
     """With the CQI grid refreshed only every 200 TTIs it is RS_HOLD_MAX_AGE (40 TTIs), not the refresh, that forces the full
-    scans the margin mu = 2^-18 + 2 / (1 + avg_w) is sized for -- a line no other test reaches.  Two starved slices (weights far
-    below their share, poor CQI is likely for some of their users) keep averages decaying through the avg_w >= 64 condition of
-    the held test and down to the clamp at 1, so winners on both sides of that boundary occur; final state bitwise."""
+    scans the margin mu = 2^-18 + 2 / (1 + avg_w) is sized for -- a line no other test reaches.  And the held test's other
+    condition, avg_w >= 64, is exercised from both sides: two starved slices (tiny weights: served a few times per hundred TTIs)
+    start with uploaded averages of 66..120 (rs_batch_write_state), so their winners pass the condition in the launch's first
+    full scan and fail it at the age-cap scans of TTI 40 and 80 (0.98^40 = 0.45), while a few users of the other slices start
+    right at 64 / just below.  Final state bitwise."""
     ues = [25] * 18 + [30, 20]
     w = [0.0555] * 18 + [0.0006, 0.0004]
     R, G, n_cells, n_ttis, refresh = 25, 4, 6, 2000, 200
     sc = rs.SliceConfig(ues, weight=w)
+    U = sc.n_users
     seeds = np.arange(n_cells, dtype=np.uint32) * 13 + 4242
+    rng = np.random.default_rng(64)
+    avg0 = np.full((n_cells, U), 100000.0)
+    avg0[:, 450:] = rng.uniform(66.0, 120.0, (n_cells, 50))
+    avg0[:, 0:450:9] = rng.choice([63.5, 64.0, 64.5, 1.0, 200.0], (n_cells, 50))
     b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=True, cqi_refresh=refresh)
     assert b.kernel_name == "rs_cell_kernel_jit"
     b.seed(seeds)
     b.synthesize_cqi(0xA6E + sched, n_ttis // refresh)
-    for n in (333, 1000, 667):
+    b.write_state(avg_rate=avg0)
+    with pytest.raises(rs.RadioSaberError, match="at or above 1"):
+        b.write_state(avg_rate=np.zeros((n_cells, U)))
+    grids = [b.download_cqi_epochs(c) for c in range(n_cells)]
+
+    def oracle_states(n):
+        def one(c):
+            cell = oracle.Cell(ues, R, G, sched, weights=w)
+            cell.set_avg_rate(avg0[c])
+            cell.run_synth(grids[c], int(seeds[c]), n, refresh=refresh, log=False)
+            return cell.state()
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+            return list(ex.map(one, range(n_cells)))
+
+    b.run(85)  # full scans at TTI 0 (launch start), 40 and 80 (age cap)
+    st = b.state()
+    ref = oracle_states(85)
+    below = sum(int((r["avg_rate"][450:] < 64.0).sum()) for r in ref)
+    assert below > 20, "the starved slices' averages did not cross the held test's avg_w >= 64 boundary"
+    for c in range(n_cells):
+        _assert_state_equal(st, c, ref[c], f"sched {sched} after 85 TTIs")
+    for n in (248, 1000, 667):
         b.run(n)
     st = b.state()
-    grids = [b.download_cqi_epochs(c) for c in range(n_cells)]
-    ref = _oracle_final_states(oracle, ues, R, G, sched, w, lambda c: grids[c], seeds, n_ttis, refresh=refresh)
-    low = 0
+    ref = oracle_states(n_ttis)
     for c in range(n_cells):
         _assert_state_equal(st, c, ref[c], f"sched {sched}")
-        low += int((ref[c]["avg_rate"][450:] < 64.0).sum())
-    assert low > 0, "no average below the held test's avg_w >= 64 boundary: the starved slices did not do their job"
     b.close()
 
 
