@@ -236,6 +236,21 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
                               (!FIXED || RS_JIT_U <= 32 * RS_JIT_S) && (kSpecBesideVec || !(FIXED && kVecScan));
 #endif
   const bool spec_enabled = kSpecSched && nwaves >= 2 && U <= 32 * S && (kSpecBesideVec || !vec_scan);
+  /* Schedulers 1 and 7 (round 4): their TTI ends with wave 0 alone (per-RBG reduction, link adaptation: 25-40 % of the TTI) while
+   * the other waves idle.  Those waves prepare TTI t+1 meanwhile -- exactly, nothing speculative:
+   *   both   the EWMA of every user as (1 - beta) * avg (what the reference computes for a user that was not served: + beta * 0
+   *          adds nothing); wave 0 adds beta * rate for the users it served as soon as it knows their bytes -- the reference's sum
+   *          of two rounded products (ref: src/flows/radio-bearer.cpp:139-164);
+   *   NVS    SelectSliceToServe of TTI t+1 (downlink-nvs-scheduler.cpp:94-142 reads slice_ewma_time_ only, not the allocation),
+   *          and, when that slice is NOT the one being served now (its users' averages then do not depend on this TTI's
+   *          allocation) and TTI t+1 reads the same CQI grid, the whole metric scan of TTI t+1: such a TTI starts with its
+   *          winners in place and is one workgroup barrier long.
+   * Shape-specialised batch kernels without queues (the owners' byte counters live in registers there). */
+#ifdef RS_NO_EARLY17
+  constexpr bool kEarly17 = false;
+#else
+  constexpr bool kEarly17 = FIXED && !DIRECT && !QUEUE && (SCHED == 1 || SCHED == 7);
+#endif
 
   double* s_avg = (double*)lds;
   double* s_avgk = (double*)(lds + o.avgk);
@@ -597,6 +612,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   bool have_quota = false; /* held winners: this TTI's quotas were worked out by the quota wave during the previous TTI's serial phase */
   bool have_ewma = false;  /* held winners: ... and so were the PF averages and terms (decay by the idle waves, served users by wave 0) */
   int pre_listed = -1;     /* held winners: this wave's list for this TTI was packed during the previous TTI's serial phase (-1: no) */
+  bool have_scan = false;  /* NVS (kEarly17): this TTI's winners were found during the previous TTI's serial phase */
   for (int tti = 0; tti < p.n_ttis; ++tti) {
     RS_STAMP(11);
     auto prb_ptr = [&](int user, int r2) -> const uint8_t* { /* the G PRBs of RBG r2 as `user` reported them */
@@ -844,7 +860,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       const double dt = t - last_update;
       auto ewma_user = [&](int u, int ku) {
         double a = s_avg[u];
-        if ((kSpecSched || kHoldSched) && a < 1) a = 1; /* an update prepared in the serial phase leaves the unclamped product behind */
+        if ((kSpecSched || kHoldSched || kEarly17) && a < 1) a = 1; /* an update prepared in the serial phase leaves the unclamped product behind */
         if (do_ewma) {
           int txb = s_tx[u];
           if (kCumRegs) {
@@ -904,11 +920,13 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         for (int ku = 0; ku < kKU; ++ku) {
           const int u = tid + ku * nt;
           if (u < U) {
-            const int v = s_tx[u];
+            int v = s_tx[u];
             if (v != 0) {
+              /* (NVS with its winners in place runs this TTI without a barrier before wave 0's next grant: take the word atomically) */
+              if (kEarly17 && SCHED == 7) v = atomicExch(&s_tx[u], 0);
+              else s_tx[u] = 0;
               cum_r[ku] += (v >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK;
               cum_b[ku] += v & RS_TX_BYTES_MASK;
-              s_tx[u] = 0;
             }
           }
         }
@@ -976,13 +994,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       m->target[lane] = target;
       m->quota[lane] = quota;
     };
-    auto quota_phase = [&](int served_before) {
-      if (!kTransport && !kDirect && p.phy_draws)
-        for (int i = 0; i < served_before; i++) (void)rng.next();
-      if (kTransport) {
-        quota_draws(served_before);
-        quota_targets();
-      } else if (SCHED == 7 || SCHED == 11) {
+    /* SelectSliceToServe (one wave, lanes = slices); also called one TTI ahead, during the previous TTI's serial phase (kEarly17) */
+    auto nvs_pick = [&](int32_t* slice_out) {
         /* SelectSliceToServe, ref: downlink-nvs-scheduler.cpp:94-142 */
         int pick;
         if (kDirect) {
@@ -1015,21 +1028,37 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             s_sstate[lane] = e2;
           }
         }
-        if (lane == 0) m->nvs_slice = pick;
+        if (lane == 0) *slice_out = pick;
         m->target[lane] = 0;
         m->quota[lane] = 0;
+    };
+    /* the served slice's word, by TTI parity when picks are made a TTI ahead: a TTI that starts without a barrier may still be
+     * reading its own while the quota wave already writes the next one's */
+    int32_t* const nvs_word_cur = (kEarly17 && (tti & 1)) ? &m->pad[0] : &m->nvs_slice;
+    int32_t* const nvs_word_nxt = (kEarly17 && !(tti & 1)) ? &m->pad[0] : &m->nvs_slice;
+    auto quota_phase = [&](int served_before) {
+      if (!kTransport && !kDirect && p.phy_draws)
+        for (int i = 0; i < served_before; i++) (void)rng.next();
+      if (kTransport) {
+        quota_draws(served_before);
+        quota_targets();
+      } else if (SCHED == 7 || SCHED == 11) {
+        nvs_pick(nvs_word_cur);
       } else {
         m->target[lane] = 0;
         m->quota[lane] = 0;
       }
     };
     if (wave == quota_wave && !have_spec && !have_quota) quota_phase(served_prev);
+    if (kEarly17 && SCHED == 7 && have_quota && wave == quota_wave && p.phy_draws) /* the pick was made a TTI ahead; the error model's */
+      for (int i = 0; i < served_prev; i++) (void)rng.next();                       /* draws (one per user served) still come first   */
     int seg_lo = 0;   /* NVS: the served slice */
     int nvs_runs = 1; /* sched 7: runs of the served slice scanned in P3 */
     if (SCHED == 7 || SCHED == 11) {
-      __syncthreads(); /* P3 scans the slice P2 picked */
-      seg_lo = kDirect ? 0 : m->nvs_slice;
+      if (!(kEarly17 && have_quota)) __syncthreads(); /* P3 scans the slice P2 picked (a pick made a TTI ahead lies behind that TTI's closing barrier) */
+      seg_lo = kDirect ? 0 : *nvs_word_cur;
     }
+    const int seg_this = seg_lo; /* (the scanning waves of an NVS cell move seg_lo on to the next TTI's slice in the serial phase) */
     RS_STAMP(1);
 
     if constexpr (SCHED == 11) {
@@ -1606,6 +1635,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #endif
     } else
     if constexpr (SCHED != 11 && !kQSerial) {
+     if (!(kEarly17 && have_scan)) { /* (NVS: the winners may be in place already, found during the previous TTI's serial phase) */
       /* fix-up of a speculated TTI: only the items whose speculative winner was served in the previous TTI (listed by the
        * scanning waves) are scanned again, now with the true averages; a list that overflowed means all of them.  One loop
        * for both cases: the scan is inlined once here and once in the serial phase. */
@@ -1618,8 +1648,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       const int n_scan = listed ? n_fix + (n_items - n_spec) : n_items;
       for (int j = tid; j < n_scan; j += nt)
         scan_item(listed ? (j < n_fix ? (int)fix_list[j] : n_spec + (j - n_fix)) : j, cur_bu, cur_rec, RsInt<RS_P3_BLOCK_TOP>{});
+     }
     }
-    __syncthreads();
+    /* (an NVS TTI whose averages, slice and winners were all prepared has written nothing since the previous TTI's closing barrier) */
+    if (!(kEarly17 && SCHED == 7 && have_scan)) __syncthreads();
     if (kTransport && p.log_keys) {
       /* parity tests only: what the inter-slice step is about to read, [R][S] per TTI: CQI key of the slice's best user
        * (0: no user) | (user + 1) << 8 -- flow_spectraleff / user_index of ref :545-567 */
@@ -1829,6 +1861,17 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     constexpr bool kCoopScan = false;
 #endif
     const bool coop_scan = kCoopScan && vec_scan && !spec_enabled;
+    /* schedulers 1 / 7: the other waves prepare TTI t+1 beside wave 0 (see kEarly17); not past the end of the launch */
+    const bool early17 = kEarly17 && nwaves >= 2 && tti + 1 < p.n_ttis;
+    bool early_scan_ok = false; /* NVS: TTI t+1 reads the CQI grid that is in LDS now */
+    if (kEarly17 && SCHED == 7 && early17) {
+      if (p.cqi_mode == RS_CQI_EPOCHS) {
+        early_scan_ok = epoch_pos + 1 != p.refresh;
+      } else if (p.cqi_mode == RS_CQI_TRACE) {
+        const double t_next = t + 0.001;
+        early_scan_ok = reported && !(((int)(t_next * 1000) - last_sent) >= 40);
+      }
+    }
     int pre_slice = -1, pre_got = 0;
     if constexpr (kCoopScan) {
       if (coop_scan) {
@@ -1850,6 +1893,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       int my_target = 0, my_quota = 0; /* lane s: this TTI's values (the quota wave may overwrite the LDS copies for TTI t+1) */
       if (kHoldSched) {
         hold_served[lane] = 0u; /* (m->hist is free: this TTI's lists are consumed, the counting sort is over) */
+      }
+      if (kEarly17) {
+        if (lane == 0) { fl_prev->ctr_p1 = 0; fl_prev->ctr_p3 = 0; fl_prev->greedy_done = 0; fl_prev->n_fix = 0; }
       }
       if (kSpecSched || kHoldSched) {
         my_target = m->target[lane];
@@ -2209,6 +2255,11 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
       }
       RS_STAMP(5);
+      if (kEarly17 && SCHED == 7 && early17) {
+        /* the winner tables are in this wave's registers now: the scanning waves may overwrite them with TTI t+1's */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) atomicExch(&fl_cur->greedy_done, 1);
+      }
 
       /* ---------------- P5: link adaptation + DoStopSchedule counters (lanes = RBGs) ---------------- */
       /* lanes holding the same user; the lowest one (leader) handles the user */
@@ -2354,23 +2405,24 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
               atomicAdd((unsigned long long*)&p.cum_rbs[(size_t)cell * U + owner], (unsigned long long)nprb);
             }
           }
-          if ((kSpecSched && spec_next) || (kHoldSched && ewma_next)) tbs_bytes_next = bytes;
+          if ((kSpecSched && spec_next) || (kHoldSched && ewma_next) || early17) tbs_bytes_next = bytes;
         }
       }
-      if (kHoldSched && ewma_next) {
+      if ((kHoldSched && ewma_next) || early17) {
         /* the exact EWMA of the served users for TTI t+1, on top of the decay the other waves applied (all of them first) */
         while (rs_lds_load(&fl_cur->ctr_p1) < nwaves - 1) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (leader) {
           const double t_next = t + 0.001;
           const double dt_next = t_next - t; /* Now - m_lastUpdate of the next update: m_lastUpdate is this TTI's time */
-          double a = s_avg[owner];
+          double a = SCHED == 1 ? s_avgk[owner] : s_avg[owner];
           const double rate = (double)(tbs_bytes_next * 8) / dt_next;
           const double beta = 0.02;
           a = a + (beta * rate);
           if (a < 1) a = 1;
           s_avg[owner] = a;
-          pf_terms(owner, a);
+          if (SCHED == 1) s_rcp32[owner] = __builtin_amdgcn_rcpf((float)a);
+          else pf_terms(owner, a);
         }
       }
       if (kSpecSched && spec_next) {
@@ -2411,18 +2463,58 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
       }
     }
-    if (kHoldSched && ewma_next && wave != 0) {
+    if (kEarly17 && SCHED == 7 && early17 && wave == quota_wave) {
+      /* SelectSliceToServe of TTI t+1 first: the scanning waves wait for it */
+      nvs_pick(nvs_word_nxt);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) atomicExch(&fl_cur->n_fix, 1);
+    }
+    if (((kHoldSched && ewma_next) || early17) && wave != 0) {
       const int nsp = nt - 64, me = tid - 64;
       for (int u = me; u < U; u += nsp) {
         double a = s_avg[u];
         if (a < 1) a = 1;
         const double beta = 0.02;
         const double us = (1 - beta) * a;
-        s_avg[u] = us; /* unclamped: a served user's exact update adds beta * rate to it */
-        pf_terms(u, us < 1 ? 1.0 : us);
+        if (SCHED == 1) {
+          /* the per-flow PF scheduler divides by s_avg itself: it keeps the clamped value, the raw product waits in s_avgk (unused
+           * by this scheduler) for wave 0 */
+          s_avgk[u] = us;
+          s_avg[u] = us < 1 ? 1.0 : us;
+          s_rcp32[u] = __builtin_amdgcn_rcpf((float)(us < 1 ? 1.0 : us));
+        } else {
+          s_avg[u] = us; /* unclamped: a served user's exact update adds beta * rate to it */
+          pf_terms(u, us < 1 ? 1.0 : us);
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) atomicAdd(&fl_cur->ctr_p1, 1);
+    }
+    if (kEarly17 && SCHED == 7 && early17) {
+      /* TTI t+1's slice is known once the quota wave has published it; its metric scan can run now when that slice is not the one
+       * wave 0 is serving (then no average it reads changes any more) and TTI t+1 reads this CQI grid */
+      if (wave != 0) {
+        while (rs_lds_load(&fl_cur->n_fix) < 1) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int seg_next = rs_lds_load(nvs_word_nxt);
+        if (early_scan_ok && seg_next != seg_this) {
+          /* every decayed average first (the scan reads other threads' users), and wave 0 must have read TTI t's winners */
+          while (rs_lds_load(&fl_cur->ctr_p1) < nwaves - 1) __builtin_amdgcn_s_sleep(1);
+          while (rs_lds_load(&fl_cur->greedy_done) < 1) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          seg_lo = seg_next; /* (this wave's copies: wave 0 keeps TTI t's; everybody re-reads them at the top of TTI t+1) */
+          int n_next = o.n_items;
+          if (nvs_split) {
+            nvs_lo = m->seg_begin[seg_lo];
+            nvs_hi = m->seg_begin[seg_lo + 1];
+            nvs_first = nvs_lo & ~7;
+            nvs_runs = idiv_small(nvs_hi - nvs_first + nvs_seg - 1, nvs_seg);
+            n_next = R * nvs_runs;
+          }
+          const int nsp = nt - 64, me = tid - 64;
+          for (int it = me; it < n_next; it += nsp) scan_item(it, cur_bu, cur_rec, RsInt<0>{});
+        }
+      }
     }
     if (quota_next && wave == quota_wave) {
       /* TTI t+1's draws and remainder rotations need nothing of TTI t (unless the error model's draws, one per UE served, come
@@ -2518,8 +2610,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     __syncthreads();
     RS_STAMP(8);
     have_spec = kSpecSched && spec_next;
-    have_quota = quota_next;
-    have_ewma = kHoldSched && ewma_next;
+    have_quota = quota_next || (kEarly17 && SCHED == 7 && early17);
+    have_ewma = (kHoldSched && ewma_next) || early17;
+    if (kEarly17 && SCHED == 7) {
+      /* did the scanning waves find TTI t+1's winners?  The same test they made, on values that are final behind the barrier */
+      have_scan = early17 && early_scan_ok && rs_lds_load(nvs_word_nxt) != seg_this;
+    }
     /* (the packing condition is the same on every wave: wave 0 learns here that wave 1 packed its list) */
     if (wave == 0 && kHoldSched && ewma_next && hold_ok && n_items_rt <= 64 * nwaves) {
 #ifndef RS_HOLD_NO_PRELIST
@@ -2560,7 +2656,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       const long long b = (long long)cum_b[ku] + (v & RS_TX_BYTES_MASK), r = (long long)cum_r[ku] + ((v >> RS_TX_NPRB_SHIFT) & RS_TX_NPRB_MASK);
       if (b != 0) p.cum_bytes[(size_t)cell * U + u] += b;
       if (r != 0) p.cum_rbs[(size_t)cell * U + u] += r;
-      p.avg[(size_t)cell * U + u] = ((kSpecSched || kHoldSched) && s_avg[u] < 1) ? 1.0 : s_avg[u];
+      p.avg[(size_t)cell * U + u] = ((kSpecSched || kHoldSched || kEarly17) && s_avg[u] < 1) ? 1.0 : s_avg[u];
       p.tx_bytes[(size_t)cell * U + u] = v ? (v | RS_TX_COUNTED) : 0;
     }
   }
