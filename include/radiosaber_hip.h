@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define RS_ABI_VERSION 9 /* 9: rs_create_checked / rs_batch_create_checked (RS_CREATE / RS_BATCH_CREATE: the caller's ABI version and struct size are
-                            checked), rs_batch_config.cqi_epoch_wrap / queue_state_lds, threads_per_cell up to 1024 with jit, rs_jit_selfcheck_untuned, rs_batch_write_state;
+                            checked), rs_batch_config.cqi_epoch_wrap / queue_state_lds, threads_per_cell up to 1024 with jit, rs_jit_selfcheck_untuned, rs_batch_write_state, rs_ctx_specialize, rs_jit_selfcheck_dropin;
                             8: rs_jit_selfcheck_queue, rs_config.synthetic_exp, any integer algo_epsilon / algo_psi in drop-in contexts; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
                             6: rs_tti_in.required_rbs / data_to_transmit (the gates of schedulers 7 and 1 in the drop-in mode);
                             5: per-PRB batch sources (rs_batch_upload_cqi_epochs_prb, rs_batch_set_trace_prb);
@@ -193,6 +193,13 @@ typedef struct rs_tti_out {
  * DownlinkNVSScheduler::RBsAllocation (ref: downlink-nvs-scheduler.cpp:275-358; pass the users of the
  * slice SelectSliceToServe chose).  The context carries slice_rbs_offset_ between calls. */
 int rs_schedule_tti(rs_ctx* ctx, const rs_tti_in* in, rs_tti_out* out);
+/* Optional, once after rs_create: compile this context's own build of the one-TTI kernel (hiprtc, ~2 s per shape and process,
+ * cached) -- slices, RBGs, PRBs per RBG, scheduler and the user capacity as compile-time constants, the users of a call still a
+ * launch argument.  Results are identical; a call gets shorter.  RS_OK, or RS_ERR_HIP with the context left on the
+ * kernels built into the library.  The C++ adapter calls it from its constructor.  (ABI 9) */
+int rs_ctx_specialize(rs_ctx* ctx);
+/* build check without a GPU: does that kernel compile for a context of this shape? (code size or a negative value) */
+int rs_jit_selfcheck_dropin(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, char* err, size_t errlen);
 /* slice_rbs_offset_ accessors (ref: downlink-transport-scheduler.h:38) */
 int rs_get_slice_offset(rs_ctx* ctx, double* offset /* [S] */);
 int rs_set_slice_offset(rs_ctx* ctx, const double* offset /* [S] */);

@@ -94,6 +94,7 @@ ABI_SYMBOLS = [
     "rs_batch_set_bearers", "rs_batch_set_arrivals", "rs_batch_read_bearer_state", "rs_internet_flow_arrivals",
     "rs_device_source_hash",
     "rs_create_checked", "rs_batch_create_checked", "rs_jit_selfcheck_untuned", "rs_batch_write_state",
+    "rs_ctx_specialize", "rs_jit_selfcheck_dropin",
 ]
 
 _lib = None
@@ -123,6 +124,8 @@ def lib():
     L.rs_batch_create_checked.restype = C.c_void_p
     L.rs_batch_create_checked.argtypes = [C.POINTER(_BatchConfig), C.c_int, C.c_size_t]
     L.rs_jit_selfcheck_untuned.argtypes = [C.c_int] * 6 + [C.c_char_p, C.c_size_t]
+    L.rs_jit_selfcheck_dropin.argtypes = [C.c_int] * 6 + [C.c_char_p, C.c_size_t]
+    L.rs_ctx_specialize.argtypes = [C.c_void_p]
     L.rs_batch_destroy.argtypes = [C.c_void_p]
     L.rs_batch_seed.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
     L.rs_batch_upload_cqi_epochs.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32]
@@ -193,11 +196,13 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-def jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCHED_MAXCELL, queues=False, untuned=False):
+def jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCHED_MAXCELL, queues=False, untuned=False, dropin=False):
     """Compile the shape-specialised kernel for one shape (hiprtc, no GPU needed); returns the code size.  queues=True: the
     queue-model kernel of the shape.  untuned=True: without the -mllvm tuning options (the library's fallback build)."""
     buf = C.create_string_buffer(4096)
     fn = lib().rs_jit_selfcheck_queue if queues else (lib().rs_jit_selfcheck_untuned if untuned else lib().rs_jit_selfcheck)
+    if dropin:  # the drop-in entry point's one-TTI kernel of a context of this shape (rs_ctx_specialize)
+        fn = lib().rs_jit_selfcheck_dropin
     n = fn(n_slices, n_users, n_rbgs, rbg_size, threads, sched, buf, 4096)
     if n < 0:
         raise RadioSaberError(n, buf.value.decode(errors="replace"))
@@ -403,12 +408,15 @@ class TtiScheduler:
     """Drop-in mode: RBsAllocation() of one TTI on the GPU (rs_create / rs_schedule_tti)."""
 
     def __init__(self, slices: SliceConfig, n_rbgs: int, rbg_size: int, sched: int = RS_SCHED_MAXCELL,
-                 device: int = 0, stream: Optional[int] = None, synthetic_exp: bool = False):
+                 device: int = 0, stream: Optional[int] = None, synthetic_exp: bool = False, jit: bool = False):
+        """jit: rs_ctx_specialize -- this context's own hiprtc build of the one-TTI kernel (identical results, shorter calls)."""
         self.slices, self.R, self.rbg_size, self.sched = slices, n_rbgs, rbg_size, sched
         self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream, synthetic_exp)
         self._h = lib().rs_create_checked(C.byref(self._cfg.c), RS_ABI_VERSION, C.sizeof(_Config))
         if not self._h:
             raise RadioSaberError(-1, lib().rs_last_error().decode())
+        if jit:
+            _check(lib().rs_ctx_specialize(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

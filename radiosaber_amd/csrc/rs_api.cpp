@@ -29,7 +29,8 @@
 extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_t stream);
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes);
 struct RsJitKernel;
-extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, int qmode, int win, char* err, size_t errlen);
+extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, int qmode, int win, char* err, size_t errlen,
+                                   int direct);
 extern "C" int rs_jit_is_untuned(const RsJitKernel* k);
 extern "C" hipError_t rs_jit_launch(RsJitKernel* k, const RsLaunch* p, hipStream_t stream);
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,
@@ -534,7 +535,7 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
     /* failure is not an error of this call: the built-in kernels stay in use and the batch keeps the reason
      * (rs_batch_jit_status); rs_last_error() is left alone */
     b->jit_wanted = true;
-    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, slice_window(b), b->jit_msg, sizeof b->jit_msg);
+    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, slice_window(b), b->jit_msg, sizeof b->jit_msg, 0);
     if (b->jit) snprintf(b->jit_msg, sizeof b->jit_msg, "%s", rs_jit_is_untuned(b->jit) ? "in use, built WITHOUT the -mllvm tuning options (hiprtc refused them): a few per cent slower" : "");
     else if (!b->jit_msg[0]) snprintf(b->jit_msg, sizeof b->jit_msg, "hiprtc build failed");
     if (!b->jit && b->threads > 512) { /* nothing else can launch this workgroup size */
@@ -907,7 +908,7 @@ int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
   RsJitKernel* qjit = nullptr;
   char qmsg[sizeof b->jit_msg] = {0};
   if (b->jit_wanted) { /* the shape-specialised kernel of the queue model is a different code object */
-    qjit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, qmode, slice_window(b), qmsg, sizeof qmsg);
+    qjit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, qmode, slice_window(b), qmsg, sizeof qmsg, 0);
     if (!qjit && !qmsg[0]) snprintf(qmsg, sizeof qmsg, "hiprtc build of the queue-model kernel failed");
     if (!qjit && b->threads > 512) return fail(RS_ERR_INVALID, "threads_per_cell %d needs the shape-specialised queue-model kernel: %s", b->threads, qmsg);
   }
@@ -1350,7 +1351,8 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   const bool want_upper = b->sched == RS_SCHED_UPPERBOUND && (out->upper_rbg || out->upper_user);
   L.log_upper = want_upper ? (int32_t*)(dev_out + l.upper) : nullptr;
   /* direct mode: the kernel clears its per-user outputs itself and reads the single grid on every call */
-  HIP_TRY(rs_launch_cells(&L, b->threads, st));
+  if (b->jit) HIP_TRY(rs_jit_launch(b->jit, &L, st)); /* rs_ctx_specialize: this context's own build of the one-TTI kernel */
+  else HIP_TRY(rs_launch_cells(&L, b->threads, st));
   if (!zc) HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, l.out_total, hipMemcpyDeviceToHost, st));
   const clk::time_point t2 = c->timing ? clk::now() : clk::time_point();
   HIP_TRY(hipStreamSynchronize(st));
@@ -1395,6 +1397,22 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
     c->t_unpack += us(t3, t4);
     c->n_calls++;
   }
+  return RS_OK;
+}
+
+/* Shape specialisation of a drop-in context (round 4): the one-TTI kernel compiled for this context's slices, RBGs, PRBs per RBG,
+ * scheduler and user CAPACITY (the LDS carve), the users of a call staying a launch argument.  About two seconds per shape and
+ * process (cached); results are identical.  On failure the context keeps the kernels built into the library. */
+int rs_ctx_specialize(rs_ctx* c) {
+  if (!c) return fail(RS_ERR_INVALID, "null context");
+  rs_batch* b = c->b;
+  if (b->jit) return RS_OK;
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  const bool gate_scratch = b->sched == RS_SCHED_PF || b->sched == RS_SCHED_NVS;
+  b->jit_wanted = true;
+  b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, gate_scratch ? 1 : 0, 0, b->jit_msg, sizeof b->jit_msg, 1);
+  if (!b->jit) return fail(RS_ERR_HIP, "%s", b->jit_msg[0] ? b->jit_msg : "hiprtc build failed");
+  b->jit_msg[0] = 0;
   return RS_OK;
 }
 

@@ -126,8 +126,9 @@ __device__ __forceinline__ double rs_div_1000(double x) {
 #ifndef RS_JIT_WIN
 #define RS_JIT_WIN 0 /* shape-specialised build: the longest 8-aligned slice window of the batch (0: not known at compile time) */
 #endif
-#ifndef RS_JIT_QMODE
-#define RS_JIT_QMODE 2 /* shape-specialised queue-model build: rs_carve's `queue` argument (2: bearers' hot words in LDS when they fit, 3: in HBM) */
+#ifndef RS_JIT_CARVEQ
+#define RS_JIT_CARVEQ 0 /* shape-specialised build: rs_carve's `queue` argument as the host passes it (0; 1: gate scratch of a drop-in PF / NVS
+                         * context; 2: queue model, bearers' hot words in LDS when they fit; 3: queue model, words in HBM) */
 #endif
 
 template <int SCHED, int EPT, bool FIXED, bool DIRECT, bool QUEUE = false>
@@ -148,7 +149,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * (bit 0: the prioritized bearer has data; queue model only, bit 1: the user has any queued data = is in UsersToSchedule) */
   /* The queue model's per-bearer words (RS_QSTATE_BYTES_PER_USER per user) stay in LDS for the whole launch when the carve has
    * room (q_lds; a compile-time fact in a shape-specialised build, so its pointers are plain LDS pointers), else in HBM. */
-  constexpr RsCarve kCvQ = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, QUEUE ? RS_JIT_QMODE : 0);
+  constexpr RsCarve kCvQ = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_CARVEQ);
   const bool q_lds = QUEUE && (FIXED ? kCvQ.q_lds != 0 : p.q_lds != 0);
   const int qU = FIXED ? RS_JIT_U : p.U;
   unsigned char* const qs = lds + (FIXED ? kCvQ.off_qstate : p.off_qstate);
@@ -169,13 +170,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   const int tid = threadIdx.x;
   const int nt = FIXED ? RS_JIT_NT : (int)blockDim.x;
   const int lane = lane_id(), wave = wave_id(), nwaves = nt >> 6;
-  const int S = FIXED ? RS_JIT_S : p.S, U = FIXED ? RS_JIT_U : p.U, R = FIXED ? RS_JIT_R : p.R, G = FIXED ? RS_JIT_G : p.G;
-  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, QUEUE ? RS_JIT_QMODE : 0);
+  /* (a shape-specialised drop-in kernel: RS_JIT_U is the context's user capacity -- it fixes the LDS carve -- while the users of one
+   * call, their grid stride and, per-flow PF, their segments are launch arguments) */
+  const int S = FIXED ? RS_JIT_S : p.S, U = (FIXED && !DIRECT) ? RS_JIT_U : p.U, R = FIXED ? RS_JIT_R : p.R, G = FIXED ? RS_JIT_G : p.G;
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_CARVEQ);
   /* byte offsets of the LDS arrays: constants in a shape-specialised build */
   struct Offs { int avgk, rcp, tab, slice, tx, misc, tbs, elems, sorted, items, sortx, cqi, queue, Upad, n_seg, n_items; };
   const Offs o = FIXED ? Offs{kCv.off_avgk, kCv.off_rcp, kCv.off_tab, kCv.off_slice, kCv.off_tx, kCv.off_misc, kCv.off_tbs,
-                              kCv.off_elems, kCv.off_sorted, kCv.off_items, kCv.off_sortx, kCv.off_cqi, kCv.off_queue, kCv.Upad,
-                              kCv.n_seg, kCv.n_items}
+                              kCv.off_elems, kCv.off_sorted, kCv.off_items, kCv.off_sortx, kCv.off_cqi, kCv.off_queue,
+                              DIRECT ? p.Upad : kCv.Upad, DIRECT ? p.n_seg : kCv.n_seg, DIRECT ? p.n_items : kCv.n_items}
                        : Offs{p.off_avgk, p.off_rcp, p.off_tab, p.off_slice, p.off_tx, p.off_misc, p.off_tbs, p.off_elems,
                               p.off_sorted, p.off_items, p.off_sortx, p.off_cqi, p.off_queue, p.Upad, p.n_seg, p.n_items};
   constexpr bool kTransport = (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103 || SCHED == 10);
@@ -249,7 +252,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #ifdef RS_NO_EARLY17
   constexpr bool kEarly17 = false;
 #else
-  constexpr bool kEarly17 = FIXED && !DIRECT && !QUEUE && (SCHED == 1 || SCHED == 7);
+  /* (the per-flow PF scheduler gains only the EWMA: one multiply-add per user, worth moving once a thread owns several users --
+   * same-box A/B, 512 cells: 1 000 UEs 96.0 against 91.5 M TTIs/s, 500 UEs 160.0 against 163.6; NVS: 184.5 against 149.8 M at
+   * 500 UEs x 25 RBGs, 161.6 against 125.4 at 1 000 UEs, 167.1 against 125.7 at 64 RBGs; profiles/r04_sched17.md) */
+  constexpr bool kEarly17 = FIXED && !DIRECT && !QUEUE && (SCHED == 7 || (SCHED == 1 && RS_JIT_U > RS_JIT_NT));
 #endif
 
   double* s_avg = (double*)lds;
@@ -2703,8 +2709,8 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
   rs_cell_body<SCHED, EPT, false, DIRECT, QUEUE>(p, lds);
 }
 #else
-#ifndef RS_JIT_QUEUE
-#define RS_JIT_QUEUE 0
+#ifndef RS_JIT_DIRECT
+#define RS_JIT_DIRECT 0 /* 1: the drop-in entry point's one-TTI form (rs_ctx_specialize) */
 #endif
 /* shape-specialised entry point compiled at run time (rs_jit.cpp): static LDS of exactly the carve's size.  RS_JIT_WPE = waves
  * per SIMD the register allocation must leave room for (4: 128 VGPRs, two 512-thread cells per CU; rs_jit.cpp passes 5 for the
@@ -2713,10 +2719,10 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
 #define RS_JIT_WPE 4
 #endif
 extern "C" __global__ void __launch_bounds__(RS_JIT_NT, RS_JIT_WPE) rs_cell_kernel_jit(RsLaunch p) {
-  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_QUEUE != 0 ? RS_JIT_QMODE : 0);
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_CARVEQ);
   __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
   constexpr int kEpt = (RS_JIT_SCHED != 9 && RS_JIT_SCHED != 10) ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);
-  rs_cell_body<RS_JIT_SCHED, kEpt, true, false, RS_JIT_QUEUE != 0>(p, lds);
+  rs_cell_body<RS_JIT_SCHED, kEpt, true, RS_JIT_DIRECT != 0, (RS_JIT_CARVEQ >= 2)>(p, lds);
 }
 #endif
 

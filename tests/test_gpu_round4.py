@@ -74,7 +74,7 @@ def test_jit_builds_without_the_llvm_tuning_options_and_for_640_threads(rs):
     assert rs.jit_selfcheck(20, 500, 25, 4, 512, rs.RS_SCHED_MAXCELL, untuned=True) > 0
     assert rs.jit_selfcheck(20, 500, 64, 8, 640, rs.RS_SCHED_MAXCELL) > 0
     src = (ROOT / "radiosaber_amd" / "csrc" / "rs_jit.cpp").read_text()
-    assert "rs_jit_compile(S, U, R, G, NT, sched, log2, qmode, win, false)" in src  # the retry in rs_jit_get
+    assert "rs_jit_compile(S, U, R, G, NT, sched, log2, qmode, win, false, direct != 0)" in src  # the retry in rs_jit_get
     assert rs.lds_bytes_per_cell(20, 500, 64, rs.RS_SCHED_MAXCELL, 640) <= 80 * 1024  # two cells per CU
 
 
@@ -232,6 +232,123 @@ def test_held_winners_age_cap_ends_the_holds(rs, oracle, sched):
     for c in range(n_cells):
         _assert_state_equal(st, c, ref[c], f"sched {sched}")
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched", [7, 1])
+@pytest.mark.parametrize("ues,weights,R,G,refresh,phy,threads", [
+    ([25] * 20, None, 25, 4, 40, 0, 0),            # the sweep's shape: a new slice every TTI, winners found a TTI ahead
+    ([50] * 20, None, 25, 4, 40, 1, 0),            # configs[2]: slices scanned in runs; the error model's draws on the stream
+    ([5] * 20, None, 64, 8, 7, 0, 256),            # the shipped grid, a refresh every 7 TTIs (no early scan into a refresh)
+    ([12, 30, 9], [0.7, 0.2, 0.1], 25, 4, 40, 0, 128),  # skewed NVS weights: the same slice twice in a row (scan at the top)
+    ([40], None, 25, 4, 40, 0, 0),                 # one slice: never a different slice
+    ([6, 0, 11, 3], None, 12, 2, 3, 1, 64),        # an empty slice, one wave per cell (nothing can be prepared)
+])
+def test_schedulers_1_and_7_prepare_the_next_tti(rs, oracle, sched, ues, weights, R, G, refresh, phy, threads):
+    """Round 4: shape-specialised kernels of schedulers 1 and 7 decay every average, pick the next NVS slice and (NVS, when the
+    next slice differs and the grid stays) find the next TTI's winners during the serial end of the current TTI.  Exact by
+    construction; checked like everything else: decisions of the first launch and the final state after uneven launches."""
+    S = len(ues)
+    w = weights or [1.0 / S] * S
+    sc = rs.SliceConfig(ues, weight=w)
+    n_cells, n_ttis = 3, 130
+    grids = synth_cqi(500 + sched + R, (n_cells, (n_ttis + refresh - 1) // refresh, sc.n_users, R), HIST)
+    seeds = np.arange(n_cells, dtype=np.uint32) * 101 + 17
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=True, cqi_refresh=refresh, phy_error_draws=bool(phy), threads_per_cell=threads)
+    assert b.kernel_name == "rs_cell_kernel_jit"
+    b.seed(seeds)
+    b.upload_cqi_epochs(grids)
+    got = b.run_logged(47)
+    for n in (1, 2, 39, 41):
+        b.run(n)
+    st = b.state()
+    for c in range(n_cells):
+        cell = oracle.Cell(ues, R, G, sched, weights=w)
+        logs = cell.run_synth(grids[c], int(seeds[c]), n_ttis, refresh=refresh, phy_error_draws=phy)
+        np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"][:47], err_msg=f"cell {c} RBG map")
+        np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"][:47], err_msg=f"cell {c} TBS")
+        _assert_state_equal(st, c, cell.state(), f"sched {sched}")
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched", [7, 1])
+def test_schedulers_1_and_7_trace_replay_with_early_preparation(rs, oracle, traces, sched):
+    """The same on the trace source: the report rule ((int)(t * 1000) - lastSent >= 40) decides whether the next TTI reads a new row."""
+    ues, R, G, n_cells, n_ttis = [5] * 20, 64, 8, 2, 170
+    sc = rs.SliceConfig(ues)
+    U = sc.n_users
+    tr = traces["cqi"]
+    seeds = np.array([749913912, 805290992], np.uint32)
+    skips = np.array([5000, 321], np.int64)
+    maps = [traces["mapping"][1], traces["mapping"][2]]
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=True, phy_error_draws=True)
+    b.seed(seeds, skips)
+    b.set_trace(tr, np.stack([m[np.arange(U) % 474] for m in maps]).astype(np.int32))
+    for n in (60, 1, 109):
+        b.run(n)
+    st = b.state()
+    for c in range(n_cells):
+        cell = oracle.Cell(ues, R, G, sched)
+        cell.run_trace(tr, maps[c], int(seeds[c]), int(skips[c]), n_ttis, log=False)
+        _assert_state_equal(st, c, cell.state(), f"sched {sched} trace")
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched", [9, 8, 1, 7, 10, 101, 103, 11])
+def test_specialised_drop_in_kernel_matches_the_built_in_one(rs, oracle, sched):
+    """rs_ctx_specialize: a context's own hiprtc build of the one-TTI kernel (slices, RBGs, scheduler, user CAPACITY fixed; the
+    users of a call a launch argument).  The same calls through a specialised and a plain context (the plain one is what every
+    other drop-in test pins against the oracle): every output array and slice_rbs_offset_ identical -- full and partial user
+    lists, customised slices with head-of-line delays, per-PRB reports, the gates of schedulers 1 and 7, exact ties."""
+    rng = np.random.default_rng(1000 + sched)
+    shapes = [([25] * 20, 25, 4), ([5] * 20, 64, 8), ([7, 0, 12, 3], 12, 2)]
+    if sched == 10:
+        shapes = [([5] * 20, 25, 4), ([7, 0, 12, 3], 12, 2)]
+    for ues, R, G in shapes:
+        S = len(ues)
+        custom = sched in (9, 8, 7)
+        alpha = [int(x) for x in rng.integers(0, 2, S)] if custom else [0] * S
+        beta = [int(x) for x in rng.integers(0, 2, S)] if custom else [0] * S
+        sc = rs.SliceConfig(ues, algo_alpha=alpha, algo_beta=beta)
+        U = sc.n_users
+        u2s = np.asarray(sc.user_to_slice)
+        a = rs.TtiScheduler(sc, R, G, sched=sched, jit=True)
+        b = rs.TtiScheduler(sc, R, G, sched=sched)
+        for it in range(8):
+            if sched in (7, 11):  # NVS: the users of the served slice only
+                sl = int(rng.choice([s for s in range(S) if ues[s] > 0]))
+                ids = np.flatnonzero(u2s == sl)
+            else:
+                ids = np.arange(U) if it % 2 == 0 else np.sort(rng.choice(U, max(1, U // 2), replace=False))
+            n = len(ids)
+            cqi = synth_cqi(7000 + 31 * it + sched, (n, R), HIST)
+            avg = rng.choice([1.0, 98000.0, 5e5], n) if it == 3 else rng.uniform(1.0, 1e6, n)
+            kw = dict(user_id=ids.astype(np.int32), rand0=int(rng.integers(0, 2**31 - 1)), rand1=int(rng.integers(0, 2**31 - 1)))
+            if custom and any(alpha):
+                kw["hol_delay"] = rng.uniform(1e-5, 0.3, n)
+                kw["prio_has_data"] = (rng.random(n) < 0.8).astype(np.uint8)
+            if sched == 11:
+                kw["rand_draws"] = rng.integers(0, 2**31 - 1, 300 * n).astype(np.int32)
+            if it == 5 and sched == 7:
+                kw["required_rbs"] = rng.integers(0, 3 * G, n).astype(np.int32)
+            if it == 5 and sched == 1:
+                kw["data_to_transmit"] = rng.integers(0, 4000, n).astype(np.int32)
+            if it == 6:
+                prb = np.repeat(cqi, G, axis=1)
+                prb[:, 1::G] = np.maximum(1, prb[:, 1::G] - 1)
+                ra, rb = a.schedule_tti(None, avg, cqi_prb=prb, **kw), b.schedule_tti(None, avg, cqi_prb=prb, **kw)
+            else:
+                ra, rb = a.schedule_tti(cqi, avg, **kw), b.schedule_tti(cqi, avg, **kw)
+            for f in ("target_rbs", "quota_rbgs", "rbg_to_user", "user_nprb", "user_final_cqi", "user_mcs", "user_tbs_bits"):
+                np.testing.assert_array_equal(getattr(ra, f), getattr(rb, f), err_msg=f"sched {sched} call {it}: {f}")
+            if sched == 10:
+                np.testing.assert_array_equal(ra.upper_rbg, rb.upper_rbg)
+                np.testing.assert_array_equal(ra.upper_user, rb.upper_user)
+            assert a.slice_offset.tobytes() == b.slice_offset.tobytes()
+        a.close()
+        b.close()
 
 
 @pytest.mark.gpu

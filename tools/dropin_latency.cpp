@@ -9,7 +9,7 @@
 
 #include "radiosaber_hip.h"
 
-static double run(int ues_per_slice, int R, int G, int sched, int calls) {
+static double run(int ues_per_slice, int R, int G, int sched, int calls, bool specialise) {
   const int S = 20, U = S * ues_per_slice;
   std::vector<double> w(S, 0.05);
   std::vector<int32_t> zero(S, 0), one(S, 1), u2s(U);
@@ -29,6 +29,7 @@ static double run(int ues_per_slice, int R, int G, int sched, int calls) {
   cfg.user_to_slice = u2s.data();
   rs_ctx* c = RS_CREATE(&cfg);
   if (!c) { fprintf(stderr, "rs_create: %s\n", rs_last_error()); exit(1); }
+  if (specialise && rs_ctx_specialize(c) != RS_OK) { fprintf(stderr, "rs_ctx_specialize: %s\n", rs_last_error()); exit(1); }
   std::mt19937 g(1);
   std::vector<uint8_t> cqi((size_t)U * R);
   std::vector<double> avg(U);
@@ -36,7 +37,7 @@ static double run(int ues_per_slice, int R, int G, int sched, int calls) {
   for (auto& x : avg) x = 1e4 + g() % 1000000;
   std::vector<int32_t> map(R), tbs(U), nprb(U), fcqi(U), mcs(U), tgt(S), quo(S);
   rs_tti_in in{};
-  in.n_users = U;
+  in.n_users = sched == RS_SCHED_NVS ? ues_per_slice : U; /* NVS: the caller passes the served slice's users (here slice 0) */
   in.cqi = cqi.data();
   in.avg_rate = avg.data();
   rs_tti_out out{};
@@ -59,16 +60,20 @@ static double run(int ues_per_slice, int R, int G, int sched, int calls) {
   }
   const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / calls;
   rs_destroy(c);
-  printf("sched %d, %d UEs x %d RBGs: %.1f us per rs_schedule_tti (checksum %lld)\n", sched, U, R, us, sum);
+  printf("sched %d, %d UEs x %d RBGs, %s kernel: %.1f us per rs_schedule_tti (checksum %lld)\n", sched, U, R,
+         specialise ? "shape-specialised" : "built-in", us, sum);
   return us;
 }
 
 int main(int argc, char** argv) {
   const int calls = argc > 1 ? atoi(argv[1]) : 2000;
-  run(5, 64, 8, RS_SCHED_MAXCELL, calls);
-  run(25, 25, 4, RS_SCHED_MAXCELL, calls);
-  run(25, 64, 8, RS_SCHED_MAXCELL, calls);
-  run(25, 25, 4, RS_SCHED_SEQUENTIAL, calls);
-  run(25, 25, 4, RS_SCHED_PF, calls);
+  for (int sp = 0; sp < 2; ++sp) { /* built-in kernels, then the context's own build (rs_ctx_specialize) */
+    run(5, 64, 8, RS_SCHED_MAXCELL, calls, sp != 0);
+    run(25, 25, 4, RS_SCHED_MAXCELL, calls, sp != 0);
+    run(25, 64, 8, RS_SCHED_MAXCELL, calls, sp != 0);
+    run(25, 25, 4, RS_SCHED_SEQUENTIAL, calls, sp != 0);
+    run(25, 25, 4, RS_SCHED_PF, calls, sp != 0);
+    run(25, 25, 4, RS_SCHED_NVS, calls, sp != 0);
+  }
   return 0;
 }

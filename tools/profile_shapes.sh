@@ -15,11 +15,12 @@ shape() { # tag, bench args...
       insts) pmc="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY";;
     esac
     rm -rf $R/gpurun_out/ps_${tag}_$pass
-    rocprofv3 --pmc $pmc --output-format csv -d $R/gpurun_out/ps_${tag}_$pass -- python3 $R/bench.py --no-cpu-baseline --no-r64 --steps 3 --warmup 1 --ttis 2000 "$@" > $R/gpurun_out/ps_${tag}_$pass.log 2>&1
+    rocprofv3 --pmc $pmc --output-format csv -d $R/gpurun_out/ps_${tag}_$pass -- python3 $R/bench.py --no-cpu-baseline --no-r64 --no-streamed --steps 3 --warmup 1 --ttis 2000 "$@" > $R/gpurun_out/ps_${tag}_$pass.log 2>&1
   done
   grep '^{' $R/gpurun_out/ps_${tag}_insts.log | tail -1 | cut -c1-140
 }
 shape s9_r25
+shape s9_r25_refresh1 --cqi-refresh 1   # streamed-CQI mode: a grid from HBM every TTI (roofline.streamed)
 shape s9_r64 --rbgs 64 --rbg-size 8
 shape s9_u1000 --ues-per-slice 50
 shape s8_r25 --sched 8

@@ -25,6 +25,8 @@ out = ROOT / "profiles"
 bench_line = json.loads([ln for ln in (ROOT / "gpurun_out" / "prof_kt.log").read_text().splitlines() if ln.startswith("{")][-1])
 cfg = bench_line["config"]
 key = f"sched{cfg['sched']}_S{cfg['slices']}_U{cfg['ues']}_R{cfg['rbgs']}_cells{cfg['cells_per_gpu']}"
+if cfg.get("cqi_refresh", 40) != 40:
+    key += f"_refresh{cfg['cqi_refresh']}"
 cell_ttis = cfg["cells_per_gpu"] * cfg["ttis_per_step"]
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 

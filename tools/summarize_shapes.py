@@ -17,6 +17,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 G = ROOT / "gpurun_out"
+ROUND = next((a for a in sys.argv[1:] if a.startswith("r") and a[1:].isdigit()), "r04")
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 tags = sorted({Path(p).name[3:-len("_insts.log")] for p in glob.glob(str(G / "ps_*_insts.log"))})
 tf, inf = ROOT / "profiles" / "traffic.json", ROOT / "profiles" / "inst_counts.json"
@@ -41,6 +42,8 @@ for tag in tags:
     d = line(tag, "insts")
     cfg = d["config"]
     key = f"sched{cfg['sched']}_S{cfg['slices']}_U{cfg['ues']}_R{cfg['rbgs']}_cells{cfg['cells_per_gpu']}"
+    if cfg.get("cqi_refresh", 40) != 40:
+        key += f"_refresh{cfg['cqi_refresh']}"  # bench.py's key for a batch that is not on the reference's 40-TTI report interval
     n = cfg["cells_per_gpu"] * cfg["ttis_per_step"]
     fetch, write, ic = counters(tag, "fetch")["FETCH_SIZE"], counters(tag, "write")["WRITE_SIZE"], counters(tag, "insts")
     fb, wb = statistics.mean(fetch) * 1024 * 2, statistics.mean(write) * 1024
@@ -49,7 +52,7 @@ for tag in tags:
     traffic[key] = {"kernel": d["kernel"], "launches_profiled": len(fetch), "FETCH_SIZE_KiB_mean": statistics.mean(fetch),
                     "WRITE_SIZE_KiB_mean": statistics.mean(write), "hbm_read_bytes_per_launch": fb, "hbm_write_bytes_per_launch": wb,
                     "hbm_bytes_per_launch": fb + wb, "ttis_per_launch": cfg["ttis_per_step"], "hbm_bytes_per_cell_tti": (fb + wb) / n,
-                    "ttis_per_s_under_pmc": line(tag, "fetch")["value"], "commit": commit, "round": "r03", "tag": tag,
+                    "ttis_per_s_under_pmc": line(tag, "fetch")["value"], "commit": commit, "round": ROUND, "tag": tag,
                     "source_hash": d.get("source_hash"),
                     "note": "FETCH_SIZE doubled per the gfx950 correction; separate --pmc passes (tools/profile_shapes.sh)"}
     per = {k: sum(v) / len(v) / n for k, v in ic.items()}
