@@ -45,9 +45,6 @@ struct RsMisc {
   int32_t seg_begin[68];
   int32_t target[64];
   int32_t quota[64];
-#ifdef RS_SERIAL_SORT
-  int32_t stack[96];             /* serial introsort emulation (debug build only) */
-#endif
   int32_t n_level[48];           /* level-synchronous introsort: live sub-ranges per recursion level */
   uint16_t hist[64 * 16];        /* counting sort: per 64-element chunk, per key */
   int32_t mcs_of_cqi[16];

@@ -15,9 +15,7 @@
 
 namespace {
 
-#ifndef RS_GBR_GROUP
 #define RS_GBR_GROUP 2 /* RBGs decided per step of GreedyByRow */
-#endif
 
 template <int S_T, int R_T>
 __device__ __forceinline__ int interslice_greedy_by_row(const uint32_t* s_elems, const RsMisc* m, int S_rt, int R_rt, int& got) {
@@ -65,7 +63,7 @@ __device__ __forceinline__ int interslice_greedy_by_row(const uint32_t* s_elems,
   return my_slice;
 }
 
-/* s_sorted: the R*S records in std::sort's order.  One record per step (the default; the vector form below is -DRS_GREEDY_VECTOR) */
+/* s_sorted: the R*S records in std::sort's order.  One record per step: the form used above 32 RBGs (the vector form below up to 32) */
 template <int S_T, int R_T>
 __device__ __forceinline__ int interslice_maximize_cell(const uint32_t* s_sorted, const RsMisc* m, int S_rt, int R_rt, int& got
 #ifdef RS_STAMPS
@@ -261,104 +259,49 @@ __device__ __forceinline__ int interslice_maximize_cell_vector(uint32_t* s_sorte
 }
 
 /*
- * The same scan called by EVERY wave of the workgroup (when the other waves have nothing else to do in the serial phase, i.e. no
- * speculation): wave 0 decides the vectors, the compaction between two vectors is shared -- every wave tests its chunks of the
- * rest of the stream (pass 1: one ballot per chunk to LDS), then writes the live records of its chunks behind those of the
- * chunks before (pass 2: a prefix over the chunk counts) into the OTHER buffer, so nobody overwrites what somebody still reads.
- * Three workgroup barriers per round (state published / masks complete / records written); wave 0's share of a round drops from
- * ~170 to ~40 instructions.  Scratch: m->hist (state words by round parity, chunk masks).  Results in wave 0 only.
+ * VogelApproximate's two searches, without walking the row / the column.  One search is the reference's sequential scan
+ *     for every allowed element in index order:  if (best < 0 || key > best) { best = key; arg = index; }
+ *                                                else if (second < 0 || key > second) second = key;
+ * (`second` is the largest key that was NOT a new best when it was met -- a new best does not demote the old one).  An element is
+ * a new best exactly when no allowed element before it has a key at or above its own, i.e. when it is the first element of the set
+ * {key >= its key}.  With the keys of the row (column) held as four bit planes over the element index -- keys are CQIs, 0..15 --
+ * the elements of key v are one AND of four masks, and walking v = 15 .. 0 with `seen` = elements of a key >= v so far gives
+ *     best   = the first v that has an element,   arg = its lowest index,
+ *     second = the first v that has an element other than the lowest bit of `seen`   (that one is the new best among them),
+ * usually within two or three values of v (a row holds 20 keys, a column up to 64, of ~9 distinct values): ~15 instructions per
+ * value instead of ~6 per element, and no LDS traffic in the rounds.  tests/test_vogel_buckets.py checks the identity against the
+ * sequential scan on random rows; the device is checked against the CPU restatement of this policy, which is pinned to the reference's own
+ * unit code.
  */
-template <int S_T, int R_T, bool K32>
-__device__ __forceinline__ int interslice_maximize_cell_vector_wg(uint32_t* buf_a, uint32_t* buf_b, RsMisc* m, int S_rt, int R_rt, int& got
-#ifdef RS_STAMPS
-                                                           , unsigned long long* stamp_acc
-#endif
-) {
-  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
-  const int S = S_T ? S_T : S_rt, R = R_T ? R_T : R_rt;
-  const int N = R * S;
-  typedef typename RsMaskT<K32>::type set_t;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  int32_t* const st = (int32_t*)m->hist;                                /* [parity][8]: free_rbg, open slices, RBGs granted so far */
-  unsigned long long* const lmask = (unsigned long long*)(st + 16);     /* [32] live lanes of a chunk */
-  set_t free_rbg = R >= (int)(8 * sizeof(set_t)) ? ~(set_t)0 : (set_t)(((set_t)1 << R) - 1);
-  int left = lane < S ? m->quota[lane] : 0;
-  int n_taken = 0;
-#ifdef RS_STAMPS
-  int n_vec = 0;
-#endif
-  if (wave == 0) {
-    m->maskA[lane] = 0ull;
-    m->maskB[lane] = 0ull;
-    ((unsigned char*)m->n_level)[lane] = 0xFF;
-  }
-  uint32_t* src = buf_a;
-  uint32_t* dst = buf_b;
-  int n = N, pos = 0;
-  for (int round = 0;; ++round) {
-    int32_t* const stp = st + 8 * (round & 1);
-    if (wave == 0) {
-      rs_scan_decide_vector<set_t>(src, pos, n, m, free_rbg, left, n_taken);
-#ifdef RS_STAMPS
-      ++n_vec;
-#endif
-      const unsigned long long open = __ballot(left > 0);
-      if (lane == 0) {
-        stp[0] = (int32_t)(uint32_t)free_rbg;
-        stp[1] = (int32_t)(uint32_t)((unsigned long long)free_rbg >> 32);
-        stp[2] = (int32_t)(uint32_t)open;
-        stp[3] = (int32_t)(uint32_t)(open >> 32);
-        stp[4] = n_taken;
+template <class M>
+struct RsKeyPlanes {
+  M p[4]; /* bit b of element i's key at bit i of p[b] */
+  M all;  /* the elements that exist */
+};
+
+template <class M>
+__device__ __forceinline__ void vogel_best_second(const RsKeyPlanes<M>& pl, M allowed, bool part, int& best, int& second, int& arg) {
+  best = second = arg = -1;
+  const M cand = pl.all & allowed;
+  M seen = 0;
+  bool done = !part || cand == 0;
+#pragma unroll
+  for (int v = 15; v >= 0; --v) {
+    if (__ballot(!done) == 0ull) break; /* wave-uniform */
+    M A = cand;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) A &= ((v >> b) & 1) ? pl.p[b] : (M)~pl.p[b];
+    seen |= A;
+    const M first = seen & (M)((M)0 - seen); /* the first element of {key >= v}: the only possible new best of this value */
+    if (!done) {
+      if (A != 0 && best < 0) {
+        best = v;
+        arg = (sizeof(M) == 8 ? __ffsll((long long)A) : __ffs((int)A)) - 1;
       }
-    }
-    __syncthreads();
-    const int taken = stp[4];
-    pos += 64;
-    if (taken >= R || pos >= n) break;
-    if (n - pos > 64) {
-      const set_t fr = (set_t)((unsigned long long)(uint32_t)stp[0] | ((unsigned long long)(uint32_t)stp[1] << 32));
-      const set_t op = (set_t)((unsigned long long)(uint32_t)stp[2] | ((unsigned long long)(uint32_t)stp[3] << 32));
-      const int c_tot = (n - pos + 63) >> 6; /* at most 32 chunks (2 048 records) */
-      for (int c = wave; c < c_tot; c += nwaves) {
-        const int x = pos + (c << 6) + lane;
-        const uint32_t e = src[x < n ? x : 0];
-        const int rbg = (e >> 8) & 63, sl = e & 63;
-        const unsigned long long mk = __ballot((x < n) & (((fr >> rbg) & (op >> sl) & 1) != 0));
-        if (lane == 0) lmask[c] = mk;
-      }
-      __syncthreads();
-      const int cnt = lane < c_tot ? __popcll(lmask[lane]) : 0;
-      const int incl = wave_scan_incl(cnt);
-      const int kept = __builtin_amdgcn_readlane(incl, 63);
-      const int pre = incl - cnt;
-      for (int c = wave; c < c_tot; c += nwaves) {
-        const int cu = __builtin_amdgcn_readfirstlane(c);
-        const int x = pos + (cu << 6) + lane;
-        const uint32_t e = src[x < n ? x : 0];
-        const unsigned long long mk = lmask[cu];
-        const int base = __builtin_amdgcn_readlane(pre, cu);
-        if ((mk >> lane) & 1ull) dst[base + __popcll(mk & lt)] = e;
-      }
-      __syncthreads();
-      uint32_t* t = src;
-      src = dst;
-      dst = t;
-      n = kept;
-      pos = 0;
+      if ((A & ~first) != 0 && second < 0) second = v;
+      done = (best >= 0 && second >= 0) || seen == cand;
     }
   }
-  if (wave != 0) return -1;
-#ifdef RS_STAMPS
-  if (threadIdx.x == 0) {
-    stamp_acc[9] += (unsigned long long)n_taken;
-    stamp_acc[10] += (unsigned long long)n_vec;
-  }
-#endif
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (lane < S) got = m->quota[lane] - left;
-  const int o = ((unsigned char*)m->n_level)[lane];
-  return (lane < R && o != 0xFF) ? o : -1;
 }
 
 template <int S_T, int R_T>
@@ -375,78 +318,46 @@ __device__ __forceinline__ int interslice_vogel(const uint32_t* s_elems, const R
    * increasing in the CQI key (0 = no user), so keys are compared and only the differences use the doubles. */
   const int quota = lane < S ? m->quota[lane] : 0;
   int my_slice = -1; /* lane r: slice that got RBG r */
-  /* the records do not change during the rounds: a shape-specialised build reads its row (lane = RBG) and its column
-   * (lane = slice) once, the keys stay in registers */
-  constexpr bool kRowRegs = S_T != 0 && S_T <= 32, kColRegs = R_T != 0 && R_T <= 32;
-  int rowk[kRowRegs ? S_T : 1], colk[kColRegs ? R_T : 1];
-  if constexpr (kRowRegs) {
-    const uint32_t* row = s_elems + (lane < R ? lane : 0) * S;
+  /* the records do not change during the rounds: every RBG lane turns its row, every slice lane its column into bit planes once
+   * per TTI (the columns through ballots over the RBG lanes: no second pass over the records) */
+  typedef typename RsMaskT<(S_T != 0 && S_T <= 32)>::type rmask_t; /* over slices */
+  typedef typename RsMaskT<(R_T != 0 && R_T <= 32)>::type cmask_t; /* over RBGs */
+  RsKeyPlanes<rmask_t> row;
+  RsKeyPlanes<cmask_t> col;
 #pragma unroll
-    for (int k = 0; k < S_T; ++k) rowk[k] = (int)(row[k] >> 16);
-  }
-  if constexpr (kColRegs) {
-    const uint32_t* col = s_elems + (lane < S ? lane : 0);
+  for (int b = 0; b < 4; ++b) { row.p[b] = 0; col.p[b] = 0; }
+  row.all = S >= (int)(8 * sizeof(rmask_t)) ? (rmask_t)~(rmask_t)0 : (rmask_t)(((rmask_t)1 << S) - 1);
+  col.all = R >= (int)(8 * sizeof(cmask_t)) ? (cmask_t)~(cmask_t)0 : (cmask_t)(((cmask_t)1 << R) - 1);
+  {
+    const uint32_t* rowp = s_elems + (lane < R ? lane : 0) * S;
+    for (int k0 = 0; k0 < S; k0 += 4) {
+      uint32_t e4[4];
 #pragma unroll
-    for (int j = 0; j < R_T; ++j) colk[j] = (int)(col[j * S] >> 16);
+      for (int q = 0; q < 4; ++q) e4[q] = rowp[k0 + q < S ? k0 + q : S - 1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + q;
+        if (k < S) { /* wave-uniform */
+          const int key = lane < R ? (int)(e4[q] >> 16) : 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const bool bit = ((key >> b) & 1) != 0;
+            if (bit) row.p[b] |= (rmask_t)1 << k;
+            const unsigned long long mk = __ballot(bit);
+            if (lane == k) col.p[b] = (cmask_t)mk;
+          }
+        }
+      }
+    }
   }
   for (int round = 0; round < R; ++round) {
     const unsigned long long elig = __ballot(lane < S && got < quota);
     const unsigned long long freeb = __ballot(lane < R && my_slice < 0);
-    /* horizontal search: lane j = free RBG j, slices ascending (four LDS reads in flight per step) */
-    int h1 = -1, h2 = -1, hs = -1;
-    if constexpr (kRowRegs) {
-#pragma unroll
-      for (int k = 0; k < S_T; ++k)
-        if ((elig >> k) & 1ull) {
-          const int key = rowk[k];
-          if (h1 < 0 || key > h1) { hs = k; h1 = key; }
-          else if (h2 < 0 || key > h2) h2 = key;
-        }
-    } else {
-      const uint32_t* row = s_elems + (lane < R ? lane : 0) * S;
-      for (int k0 = 0; k0 < S; k0 += 4) {
-        uint32_t e4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) e4[q] = row[k0 + q < S ? k0 + q : S - 1];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int k = k0 + q;
-          if (k < S && ((elig >> k) & 1ull)) {
-            const int key = (int)(e4[q] >> 16);
-            if (h1 < 0 || key > h1) { hs = k; h1 = key; }
-            else if (h2 < 0 || key > h2) h2 = key;
-          }
-        }
-      }
-    }
-    /* vertical search: lane k = slice k under quota, free RBGs ascending */
-    int v1 = -1, v2 = -1, vr = -1;
-    if constexpr (kColRegs) {
-#pragma unroll
-      for (int j = 0; j < R_T; ++j)
-        if ((freeb >> j) & 1ull) {
-          const int key = colk[j];
-          if (v1 < 0 || key > v1) { vr = j; v1 = key; }
-          else if (v2 < 0 || key > v2) v2 = key;
-        }
-    } else {
-      const uint32_t* col = s_elems + (lane < S ? lane : 0);
-      for (int j0 = 0; j0 < R; j0 += 4) {
-        uint32_t e4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) e4[q] = col[(j0 + q < R ? j0 + q : R - 1) * S];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = j0 + q;
-          if (j < R && ((freeb >> j) & 1ull)) {
-            const int key = (int)(e4[q] >> 16);
-            if (v1 < 0 || key > v1) { vr = j; v1 = key; }
-            else if (v2 < 0 || key > v2) v2 = key;
-          }
-        }
-      }
-    }
     const bool hpart = (freeb >> lane) & 1ull, vpart = (elig >> lane) & 1ull;
+    /* horizontal search: lane j = free RBG j over the slices under quota; vertical: lane k = such a slice over the free RBGs */
+    int h1, h2, hs, v1, v2, vr;
+    vogel_best_second<rmask_t>(row, (rmask_t)elig, hpart, h1, h2, hs);
+    vogel_best_second<cmask_t>(col, (cmask_t)freeb, vpart, v1, v2, vr);
     const double hd = (h1 < 0 ? -1.0 : m->eff16[h1]) - (h2 < 0 ? -1.0 : m->eff16[h2]);
     const double vd = (v1 < 0 ? -1.0 : m->eff16[v1]) - (v2 < 0 ? -1.0 : m->eff16[v2]);
     /* running truncated maximum before each candidate (-1 at the start), candidates in the reference's order */

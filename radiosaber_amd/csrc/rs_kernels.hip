@@ -55,25 +55,15 @@ template <int N> struct RsInt { static constexpr int v = N; };
  * and y approximates 1 / b with a relative error below 2^-53, then r = fma(-b, q, a) is exact and fma(r, y, q) = RN(a / b).
  * Here y = 0.001 as a double (relative error 2.08e-17 = 2^-55.4), so q = RN(x * y) lies within 0.5 + 0.19 ulp of x / 1000, i.e.
  * it is one of its two neighbours.  No underflow: x >= 1.  tests/test_abi.py checks the identity in exact rational arithmetic
- * (random, near-midpoint and small-integer quotients); -DRS_DIV1000_HW restores the division. */
+ * (random, near-midpoint and small-integer quotients). */
 __device__ __forceinline__ double rs_div_1000(double x) {
-#ifdef RS_DIV1000_HW
-  return x / 1000.0;
-#else
   const double q = x * 0.001;
   const double r = __builtin_fma(-q, 1000.0, x);
   return __builtin_fma(r, 0.001, q);
-#endif
 }
-#ifndef RS_SPEC_NAP
-#define RS_SPEC_NAP 2 /* s_sleep argument (x 64 cycles) while the scanning waves wait for the allocation */
-#endif
-#ifndef RS_SERIAL_PRIO
+#define RS_SPEC_NAP 2    /* s_sleep argument (x 64 cycles) while the scanning waves wait for the allocation */
 #define RS_SERIAL_PRIO 3 /* issue priority of the wave that runs the serial end of the TTI (inter-slice policy, link adaptation) */
-#endif
-#ifndef RS_SPEC_PRIO
-#define RS_SPEC_PRIO 0 /* issue priority of the scanning waves during the serial phase */
-#endif
+#define RS_SPEC_PRIO 0   /* issue priority of the scanning waves during the serial phase */
 #ifndef RS_P3_BLOCK
 #define RS_P3_BLOCK 32 /* users ranked per stage-1 block (multiple of 8, <= 32) */
 #endif
@@ -196,21 +186,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * the vector form's atomics and compaction more than the serial loop's lane reads).  The vector form shortens the serial
    * phase to the point where the speculation no longer pays for its fix-up pass and its flags (31.1 M without, 30.8 M with the
    * averages alone prepared, 29.9 M with the scan): MaximizeCell speculates only where it keeps the serial scan.
-   * -DRS_GREEDY_SERIAL / -DRS_GREEDY_VECTOR force one form, -DRS_SPEC_WITH_VECTOR keeps the speculation beside the vector form. */
-#if defined(RS_GREEDY_SERIAL)
-  constexpr int kVecMaxR = 0;
-#elif defined(RS_GREEDY_VECTOR)
-  constexpr int kVecMaxR = 64;
-#else
+   * (64 RBGs again in round 4, vector form with nothing speculated: 12.3 against 13.5 M -- profiles/r04_r64.md.) */
   constexpr int kVecMaxR = 32;
-#endif
-  constexpr bool kVecScan = SCHED == 9 && kVecMaxR > 0 && (!FIXED || RS_JIT_R <= kVecMaxR);
+  constexpr bool kVecScan = SCHED == 9 && (!FIXED || RS_JIT_R <= kVecMaxR);
   const bool vec_scan = kVecScan && R <= kVecMaxR;
-#ifdef RS_SPEC_WITH_VECTOR
-  constexpr bool kSpecBesideVec = true;
-#else
-  constexpr bool kSpecBesideVec = false;
-#endif
   /* Held winners (round 3): the winner of a (slice, RBG) item is NOT looked for again in a TTI in which it cannot
    * have changed -- the winner was not served in the previous TTI, the CQI grid is the same, and at the item's last scan its
    * stage-1 value led the slice by a margin that 40 TTIs of rounding and of the "+1" in (1 + avg) cannot use up.  Such TTIs scan
@@ -236,9 +215,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   constexpr bool kSpecSched = false;
 #else
   constexpr bool kSpecSched = !kHoldSched && !DIRECT && !QUEUE && (SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103) &&
-                              (!FIXED || RS_JIT_U <= 32 * RS_JIT_S) && (kSpecBesideVec || !(FIXED && kVecScan));
+                              (!FIXED || RS_JIT_U <= 32 * RS_JIT_S) && !(FIXED && kVecScan);
 #endif
-  const bool spec_enabled = kSpecSched && nwaves >= 2 && U <= 32 * S && (kSpecBesideVec || !vec_scan);
+  const bool spec_enabled = kSpecSched && nwaves >= 2 && U <= 32 * S && !vec_scan;
   /* Schedulers 1 and 7 (round 4): their TTI ends with wave 0 alone (per-RBG reduction, link adaptation: 25-40 % of the TTI) while
    * the other waves idle.  Those waves prepare TTI t+1 meanwhile -- exactly, nothing speculative:
    *   both   the EWMA of every user as (1 - beta) * avg (what the reference computes for a user that was not served: + beta * 0
@@ -291,6 +270,33 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   int cum_b[kKU], cum_r[kKU];
 #pragma unroll
   for (int k = 0; k < kKU; ++k) { cum_b[k] = 0; cum_r[k] = 0; }
+  /* A shape-specialised drop-in kernel (rs_ctx_specialize) reads its per-call inputs -- averages, slice ids, the CQI grid -- from
+   * the caller's pinned host block over PCIe.  The built-in kernel meets them one after the other (averages, slice ids twice
+   * behind barriers, the grid in rounds of one 16-byte word per thread); here every thread issues all of its reads at kernel
+   * entry and the phases below take them from registers.  Same-box A/B (us per rs_schedule_tti, tools/dropin_latency.cpp):
+   * MaximizeCell 500 UEs x 25 RBGs 41.0 against 43.0, 100 x 64 53.8 against 55.0 -- but 500 x 64 (four grid words per thread)
+   * 70.2 against 68.8, GreedyByRow 37.0 against 35.9, NVS 29.0 against 26.2: MaximizeCell with at most two grid words per thread. */
+  constexpr int kPU = (FIXED && DIRECT) ? (RS_JIT_U + RS_JIT_NT - 1) / RS_JIT_NT : 1;
+  constexpr int kPG = (FIXED && DIRECT) ? ((RS_JIT_U * RS_JIT_R + 15) / 16 + RS_JIT_NT - 1) / RS_JIT_NT : 1;
+  constexpr bool kPrefetch = FIXED && DIRECT && SCHED == 9 && kPG <= 2;
+  double pre_avg[kPU];
+  int pre_sl[kPU];
+  uint4 pre_grid[kPG];
+  if constexpr (kPrefetch) {
+    const uint4* src = (const uint4*)p.epochs;
+    const int n16 = (int)(p.grid_stride >> 4);
+#pragma unroll
+    for (int k = 0; k < kPU; ++k) {
+      const int u = tid + k * nt;
+      pre_avg[k] = u < U ? p.avg[u] : 0.0;
+      pre_sl[k] = u < U ? (int)p.user_slice[u] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < kPG; ++j) {
+      const int i = tid + j * nt;
+      pre_grid[j] = i < n16 ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
   /* ---------------- load the cell ---------------- */
 #pragma unroll
   for (int ku = 0; ku < (kCumRegs ? kKU : 1); ++ku) {
@@ -308,11 +314,19 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
   }
   for (int u = tid; u < U && !kCumRegs; u += nt) {
-    s_avg[u] = p.avg[(size_t)cell * U + u];
+    if (!kPrefetch) s_avg[u] = p.avg[(size_t)cell * U + u];
     s_tx[u] = p.tx_bytes[(size_t)cell * U + u];
     if (kDirect) { /* rs_schedule_tti: one row of per-user outputs, cleared here instead of by a memset */
       if (p.log_tbs) p.log_tbs[u] = 0;
       if (p.log_uinfo) p.log_uinfo[u] = 0;
+    }
+  }
+  int16_t* const s_uoff = (int16_t*)(s_rcp32 + Upad + 16 * S); /* per user: window position minus user index (until then: the prefetched slice id) */
+  if constexpr (kPrefetch) {
+#pragma unroll
+    for (int k = 0; k < kPU; ++k) {
+      const int u = tid + k * nt;
+      if (u < U) { s_avg[u] = pre_avg[k]; s_uoff[u] = (int16_t)pre_sl[k]; }
     }
   }
   /* TBS bits of n RBGs at a final CQI: the I_TBS step of CQI -> MCS -> I_TBS -> TBS folded in ([R+1][16]) */
@@ -346,15 +360,14 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   if (SCHED != 1) {
     /* user_slice is non-decreasing: slice s = [first u with slice >= s, ...) */
     for (int u = tid; u < U; u += nt) {
-      int s = p.user_slice[u];
-      int sp = u == 0 ? -1 : (int)p.user_slice[u - 1];
+      int s = kPrefetch ? (int)s_uoff[u] : (int)p.user_slice[u];
+      int sp = u == 0 ? -1 : (kPrefetch ? (int)s_uoff[u - 1] : (int)p.user_slice[u - 1]);
       for (int q = sp + 1; q <= s; q++) m->seg_begin[q] = u;
     }
   }
   /* The stage-1 reciprocals of a slice live in their own 8-aligned window of s_rcp32, zero before the slice's first user
    * and after its last: the metric scan reads whole groups of 8 and a slot outside the slice multiplies to 0 without a
    * range test.  (Sched 1 has no slices: natural order, zeros behind the last user.) */
-  int16_t* s_uoff = (int16_t*)(s_rcp32 + Upad + 16 * S); /* per user: window position minus user index */
   if (SCHED != 1) {
     __syncthreads();
     if (wave == 0) {
@@ -365,7 +378,15 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
     __syncthreads();
     /* window offsets are multiples of 8 (>= 0): bit 0 carries the slice's algo_psi, so that P1 needs no other per-user table */
-    for (int u = tid; u < U; u += nt) s_uoff[u] = (int16_t)(m->rcp_off[p.user_slice[u]] | (p.psi[p.user_slice[u]] ? 1 : 0));
+    if constexpr (kPrefetch) {
+#pragma unroll
+      for (int k = 0; k < kPU; ++k) {
+        const int u = tid + k * nt;
+        if (u < U) s_uoff[u] = (int16_t)(m->rcp_off[pre_sl[k]] | ((m->eps_psi[pre_sl[k]] & 2) ? 1 : 0));
+      }
+    } else {
+      for (int u = tid; u < U; u += nt) s_uoff[u] = (int16_t)(m->rcp_off[p.user_slice[u]] | (p.psi[p.user_slice[u]] ? 1 : 0));
+    }
   }
   double t = scal->t;
   double last_update = scal->last_update;
@@ -642,8 +663,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         const uint4* src = (const uint4*)(p.epochs + ((size_t)cell * p.n_epochs + (size_t)e) * p.grid_stride);
         const int n16 = (int)(p.grid_stride >> 4);
         const int total = U * R;
-        for (int i = tid; i < n16; i += nt) {
-          const uint4 w = src[i];
+        auto scatter16 = [&](int i, const uint4 w) { /* 16 grid bytes [u][r] -> the RBG-major LDS grid */
           const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
           int idx = i << 4;
           int u = idx / R, r = idx - u * R;
@@ -652,6 +672,13 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             if (idx < total) s_cqi[r * Upad + u] = (uint8_t)(ww[k >> 2] >> ((k & 3) * 8));
             if (++r == R) { r = 0; ++u; }
           }
+        };
+        if constexpr (kPrefetch) {
+#pragma unroll
+          for (int j = 0; j < kPG; ++j)
+            if (tid + j * nt < n16) scatter16(tid + j * nt, pre_grid[j]);
+        } else {
+          for (int i = tid; i < n16; i += nt) scatter16(i, src[i]);
         }
       }
     } else if (p.cqi_mode == RS_CQI_TRACE) {
@@ -709,18 +736,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     /* items the scanning waves take in the serial phase: whole rounds of nt - 64 lanes (at least one round) */
     auto spec_items = [&](int n) {
       const int nsp_ = nt > 64 ? nt - 64 : 64; /* (one-wave cells never speculate) */
-#if defined(RS_SPEC_EWMA_ONLY)
-      return 0; /* the serial phase prepares the averages and the quotas of TTI t+1 only; every item is scanned at the top */
-#elif defined(RS_SPEC_ALL)
-      return n;
-#else
       /* the serial phase lasts ~330 cycles per RBG, a round of scans ~4 000-5 000: with many RBGs every round fits (64 RBGs:
        * 13.06 instead of 12.92 M TTIs/s), with 25 a second, nearly empty round would outlast the serial wave */
       const int rounds_all = (n + nsp_ - 1) / nsp_;
       if (rounds_all * 16 <= R) return n;
       const int rounds = n / nsp_;
       return rounds == 0 ? n : rounds * nsp_;
-#endif
     };
     /* averageRate /= 1000.0 (ref: :685-689).  The three-instruction form needs an ordinary operand (no underflow, finite); the
      * drop-in entry point takes any double from its caller, and when one is out of range (p.exact_scan, set by the host) it
@@ -897,10 +918,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             float r32 = (uo & 1) ? __builtin_amdgcn_rcpf((float)k) : 1.0f;
             /* customised slice (ref: :694-711): metric 0 while the prioritized bearer is empty, times the
              * head-of-line delay when beta (sched 7: always) -- folded into the stage-1 factor */
-            const int sl = p.user_slice[u];
-            if (p.alpha[sl]) {
+            const int sl = kPrefetch ? pre_sl[ku < kPU ? ku : 0] : (int)p.user_slice[u];
+            if (m->eps_psi[sl] & 4) { /* algo_alpha */
               const bool has = prio_in ? (prio_in[u] & 1) != 0 : true;
-              const bool use_hol = SCHED == 7 || SCHED == 11 || p.beta[sl] != 0;
+              const bool use_hol = SCHED == 7 || SCHED == 11 || (m->eps_psi[sl] & 8) != 0; /* algo_beta */
               r32 = !has ? 0.0f : (use_hol ? r32 * (float)hol_in[u] : r32);
             }
             s_rcp32[u + (uo & ~7)] = r32;
@@ -912,6 +933,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       if constexpr (kCumRegs) {
 #pragma unroll
         for (int ku = 0; ku < kKU; ++ku)
+          if (tid + ku * nt < U) ewma_user(tid + ku * nt, ku);
+      } else if constexpr (kPrefetch) {
+#pragma unroll
+        for (int ku = 0; ku < kPU; ++ku)
           if (tid + ku * nt < U) ewma_user(tid + ku * nt, ku);
       } else {
         for (int u = tid, ku = 0; u < U; u += nt, ++ku) ewma_user(u, ku);
@@ -1508,10 +1533,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
            * co-resident cell is mostly in its one-wave serial phase, which runs at 3 anyway; MaximizeCell 32.8 against 33.7 -- there
            * the pass would take issue slots from the co-resident cell's sort levels (priority 1, a barrier every few dozen
            * instructions) */
-#ifndef RS_HOLD_PRIO
-#define RS_HOLD_PRIO (SCHED == 8 ? 1 : 0)
-#endif
-          if (RS_HOLD_PRIO) __builtin_amdgcn_s_setprio(RS_HOLD_PRIO);
+          constexpr int kHoldPrio = SCHED == 8 ? 1 : 0;
+          if (kHoldPrio) __builtin_amdgcn_s_setprio(kHoldPrio);
           for (int base = 0; base < n_list; base += 16) {
             const bool on = base + grp < n_list;
             const int it = on ? (int)wl[base + grp] : 0;
@@ -1619,7 +1642,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          if (RS_HOLD_PRIO) __builtin_amdgcn_s_setprio(0);
+          if (kHoldPrio) __builtin_amdgcn_s_setprio(0);
           RS_HSTAMP(1);
         }
         hold_age += 1;
@@ -1674,14 +1697,6 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     if (SCHED == 9) {
       const int N = R * S;
       /* std::sort emulation (:361): introsort loop, then the final insertion sort */
-#ifdef RS_SERIAL_SORT
-      if (tid == 0) {
-        LdsArr a{s_elems};
-        LdsInt st{m->stack};
-        rs_sort::introsort_loop(a, N, st);
-      }
-      __syncthreads();
-#else
       {
         uint16_t* sx = (uint16_t*)(lds + o.sortx);
         uint16_t* pa = (uint16_t*)s_sorted;
@@ -1707,7 +1722,6 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         if constexpr (EPT > 0) introsort_levels_reg<EPT>(s_elems, N, s_sorted, (int32_t*)sx, m, sort_sub);
         else introsort_loop_levels(s_elems, N, pa, pa + N, sx, sx + N, sx + 2 * N, sx + 3 * N, m);
       }
-#endif
       RS_STAMP(3);
       __builtin_amdgcn_s_setprio(2);
       if constexpr (EPT > 0) counting_sort_desc_owned<EPT>(s_elems, s_sorted, N, m);
@@ -1845,28 +1859,8 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
      * to scan again.  The top of the next TTI is then one pass over those lists.
      * Same-box A/B (512 cells, 25 RBGs): GreedyByRow 94.8 against 93.4 M TTIs/s (its TTI is short: the top of the TTI is a large
      * share), MaximizeCell 32.86 against 33.16 -- the waves that work beside wave 0 slow its greedy scan and link adaptation by
-     * what the shorter top saves, as round 2 found for its speculation -- so: GreedyByRow only (-DRS_HOLD_EARLY_ALL: every
-     * scheduler that holds winners; -DRS_HOLD_NO_EARLY: none). */
-#if defined(RS_HOLD_NO_EARLY)
-    const bool ewma_next = false;
-#elif defined(RS_HOLD_EARLY_ALL)
-    const bool ewma_next = quota_next;
-#else
+     * what the shorter top saves, as round 2 found for its speculation -- so: GreedyByRow only. */
     const bool ewma_next = quota_next && SCHED == 8;
-#endif
-    /* Opt-in (-DRS_COOP_SCAN): MaximizeCell's vector scan with nothing speculated beside it and every wave taking part (the
-     * compaction between two vectors is shared, rs_interslice.h); the decisions still fall on wave 0, which keeps the result */
-#ifdef RS_STAMPS
-#define RS_SCAN_WG_ARGS s_sorted, s_elems, m, S, R, pre_got, stamp_acc
-#else
-#define RS_SCAN_WG_ARGS s_sorted, s_elems, m, S, R, pre_got
-#endif
-#ifdef RS_COOP_SCAN /* measured at 25 RBGs, two cells per CU: 30.75 against 31.03 M TTIs/s (three more barriers per TTI); +3 % at 64 RBGs */
-    constexpr bool kCoopScan = kVecScan;
-#else
-    constexpr bool kCoopScan = false;
-#endif
-    const bool coop_scan = kCoopScan && vec_scan && !spec_enabled;
     /* schedulers 1 / 7: the other waves prepare TTI t+1 beside wave 0 (see kEarly17); not past the end of the launch */
     const bool early17 = kEarly17 && nwaves >= 2 && tti + 1 < p.n_ttis;
     bool early_scan_ok = false; /* NVS: TTI t+1 reads the CQI grid that is in LDS now */
@@ -1876,18 +1870,6 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       } else if (p.cqi_mode == RS_CQI_TRACE) {
         const double t_next = t + 0.001;
         early_scan_ok = reported && !(((int)(t_next * 1000) - last_sent) >= 40);
-      }
-    }
-    int pre_slice = -1, pre_got = 0;
-    if constexpr (kCoopScan) {
-      if (coop_scan) {
-        if (wave == 0) __builtin_amdgcn_s_setprio(RS_SERIAL_PRIO);
-        if constexpr (FIXED) {
-          pre_slice = interslice_maximize_cell_vector_wg<RS_JIT_S, RS_JIT_R, (RS_JIT_S <= 32 && RS_JIT_R <= 32)>(RS_SCAN_WG_ARGS);
-        } else {
-          if (R <= 32 && S <= 32) pre_slice = interslice_maximize_cell_vector_wg<0, 0, true>(RS_SCAN_WG_ARGS);
-          else pre_slice = interslice_maximize_cell_vector_wg<0, 0, false>(RS_SCAN_WG_ARGS);
-        }
       }
     }
     if (SCHED != 10 && wave == 0) {
@@ -2195,10 +2177,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #else
 #define RS_SCAN_ARGS s_sorted, m, S, R, got
 #endif
-          if (coop_scan) {
-            my_slice = pre_slice;
-            got = pre_got;
-          } else if constexpr (kVecScan) {
+          if constexpr (kVecScan) {
             if constexpr (FIXED) {
               my_slice = interslice_maximize_cell_vector<kS, kR, (kS <= 32 && kR <= 32)>(RS_SCAN_ARGS);
             } else {
@@ -2269,16 +2248,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 
       /* ---------------- P5: link adaptation + DoStopSchedule counters (lanes = RBGs) ---------------- */
       /* lanes holding the same user; the lowest one (leader) handles the user */
-      /* owner + 1 <= U <= 2047; a shape-specialised build knows how many bits that takes */
       constexpr bool kFlows = kQSerial && SCHED == 1; /* owner = flow id 2 * user + bearer */
-      constexpr int kOwnerMax = FIXED ? (kFlows ? 2 * RS_JIT_U : RS_JIT_U) : 0;
-      constexpr int kOwnerBits = !FIXED ? (kFlows ? 12 : 11) : kOwnerMax < 63 ? 6 : kOwnerMax < 127 ? 7 : kOwnerMax < 255 ? 8
-                                 : kOwnerMax < 511 ? 9 : kOwnerMax < 1023 ? 10 : kOwnerMax < 2047 ? 11 : 12;
-#ifdef RS_OWNER_BALLOTS /* the form this replaced: one ballot per bit of the owner index (~55 instructions at 500 UEs) */
-      BitBallots<kOwnerBits> ob;
-      ob.gather(owner + 1, lane < R && owner >= 0);
-      const unsigned long long same = owner >= 0 ? ob.lanes_with(owner + 1) : 0ull;
-#else
       /* owner + 1 < 4096 = two base-64 digits: the lanes that share both digits share the owner.  One LDS atomic OR per digit
        * into the sort's two 64-entry mask arrays (idle here), ~15 instructions and one LDS round trip */
       unsigned long long same = 0ull;
@@ -2298,7 +2268,6 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         const unsigned long long lo = m->maskA[key & 63], hi = m->maskB[key >> 6];
         if (has) same = lo & hi;
       }
-#endif
       const bool leader = owner >= 0 && (same & ((1ull << lane) - 1ull)) == 0;
       const unsigned long long lead_mask = __ballot(leader);
       served_prev = __popcll(lead_mask);
@@ -2328,7 +2297,6 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         unsigned long long mm = leader ? same : 0ull;
         double sum = 0;
         const uint8_t* col = s_cqi + (owner < 0 ? 0 : (kFlows ? owner >> 1 : owner));
-#ifndef RS_LA_NO_GATHER /* (the opt-out is the form this replaced: sched 7 -4 % at 25 RBGs, -8 % at 64) */
         /* every RBG lane looks up the E value of its own RBG for its owner once (two dependent LDS reads, all lanes side by
          * side); the leaders then collect their lanes' values in RBG order with lane reads instead of two LDS round trips per RBG */
         if (!per_prb) {
@@ -2344,7 +2312,6 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
             }
           }
         }
-#endif
         while (mm) {
           const int r2 = __ffsll((long long)mm) - 1;
           mm &= mm - 1;
@@ -2415,7 +2382,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         }
       }
       if ((kHoldSched && ewma_next) || early17) {
-        /* the exact EWMA of the served users for TTI t+1, on top of the decay the other waves applied (all of them first) */
+        /* the exact EWMA of the served users for TTI t+1, on top of the decay the other waves applied (all of them first).
+         * (Handing these ~900 cycles to wave 1 through an LDS list was measured and lost -- NVS 164 against 184 M TTIs/s, GreedyByRow
+         * 97.8 against 98.4: the update is a dependent chain that nothing overlaps with, whoever runs it, and the hand-over adds a
+         * polling round trip; profiles/r04_sched17.md) */
         while (rs_lds_load(&fl_cur->ctr_p1) < nwaves - 1) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (leader) {
@@ -2532,7 +2502,6 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       if (p.phy_draws) quota_draws(rs_lds_load(&m->served));
       quota_targets();
     }
-#ifndef RS_HOLD_NO_PRELIST
     if (kHoldSched && ewma_next && wave != 0 && hold_ok && n_items_rt <= 64 * nwaves) {
       /* my list for TTI t+1 (the held bits, the winners and -- once wave 0 has published it -- the served set are what the top
        * of TTI t+1 would read; if that TTI turns out to scan everything, the list is simply not used) */
@@ -2545,7 +2514,6 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         if (lane == 0) m->pad[1] = n0;
       }
     }
-#endif
     if (kSpecSched && spec_next && wave != 0) {
       /* ---------------- the other waves meanwhile: TTI t+1 as if nobody were served in TTI t ---------------- */
       const int nsp = nt - 64, me = tid - 64; /* scanning threads and my index among them */
@@ -2624,9 +2592,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
     /* (the packing condition is the same on every wave: wave 0 learns here that wave 1 packed its list) */
     if (wave == 0 && kHoldSched && ewma_next && hold_ok && n_items_rt <= 64 * nwaves) {
-#ifndef RS_HOLD_NO_PRELIST
       pre_listed = rs_lds_load(&m->pad[1]);
-#endif
     }
     served_prev = m->served;
     n_done += 1;

@@ -259,12 +259,8 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
                                      unsigned long long* sub, int seg_len = 0) {
   /* sub-ranges per wave at which the last levels go to single waves (same-box A/B, 512 cells: one position per lane -- 500 records --
    * 33.38 M TTIs/s with 2 against 33.18 with 4 and 32.70 with 1; three positions per lane -- 1 280 records -- 13.24 with 2 against 13.41
-   * with 4) */
-#ifdef RS_WAVE_FINISH_MAX
-  constexpr int kFinishMax = RS_WAVE_FINISH_MAX;
-#else
+   * with 4; round 4, 1 280 records: 2 / 4 / 8 within 0.3 % of each other) */
   constexpr int kFinishMax = EPT == 1 ? 2 : 4;
-#endif
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
 #ifdef RS_STAMPS
   unsigned long long sub_prev = __builtin_readcyclecounter();
@@ -315,11 +311,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       __syncthreads();
       /* (same-box A/B, 512 cells: the zigzag below 33.17 against 32.99 M TTIs/s at 500 records, one position per lane; at 1 280
        * records -- up to 32 entries to rank -- 13.30 against 13.49: list order there) */
-#ifdef RS_TAIL_ROUND_ROBIN
-      constexpr bool kZigzag = false;
-#else
       constexpr bool kZigzag = EPT == 1;
-#endif
       if constexpr (!kZigzag) {
       /* my share: entries wave, wave + nwaves, ... (lane t fetches the t-th of them), packed side by side while they fit */
       int n_mine = 0; /* entries j = wave + t * nwaves below n_alive (no division: nwaves is a run-time value) */
@@ -441,11 +433,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     {
       int cnt = 0;
       if (lane < n_chunks) cnt = __popcll(m->maskA[lane]) | (__popcll(m->maskB[lane]) << 16);
-#ifdef RS_SORT_SCAN64
-      pre = wave_scan_incl(cnt) - cnt;
-#else
       pre = n_chunks <= 8 ? wave_scan_excl8(cnt) : wave_scan_incl(cnt) - cnt; /* (512 records: the counts sit in lanes 0..7) */
-#endif
     }
     int slot[EPT]; /* where my element went / where its replacement arrives; -1: not swapped */
 #pragma unroll

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round 4, GPU run 6: same-box A/B of the drop-in prefetch; Vogel on bit planes: parity + rates; sched 7/8 sanity after the revert
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04_run6; mkdir -p $O; cd $R
+python -m pytest tests -m gpu -x -q -k "vogel or Vogel or 103 or random_shapes or experiment or specialised or drop_in or prepare" > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log; tail -4 $O/pytest.log
+for rep in 1 2; do
+echo "--- prefetch"; tools/dropin_latency 1500 | grep specialised
+echo "--- no prefetch"; RS_JIT_EXTRA="-DRS_NO_PREFETCH" tools/dropin_latency 1500 | grep specialised
+done 2>&1 | tee $O/dropin_ab.log
+ab() { # tag, extra, bench args
+  local tag=$1 extra=$2; shift 2
+  RS_JIT_EXTRA="$extra" timeout 300 python bench.py --allow-variant --no-cpu-baseline --no-r64 --no-streamed --steps 4 --warmup 1 --ttis 2000 "$@" > $O/ab_$tag.log 2>&1
+  grep -h '^{' $O/ab_$tag.log | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('%-28s %-20s %.2f M TTIs/s  %.3f us' % (sys.argv[1], sys.argv[2], d['value']/1e6, d['us_per_tti_per_cell']))" "$tag" "[$extra]" || tail -3 $O/ab_$tag.log
+}
+ab s103_r25 "" --sched 103
+ab s103_r64 "" --sched 103 --rbgs 64 --rbg-size 8
+ab s103_u1000 "" --sched 103 --ues-per-slice 50
+ab s7_r25 "" --sched 7
+ab s8_r25 "" --sched 8
