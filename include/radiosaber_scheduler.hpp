@@ -95,6 +95,10 @@ class GpuDownlinkScheduler {
     c.user_to_slice = user_to_slice_.data();
     ctx_ = RS_CREATE(&c); /* rs_create behind the ABI-version + struct-size check */
     if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
+    /* this context's own build of the one-TTI kernel (hiprtc, ~2 s once per shape and process; identical results, a call
+     * ~15-20 % shorter); a failure leaves the context on the kernels built into the library.  RS_DROPIN_JIT=0 skips it. */
+    const char* jit = getenv("RS_DROPIN_JIT");
+    if (!(jit && jit[0] == '0')) (void)rs_ctx_specialize(ctx_);
   }
   ~GpuDownlinkScheduler() { rs_destroy(ctx_); }
   GpuDownlinkScheduler(const GpuDownlinkScheduler&) = delete;

@@ -47,6 +47,7 @@ void DL_GPU_PF_PacketScheduler::RBsAllocation() {
     cfg.synthetic_exp = 0; /* DownlinkPacketScheduler::RBsAllocation has no synthetic-experiment branch */
     ctx_ = RS_CREATE(&cfg);
     if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
+    (void)rs_ctx_specialize(ctx_); /* this shape's own build of the one-TTI kernel (~2 s at start-up; on failure the built-in kernels stay) */
     nb_rbs_ = nb_rbs;
   }
   if (nb_rbs != nb_rbs_) throw std::runtime_error("DL_GPU_PF_PacketScheduler: the PRB grid changed after the first TTI");

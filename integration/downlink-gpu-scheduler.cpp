@@ -79,6 +79,7 @@ void DownlinkGpuScheduler::LazyCreate(int nb_rbs, int rbg_size) {
 #endif
   ctx_ = RS_CREATE(&cfg);
   if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
+  (void)rs_ctx_specialize(ctx_); /* this shape's own build of the one-TTI kernel (~2 s at start-up; on failure the built-in kernels stay) */
   nb_rbs_ = nb_rbs;
   rbg_size_ = rbg_size;
 }
