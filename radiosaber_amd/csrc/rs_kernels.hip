@@ -246,6 +246,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * 500 UEs x 25 RBGs, 161.6 against 125.4 at 1 000 UEs, 167.1 against 125.7 at 64 RBGs; profiles/r04_sched17.md) */
   constexpr bool kEarly17 = FIXED && !DIRECT && !QUEUE && (SCHED == 7 || (SCHED == 1 && RS_JIT_U > RS_JIT_NT));
 #endif
+  /* NVS scans the next TTI's slice four lanes per item (quad_scan, rs_phase_p3.inc) when its slices are scanned whole (no split
+   * runs) and the batch's longest slice window is known and fits two groups of eight users per lane */
+  constexpr bool kQuad7 = kEarly17 && SCHED == 7 && kCv.nvs_seg == 0 && RS_JIT_WIN > 0 && RS_JIT_WIN <= 64;
 
   double* s_avg = (double*)lds;
   double* s_avgk = (double*)(lds + o.avgk);
@@ -427,7 +430,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   uint32_t* const hold_served = (uint32_t*)m->hist; /* [64] */
   uint16_t* const hold_list = m->hist + 128;        /* 64 entries per wave: the items a wave scans again */
   int hold_win = 0; /* the longest 8-aligned slice window: 32 or 64 lanes per listed item (longer: no held winners) */
-  if (kHoldSched) {
+  if (kHoldSched || kQuad7) {
     int w = 0;
     if (lane < S && m->seg_begin[lane + 1] > m->seg_begin[lane]) w = ((m->seg_begin[lane + 1] + 7) & ~7) - (m->seg_begin[lane] & ~7);
     hold_win = wave_max(w);

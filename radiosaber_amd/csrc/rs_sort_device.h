@@ -154,7 +154,7 @@ __device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
   return upto_hi & (~0ull << lo);
 }
 
-#if defined(RS_STAMPS) && !defined(RS_STAMPS_HOLD)
+#if defined(RS_STAMPS) && !defined(RS_STAMPS_HOLD) && !defined(RS_STAMPS_P5)
 #define RS_SUBSTAMP(i)                                            \
   do {                                                            \
     if (tid == 0) {                                               \

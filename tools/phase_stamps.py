@@ -26,6 +26,7 @@ ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--ues-per-slice", type=int, default=25)
 ap.add_argument("--w1", action="store_true", help="-DRS_STAMPS_W1 build: the sub-stamp slots hold wave 1's serial-phase clock")
 ap.add_argument("--jit", action="store_true", help="shape-specialised kernel (export RS_JIT_EXTRA=-DRS_STAMPS)")
+ap.add_argument("--p5", action="store_true", help="-DRS_STAMPS_P5 build: sub-stamp slots = the steps of P5 on wave 0")
 ap.add_argument("--hold", action="store_true", help="-DRS_STAMPS_HOLD build: sub-stamp slots 0 / 1 = the held-winner scan's list step / item passes (wave 0)")
 ap.add_argument("--queues", action="store_true", help="the queue model on exp-customize-20slices (tools/bench_queue_mode.py's workload)")
 a = ap.parse_args()
@@ -53,7 +54,10 @@ st = np.stack([b.debug_stamps(c) for c in (0, a.cells // 2, a.cells - 1)]).astyp
 tot = st.sum(1)
 print("greedy: RBGs assigned / TTI", st[:, 9] / a.ttis, " sorted position of the last assignment (mean)", st[:, 10] / a.ttis)
 print(f"launch {ms[0]:.3f} ms, {ms[0] * 1e3 / a.ttis:.2f} us/TTI/cell; cycles/TTI (thread 0): {tot / a.ttis}")
-if a.hold:
+if a.p5:
+    SUB = ["P5: lanes per user (LDS atomics)", "P5: leaders, offsets, flags", "P5: E values + ordered sums", "P5: synthetic-exp bits", "P5: divide + classify",
+           "P5: MCS / TBS / counters", "P5: exact EWMA of the served", "-"]
+elif a.hold:
     SUB = ["hold: need + list", "hold: passes over the listed items", "-", "-", "-", "-", "-", "-"]
 elif a.w1:
     SUB = ["scan: EWMA of every user", "scan: wait for the other scanning waves", "scan: items", "scan: wait for the allocation", "scan: (quotas,) served check, list", "-", "-", "-"]
