@@ -556,6 +556,18 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   if constexpr (QUEUE) {
     /* DoStopSchedule of the launch's last TTI, so that the bearers' counters and queues the host reads are complete */
     for (int u = tid; u < U; u += nt) stop_schedule_user(u);
+    if constexpr (kQCumRegs) { /* the launch's cumulative counts of this thread's one user: plain adds, the owner is the only writer */
+      if (tid < U) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const size_t bi = bearer_index(tid, b);
+          if (qc_bytes[b] != 0) p.b_cumb[bi] += qc_bytes[b];
+          if (qc_rbs[b] != 0) p.b_cumr[bi] += qc_rbs[b];
+        }
+        if (qc_ubytes != 0) p.cum_bytes[(size_t)cell * U + tid] += qc_ubytes;
+        if (qc_urbs != 0) p.cum_rbs[(size_t)cell * U + tid] += qc_urbs;
+      }
+    }
     if (q_lds) { /* the bearers' words back to HBM, by their owner threads */
       const size_t n = (size_t)p.n_cells * 2 * U;
       for (int u = tid; u < U; u += nt)
