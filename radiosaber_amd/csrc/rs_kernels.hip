@@ -513,6 +513,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
      * share), MaximizeCell 32.86 against 33.16 -- the waves that work beside wave 0 slow its greedy scan and link adaptation by
      * what the shorter top saves, as round 2 found for its speculation -- so: GreedyByRow only. */
     const bool ewma_next = quota_next && SCHED == 8;
+    /* ... and pack their lists for TTI t+1 (a one-chunk shape: at most 64 items per wave).  Packing them for MaximizeCell too,
+     * without the early EWMA, was measured in round 4: 33.34 against 33.38 M TTIs/s -- the top of its TTI does not wait for it. */
+    const bool prelist_next = kHoldSched && ewma_next && hold_ok && n_items_rt <= 64 * nwaves;
     /* schedulers 1 / 7: the other waves prepare TTI t+1 beside wave 0 (see kEarly17); not past the end of the launch */
     const bool early17 = kEarly17 && nwaves >= 2 && tti + 1 < p.n_ttis;
     bool early_scan_ok = false; /* NVS: TTI t+1 reads the CQI grid that is in LDS now */
@@ -541,7 +544,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       have_scan = early17 && early_scan_ok && rs_lds_load(nvs_word_nxt) != seg_this;
     }
     /* (the packing condition is the same on every wave: wave 0 learns here that wave 1 packed its list) */
-    if (wave == 0 && kHoldSched && ewma_next && hold_ok && n_items_rt <= 64 * nwaves) {
+    if (wave == 0 && prelist_next) {
       pre_listed = rs_lds_load(&m->pad[1]);
     }
     served_prev = m->served;
