@@ -7,8 +7,14 @@ opponent is one that is never served either).  This test builds opponents that p
 possible amount, with the stage-1 reciprocal pushed one ulp in the unfavourable direction on both sides, lets both averages decay
 for 40 TTIs exactly as the kernel's EWMA does (separate multiply, add of beta * 0, clamp, 1 + avg, division by 1000, the metric's
 division), and requires q_w > q_v in every TTI."""
+import re
+from pathlib import Path
+
 import numpy as np
 
+# the age cap comes from the kernel source itself: the bound proved here and the constant the device uses cannot drift apart
+_SRC = (Path(__file__).resolve().parents[1] / "radiosaber_amd" / "csrc" / "rs_kernels.hip").read_text()
+MAX_AGE = int(re.search(r"#define RS_HOLD_MAX_AGE (\d+)", _SRC).group(1))
 C = 1.0 - 0.02  # the kernel's (1 - beta) in double
 KBPS = np.array([16, 32, 56, 88, 120, 136, 176, 224, 280, 328, 376, 440.00000000000006, 520, 584, 712])
 
@@ -53,7 +59,8 @@ def test_a_held_winner_is_never_overtaken_within_40_unserved_ttis():
     assert held(la, stage1(num_v, avg_v, +1), avg_w).all()
     worst = np.inf
     aw, av = avg_w.copy(), avg_v.copy()
-    for _ in range(41):
+    assert MAX_AGE <= 40, "the margin mu = 2^-18 + 2 / (1 + avg_w) is sized for at most 40 unserved TTIs (DESIGN.md, held winners)"
+    for _ in range(MAX_AGE + 1):
         qw, qv = metric(num_w, aw), metric(num_v, av)
         assert (qw > qv).all(), "a held winner was caught"
         worst = min(worst, float(((qw - qv) / qw).min()))
