@@ -246,6 +246,21 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * 500 UEs x 25 RBGs, 161.6 against 125.4 at 1 000 UEs, 167.1 against 125.7 at 64 RBGs; profiles/r04_sched17.md) */
   constexpr bool kEarly17 = FIXED && !DIRECT && !QUEUE && (SCHED == 7 || (SCHED == 1 && RS_JIT_U > RS_JIT_NT));
 #endif
+  /* Per-flow PF over backlogged users (shape-specialised batches): its arg-max has no slices -- per RBG the first maximum over ALL
+   * users -- so the scan can be dealt out by RBG instead of by (32-user run, RBG) item: every wave takes RBGs nwaves - 1 - wave,
+   * + nwaves, ... with all users in its lanes (8 or 16 consecutive ones per lane, their stage-1 reciprocals in registers), ranks them
+   * with the FP32 product of DESIGN.md 3.2, reduces over the wave (DPP) and settles ties exactly: an RBG's winner is final when its
+   * wave is done with it -- no per-item exact metric, no reduction over run winners on wave 0 (rs_phase_p3.inc).
+   * The scan is VALU-bound either way (five instructions per (user, RBG) product on every SIMD of the CU); what this form saves is
+   * the second stage.  Same-box A/B, 512 cells (tools/r04_run17.sh): 1 000 UEs x 25 RBGs 112.7 against 96.5 M TTIs/s, 500 x 25 161.5
+   * against 163.3, 500 x 64 96.7 against 96.3 -- so: from 16 users per lane on (-DRS_PF1_ALWAYS: every shape). */
+#if defined(RS_NO_PF1_LANES)
+  constexpr bool kPf1 = false;
+#elif defined(RS_PF1_ALWAYS)
+  constexpr bool kPf1 = FIXED && !DIRECT && !QUEUE && SCHED == 1 && RS_JIT_U <= 2048;
+#else
+  constexpr bool kPf1 = FIXED && !DIRECT && !QUEUE && SCHED == 1 && RS_JIT_U > 512 && RS_JIT_U <= 2048;
+#endif
   /* NVS scans the next TTI's slice four lanes per item (quad_scan, rs_phase_p3.inc) when its slices are scanned whole (no split
    * runs) and the batch's longest slice window is known and fits two groups of eight users per lane */
   constexpr bool kQuad7 = kEarly17 && SCHED == 7 && kCv.nvs_seg == 0 && RS_JIT_WIN > 0 && RS_JIT_WIN <= 64;

@@ -272,6 +272,23 @@ def test_schedulers_1_and_7_prepare_the_next_tti(rs, oracle, sched, ues, weights
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", ["-DRS_PF1_ALWAYS", "-DRS_PF1_ALWAYS -DRS_NO_EARLY17", "-DRS_NO_PF1_LANES"])
+def test_per_flow_pf_scan_one_wave_per_rbg(rs, oracle, extra, monkeypatch):
+    """Round 4: backlogged per-flow PF (sched 1) in shape-specialised batches settles every RBG on one wave over ALL users (kPf1,
+    rs_phase_p3.inc) -- the default from 16 users per lane on (1 000 UEs), forced here on every shape, and switched off again so
+    that the item scan stays under test at 1 000 UEs.  The first TTIs are the hard ones: every user starts from one average, so
+    whole CQI classes tie and go through the exact comparison (ascending user id, strict '>')."""
+    from test_gpu_parity import _check_batch
+    monkeypatch.setenv("RS_JIT_EXTRA", extra)
+    _check_batch(rs, oracle, 1, [50] * 20, 25, 4, n_cells=2, n_ttis=130, jit=True)            # 16 users per lane
+    _check_batch(rs, oracle, 1, [25] * 20, 25, 4, n_cells=2, n_ttis=90, jit=True, phy=1)      # 25 RBGs on 8 waves: shares of 4 and 3
+    _check_batch(rs, oracle, 1, [5] * 20, 64, 8, n_cells=2, n_ttis=85, jit=True, threads=256)  # 16 RBGs per wave
+    _check_batch(rs, oracle, 1, [3, 0, 7, 1, 12], 12, 2, n_cells=2, n_ttis=60, jit=True, threads=64)  # one wave, ragged, an empty slice
+    _check_batch(rs, oracle, 1, [37, 64, 12], 33, 3, n_cells=2, n_ttis=60, jit=True, threads=128)     # 113 users: lanes 15 ... 63 idle
+    _check_batch(rs, oracle, 1, [73] * 14, 7, 4, n_cells=1, n_ttis=50, jit=True)              # 1 022 users, fewer RBGs than waves
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sched", [7, 1])
 def test_schedulers_1_and_7_trace_replay_with_early_preparation(rs, oracle, traces, sched):
     """The same on the trace source: the report rule ((int)(t * 1000) - lastSent >= 40) decides whether the next TTI reads a new row."""
