@@ -313,7 +313,8 @@ def main():
 
     def make_batch(n_rbgs, rbg_size, launches, ttis, refresh=40):
         need = (launches * ttis + refresh - 1) // refresh
-        stride = (U * n_rbgs + 15) // 16 * 16
+        k8 = (U + 7) // 8
+        stride = (8 * (k8 if k8 & 1 else k8 + 1) * n_rbgs + 15) // 16 * 16  # device-resident grids are RBG-major [R][Upad]
         n_epochs = need
         wrap = False
         if refresh != 40 and need * args.cells * stride > EPOCH_BYTES_CAP:

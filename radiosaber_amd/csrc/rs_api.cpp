@@ -33,7 +33,7 @@ extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int N
                                    int direct);
 extern "C" int rs_jit_is_untuned(const RsJitKernel* k);
 extern "C" hipError_t rs_jit_launch(RsJitKernel* k, const RsLaunch* p, hipStream_t stream);
-extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,
+extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R, int Upad,
                                       uint64_t seed, int64_t first_cell, const uint32_t* cdf16, hipStream_t stream);
 extern "C" hipError_t rs_launch_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t stream);
 extern "C" hipError_t rs_launch_slice_bytes(const int64_t* cum_bytes, const uint8_t* user_slice, int n_cells, int U,
@@ -643,12 +643,16 @@ int rs_batch_upload_cqi_epochs(rs_batch* b, const uint8_t* h_cqi, int32_t n_epoc
   if (!b || !h_cqi || n_epochs < 1) return fail(RS_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   const size_t grid = (size_t)b->U * b->R;
-  const size_t stride = round_up((int)grid, 16);
+  /* device-resident form = the cell kernel's LDS image: RBG-major [R][Upad] with zero padding (a refresh is a straight copy) */
+  const size_t Upad = (size_t)rs_upad_of(b->U);
+  const size_t stride = round_up((int)(Upad * b->R), 16);
   const size_t total = (size_t)b->n_cells * n_epochs;
   for (size_t i = 0; i < total * grid; i++)
     if (h_cqi[i] < 1 || h_cqi[i] > 15) return fail(RS_ERR_INVALID, "CQI %d at byte %zu outside 1..15", h_cqi[i], i);
   std::vector<uint8_t> packed(total * stride, 0);
-  for (size_t g = 0; g < total; g++) memcpy(&packed[g * stride], h_cqi + g * grid, grid);
+  for (size_t g = 0; g < total; g++)
+    for (size_t u = 0; u < (size_t)b->U; u++)
+      for (size_t r = 0; r < (size_t)b->R; r++) packed[g * stride + r * Upad + u] = h_cqi[g * grid + u * b->R + r];
   if (b->d_epochs) { HIP_TRY(hipFree(b->d_epochs)); b->d_epochs = nullptr; }
   HIP_TRY(hipMalloc(&b->d_epochs, packed.size()));
   HIP_TRY(hipMemcpy(b->d_epochs, packed.data(), packed.size(), hipMemcpyHostToDevice));
@@ -702,11 +706,12 @@ int rs_batch_synthesize_cqi_at(rs_batch* b, uint64_t seed, const double* w, int3
   }
   cdf[14] = 4294967295u;
   cdf[15] = 4294967295u;
-  const size_t stride = round_up(b->U * b->R, 16);
+  const int Upad = rs_upad_of(b->U);
+  const size_t stride = round_up(Upad * b->R, 16); /* RBG-major [R][Upad]: the cell kernel's LDS image */
   const size_t bytes = (size_t)b->n_cells * n_epochs * stride;
   if (b->d_epochs) { HIP_TRY(hipFree(b->d_epochs)); b->d_epochs = nullptr; }
   HIP_TRY(hipMalloc(&b->d_epochs, bytes));
-  HIP_TRY(rs_launch_synth(b->d_epochs, (int64_t)stride, b->n_cells, n_epochs, b->U, b->R, seed, first_cell, cdf, b->stream));
+  HIP_TRY(rs_launch_synth(b->d_epochs, (int64_t)stride, b->n_cells, n_epochs, b->U, b->R, Upad, seed, first_cell, cdf, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->grid_stride = (int64_t)stride;
   b->n_epochs = n_epochs;
@@ -725,7 +730,10 @@ int rs_batch_download_cqi_epochs(rs_batch* b, int32_t cell, uint8_t* h_cqi) {
   const size_t grid = (size_t)b->U * b->R, stride = (size_t)b->grid_stride;
   std::vector<uint8_t> tmp((size_t)b->n_epochs * stride);
   HIP_TRY(hipMemcpy(tmp.data(), b->d_epochs + (size_t)cell * b->n_epochs * stride, tmp.size(), hipMemcpyDeviceToHost));
-  for (int e = 0; e < b->n_epochs; e++) memcpy(h_cqi + e * grid, &tmp[e * stride], grid);
+  const size_t Upad = (size_t)rs_upad_of(b->U);
+  for (int e = 0; e < b->n_epochs; e++) /* back to the caller's [U][R] order */
+    for (size_t u = 0; u < (size_t)b->U; u++)
+      for (size_t r = 0; r < (size_t)b->R; r++) h_cqi[e * grid + u * b->R + r] = tmp[e * stride + r * Upad + u];
   return RS_OK;
 }
 

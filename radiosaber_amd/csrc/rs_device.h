@@ -57,6 +57,8 @@ struct RsMisc {
   uint8_t eps_psi[64];           /* per slice: bit 0 = algo_epsilon, bit 1 = algo_psi (read by every work item of P3) */
   int32_t rcp_off[64];           /* per slice: window start in the reciprocal array minus the slice's 8-aligned first user */
   RsSpecFlags spec[2];           /* by TTI parity */
+  int32_t grid_free;             /* TTIs of this launch whose serial wave is done reading the CQI grid (the next grid may be written over it) */
+  int32_t pad2[3];
 };
 
 /* LDS carve of one cell (byte offsets from the dynamic LDS base), a pure function of the cell shape so

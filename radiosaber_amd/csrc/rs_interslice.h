@@ -421,7 +421,8 @@ __device__ __forceinline__ int interslice_subopt(const uint32_t* s_elems, const 
   int fewer = (lane < S && got < quota) ? quota - got : 0;
   unsigned long long more_mask = __ballot(more > 0), fewer_mask = __ballot(fewer > 0);
   int n_ord = 0;
-  if (lane == 0 && more_mask && fewer_mask) n_ord = rs_umap_order(fewer_mask, um, um + 68, um + 196);
+  /* every lane runs it (wave-uniform input, the same bytes to the same LDS addresses): no divergent region around the serial walk */
+  if (more_mask && fewer_mask) n_ord = rs_umap_order(fewer_mask, um, um + 68, um + 196);
   n_ord = __builtin_amdgcn_readfirstlane(n_ord);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();

@@ -372,6 +372,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     m->eff16[tid] = tab->eff[tid];
   }
   if (tid < 2) { m->spec[tid].ctr_p1 = 0; m->spec[tid].ctr_p3 = 0; m->spec[tid].greedy_done = 0; m->spec[tid].n_fix = 0; }
+  if (tid == 0) m->grid_free = 0;
   if (tid < S) {
     /* bit 0 = algo_epsilon, bit 1 = algo_psi, bit 2 = algo_alpha, bit 3 = algo_beta */
     m->eps_psi[tid] = (uint8_t)((p.eps[tid] ? 1 : 0) | (p.psi[tid] ? 2 : 0) | ((p.alpha && p.alpha[tid]) ? 4 : 0) | ((p.beta && p.beta[tid]) ? 8 : 0));
@@ -489,6 +490,21 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   bool have_ewma = false;  /* held winners: ... and so were the PF averages and terms (decay by the idle waves, served users by wave 0) */
   int pre_listed = -1;     /* held winners: this wave's list for this TTI was packed during the previous TTI's serial phase (-1: no) */
   bool have_scan = false;  /* NVS (kEarly17): this TTI's winners were found during the previous TTI's serial phase */
+  /* The next CQI grid, fetched ahead (batches on epoch grids; the schedulers whose TTI ends with wave 0 alone): when TTI t+1 starts a
+   * new epoch, the other waves read its grid from HBM during TTI t's serial phase and write it over the old one as soon as wave 0
+   * has read what its link adaptation needs of it (m->grid_free).  The device-resident grids are stored as the LDS image, RBG-major
+   * [R][Upad], so a refresh is a straight 16-byte copy either way; with the fetch ahead TTI t+1 starts with its grid in place -- no
+   * HBM latency at the top of the TTI.  Streamed-CQI mode (cqi_refresh = 1), 512 cells x 500 UEs x 25 RBGs, same box
+   * (tools/r04_run20.sh, against -DRS_NO_GRID_AHEAD, which keeps the straight copy at the top): GreedyByRow 59.9 against 53.9 M
+   * TTIs/s, NVS 148.9 against 124.4, per-flow PF 156.3 against 125.9; MaximizeCell LOSES (26.7 against 28.5 streamed, 31.2 against
+   * 33.4 with the grid resident: its kernel is register-bound and the extra live scalars cost more spills than the fetch saves),
+   * so it keeps the copy at the top of the TTI.  -DRS_GRID_AHEAD_ALL: MaximizeCell too. */
+#ifdef RS_GRID_AHEAD_ALL
+  constexpr bool kGridAhead = !DIRECT && (SCHED == 1 || SCHED == 7 || SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
+#else
+  constexpr bool kGridAhead = !DIRECT && (SCHED == 1 || SCHED == 7 || SCHED == 8 || SCHED == 101 || SCHED == 103);
+#endif
+  bool grid_ahead = false; /* this TTI's grid was written during the previous TTI's serial phase */
   for (int tti = 0; tti < p.n_ttis; ++tti) {
     RS_STAMP(11);
     auto prb_ptr = [&](int user, int r2) -> const uint8_t* { /* the G PRBs of RBG r2 as `user` reported them */
@@ -542,6 +558,16 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
         early_scan_ok = reported && !(((int)(t_next * 1000) - last_sent) >= 40);
       }
     }
+    /* does TTI t+1 start a new epoch whose grid is in HBM?  Then the other waves fetch it beside wave 0 (kGridAhead) */
+    bool grid_next = false;
+    long long epoch_next = 0;
+#ifndef RS_NO_GRID_AHEAD
+    if (kGridAhead && p.cqi_mode == RS_CQI_EPOCHS && nwaves >= 2 && tti + 1 < p.n_ttis && epoch_pos + 1 == p.refresh) {
+      epoch_next = epoch + 1;
+      if (epoch_next == p.n_epochs && p.epoch_wrap) epoch_next = 0;
+      grid_next = epoch_next < p.n_epochs; /* (past the last grid: the next TTI's P0 reports it) */
+    }
+#endif
     if (SCHED != 10 && wave == 0) {
 #include "rs_phase_p4_serial.inc"
 #include "rs_phase_p5.inc"
@@ -551,6 +577,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     RS_STAMP(7);
     __syncthreads();
     RS_STAMP(8);
+    grid_ahead = grid_next;
     have_spec = kSpecSched && spec_next;
     have_quota = quota_next || (kEarly17 && SCHED == 7 && early17);
     have_ewma = (kHoldSched && ewma_next) || early17;
@@ -688,7 +715,8 @@ struct RsCdf {
 };
 
 __global__ void rs_synth_cqi_kernel(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U,
-                                    int R, uint64_t seed, int64_t first_cell, RsCdf cdf) {
+                                    int R, int Upad, uint64_t seed, int64_t first_cell, RsCdf cdf) {
+  /* the grids are stored as the cell kernel's LDS image: RBG-major [R][Upad], zeros in the padding (rs_upad_of) */
   const int64_t grids = (int64_t)n_cells * n_epochs;
   const int64_t per_grid16 = grid_stride >> 4;
   const int64_t total = grids * per_grid16;
@@ -696,13 +724,14 @@ __global__ void rs_synth_cqi_kernel(uint8_t* epochs, int64_t grid_stride, int n_
     int64_t g = w / per_grid16;
     int64_t o = (w - g * per_grid16) << 4;
     uint8_t out[16];
+    int r = (int)(o / Upad), u = (int)(o - (int64_t)r * Upad);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      int64_t idx = o + k;
       uint8_t v = 0;
-      if (idx < (int64_t)U * R) {
+      if (r < R && u < U) {
         /* keyed by (seed, GLOBAL cell id, epoch, user, rbg): a cell's grids do not depend on how the cells are sharded over
-         * ranks nor on how many epochs were generated */
+         * ranks nor on how many epochs were generated -- nor on the storage order (the key is the [U][R] index) */
+        const int64_t idx = (int64_t)u * R + r;
         const uint64_t gcell = (uint64_t)(first_cell + g / n_epochs), ep = (uint64_t)(g % n_epochs);
         uint64_t h = splitmix64(seed ^ splitmix64(splitmix64(gcell * 0x100000001B3ull + ep) + (uint64_t)idx));
         uint32_t x = (uint32_t)(h >> 32);
@@ -712,6 +741,7 @@ __global__ void rs_synth_cqi_kernel(uint8_t* epochs, int64_t grid_stride, int n_
         v = (uint8_t)(q + 1);
       }
       out[k] = v;
+      if (++u == Upad) { u = 0; ++r; }
     }
     *(uint4*)(epochs + g * grid_stride + o) = *(const uint4*)out;
   }
@@ -816,7 +846,7 @@ extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes) {
   return hipSuccess;
 }
 
-extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R,
+extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R, int Upad,
                                       uint64_t seed, int64_t first_cell, const uint32_t* cdf16, hipStream_t stream) {
   RsCdf cdf;
   for (int i = 0; i < 16; ++i) cdf.c[i] = cdf16[i];
@@ -825,7 +855,7 @@ extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int 
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(rs_synth_cqi_kernel, dim3(blocks), dim3(256), 0, stream, epochs, grid_stride, n_cells, n_epochs,
-                     U, R, seed, first_cell, cdf);
+                     U, R, Upad, seed, first_cell, cdf);
   return hipGetLastError();
 }
 

@@ -123,7 +123,8 @@ def test_more_than_512_threads_needs_the_shape_specialised_kernel(rs):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sched,jit,refresh,R,G", [(9, True, 1, 25, 4), (9, False, 1, 25, 4), (8, True, 1, 25, 4), (9, True, 7, 64, 8),
-                                                   (7, True, 1, 25, 4), (1, False, 3, 25, 4)])
+                                                   (7, True, 1, 25, 4), (1, False, 3, 25, 4), (1, True, 1, 25, 4), (101, True, 1, 25, 4),
+                                                   (103, True, 1, 25, 4), (103, False, 2, 25, 4), (8, False, 1, 64, 8), (7, False, 1, 25, 4)])
 def test_cycling_epochs_and_streamed_cqi(rs, oracle, sched, jit, refresh, R, G):
     """rs_batch_config.cqi_epoch_wrap: a bounded set of grids serves a run of any length (epoch index modulo n_epochs), across
     launches too; cqi_refresh = 1 is SURVEY 8d's streamed-CQI mode (a grid from HBM every TTI).  The oracle gets the same
@@ -152,6 +153,44 @@ def test_cycling_epochs_and_streamed_cqi(rs, oracle, sched, jit, refresh, R, G):
     with pytest.raises(rs.RadioSaberError, match="past the last CQI epoch"):
         b.run(n_ttis)
         b.state()
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched,ues,R,G,refresh,threads", [
+    (8, [25] * 20, 25, 4, 1, 0),      # two 16-byte words per fetching thread
+    (8, [25] * 20, 64, 8, 1, 0),      # five
+    (7, [25] * 20, 25, 4, 1, 0),      # NVS: no early scan into a refresh, the grid arrives beside the link adaptation
+    (1, [50] * 20, 25, 4, 1, 0),      # per-flow PF on lanes (kPf1) reading a grid that was fetched ahead
+    (1, [25] * 20, 25, 4, 2, 256),    # every other TTI, four waves
+    (103, [25] * 20, 25, 4, 1, 0),
+    (101, [12, 30, 9], 33, 3, 1, 128),
+    (9, [25] * 20, 25, 4, 1, 0),      # MaximizeCell: the straight copy at the top of the TTI (no fetch ahead)
+])
+def test_next_cqi_grid_fetched_during_the_serial_phase(rs, oracle, sched, ues, R, G, refresh, threads):
+    """Round 4: the device-resident epoch grids are the LDS image (RBG-major [R][Upad]); when the next TTI starts a new epoch, the
+    waves beside wave 0 fetch its grid during the serial phase and write it over the old one once wave 0 has read what its link
+    adaptation needs (kGridAhead, rs_phase_next.inc).  Streamed-CQI mode on full-size cells, uneven launches (a launch's first TTI
+    loads its grid at the top), the decisions of the first launch and the final state against the oracle."""
+    sc = rs.SliceConfig(ues)
+    n_cells, n_ttis = 2, 58
+    grids = synth_cqi(4100 + sched + R, (n_cells, (n_ttis + refresh - 1) // refresh, sc.n_users, R), HIST)
+    seeds = np.arange(n_cells, dtype=np.uint32) * 31 + 5
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=True, cqi_refresh=refresh, threads_per_cell=threads)
+    assert b.kernel_name == "rs_cell_kernel_jit"
+    b.seed(seeds)
+    b.upload_cqi_epochs(grids)
+    np.testing.assert_array_equal(b.download_cqi_epochs(1), grids[1])  # the caller's [U][R] order back from the RBG-major store
+    got = b.run_logged(21)
+    for n in (1, 2, 34):
+        b.run(n)
+    st = b.state()
+    for c in range(n_cells):
+        cell = oracle.Cell(ues, R, G, sched)
+        logs = cell.run_synth(grids[c], int(seeds[c]), n_ttis, refresh=refresh)
+        np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"][:21], err_msg=f"cell {c} RBG map")
+        np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"][:21], err_msg=f"cell {c} TBS")
+        _assert_state_equal(st, c, cell.state(), f"sched {sched} refresh {refresh}")
     b.close()
 
 

@@ -28,6 +28,7 @@ ap.add_argument("--w1", action="store_true", help="-DRS_STAMPS_W1 build: the sub
 ap.add_argument("--jit", action="store_true", help="shape-specialised kernel (export RS_JIT_EXTRA=-DRS_STAMPS)")
 ap.add_argument("--p5", action="store_true", help="-DRS_STAMPS_P5 build: sub-stamp slots = the steps of P5 on wave 0")
 ap.add_argument("--hold", action="store_true", help="-DRS_STAMPS_HOLD build: sub-stamp slots 0 / 1 = the held-winner scan's list step / item passes (wave 0)")
+ap.add_argument("--cqi-refresh", type=int, default=40, help="TTIs between two CQI grids (1: streamed-CQI mode; the epochs cycle through 64 grids)")
 ap.add_argument("--queues", action="store_true", help="the queue model on exp-customize-20slices (tools/bench_queue_mode.py's workload)")
 a = ap.parse_args()
 if a.queues:
@@ -41,13 +42,14 @@ if a.queues:
     bursts = {(c, u, k): v for c in range(a.cells) for (u, k), v in per_cell[c % 8].items()}
 else:
     sc = rs.SliceConfig([a.ues_per_slice] * 20, weight=[0.05] * 20)
-b = rs.BatchScheduler(sc, a.rbgs, a.rbg_size, a.cells, sched=a.sched, threads_per_cell=a.threads, jit=a.jit)
+b = rs.BatchScheduler(sc, a.rbgs, a.rbg_size, a.cells, sched=a.sched, threads_per_cell=a.threads, jit=a.jit,
+                      cqi_refresh=a.cqi_refresh, cqi_epoch_wrap=a.cqi_refresh != 40)
 if a.queues:
     b.set_bearers(sc.bearer_kinds())
     b.set_arrivals(bursts)
     print("jit status:", b.jit_status())
 b.seed(np.arange(a.cells, dtype=np.uint32) + 1)
-b.synthesize_cqi(1, (2 * a.ttis + 39) // 40)
+b.synthesize_cqi(1, (2 * a.ttis + 39) // 40 if a.cqi_refresh == 40 else 64)
 b.run(a.ttis)
 ms = b.run_timed(a.ttis, 1)
 st = np.stack([b.debug_stamps(c) for c in (0, a.cells // 2, a.cells - 1)]).astype(np.float64)
