@@ -535,7 +535,8 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
     /* failure is not an error of this call: the built-in kernels stay in use and the batch keeps the reason
      * (rs_batch_jit_status); rs_last_error() is left alone */
     b->jit_wanted = true;
-    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, slice_window(b), b->jit_msg, sizeof b->jit_msg, 0);
+    b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, slice_window(b), b->jit_msg, sizeof b->jit_msg,
+                        b->cfg.cqi_refresh <= 4 ? 2 : 0);
     if (b->jit) snprintf(b->jit_msg, sizeof b->jit_msg, "%s", rs_jit_is_untuned(b->jit) ? "in use, built WITHOUT the -mllvm tuning options (hiprtc refused them): a few per cent slower" : "");
     else if (!b->jit_msg[0]) snprintf(b->jit_msg, sizeof b->jit_msg, "hiprtc build failed");
     if (!b->jit && b->threads > 512) { /* nothing else can launch this workgroup size */
