@@ -498,11 +498,17 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * (tools/r04_run20.sh, against -DRS_NO_GRID_AHEAD, which keeps the straight copy at the top): GreedyByRow 59.9 against 53.9 M
    * TTIs/s, NVS 148.9 against 124.4, per-flow PF 156.3 against 125.9; MaximizeCell LOSES (26.7 against 28.5 streamed, 31.2 against
    * 33.4 with the grid resident: its kernel is register-bound and the extra live scalars cost more spills than the fetch saves),
-   * so it keeps the copy at the top of the TTI.  -DRS_GRID_AHEAD_ALL: MaximizeCell too. */
+   * so it keeps the copy at the top of the TTI (-DRS_GRID_AHEAD_ALL: MaximizeCell too).
+   * The code costs the kernels that never use it (same box, grid resident, with / without it compiled in: NVS 218.7 / 232.4 M TTIs/s,
+   * GreedyByRow at 64 RBGs 44.4 / 48.0 -- tools/r04_run30.sh), so only the kernels of a streamed batch carry it: rs_jit.cpp defines
+   * RS_JIT_STREAMED when the batch's cqi_refresh is at most 4 (the built-in kernels copy at the top of the TTI). */
+#ifndef RS_JIT_STREAMED
+#define RS_JIT_STREAMED 0
+#endif
 #ifdef RS_GRID_AHEAD_ALL
-  constexpr bool kGridAhead = !DIRECT && (SCHED == 1 || SCHED == 7 || SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
+  constexpr bool kGridAhead = FIXED && RS_JIT_STREAMED && !DIRECT && (SCHED == 1 || SCHED == 7 || SCHED == 8 || SCHED == 9 || SCHED == 101 || SCHED == 103);
 #else
-  constexpr bool kGridAhead = !DIRECT && (SCHED == 1 || SCHED == 7 || SCHED == 8 || SCHED == 101 || SCHED == 103);
+  constexpr bool kGridAhead = FIXED && RS_JIT_STREAMED && !DIRECT && (SCHED == 1 || SCHED == 7 || SCHED == 8 || SCHED == 101 || SCHED == 103);
 #endif
   bool grid_ahead = false; /* this TTI's grid was written during the previous TTI's serial phase */
   for (int tti = 0; tti < p.n_ttis; ++tti) {
