@@ -260,6 +260,8 @@ struct rs_batch {
   uint8_t* d_qflags = nullptr;
   double* d_qhol = nullptr;
   RsJitKernel* jit = nullptr; /* shape-specialised kernel (owned by the process-wide cache) */
+  RsJitKernel* jit_lean = nullptr; /* its lean build, compiled at the first launch that can use it (launch()) */
+  bool jit_lean_tried = false;
   bool jit_wanted = false;
   char jit_msg[512] = ""; /* why the shape-specialised kernel is not in use (empty: it is, or it was not asked for) */
   int64_t ttis_done = 0;
@@ -597,7 +599,29 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
     L.b_avg = b->d_bavg; L.b_cumb = b->d_bcum; L.b_cumr = b->d_bcum + n;
     L.q_flags = b->d_qflags; L.q_hol = b->d_qhol;
   }
-  if (b->jit) HIP_TRY(rs_jit_launch(b->jit, &L, b->stream));
+  RsJitKernel* k = b->jit;
+  if (k && !b->queues && !b->direct) {
+    /* Long unlogged runs on epoch grids -- what the measurements and any production batch are -- go to the LEAN build of the
+     * shape-specialised kernel: the options this launch does not use are compile-time constants there.  Compiled once, at the
+     * first launch that qualifies (RS_JIT_LEAN_MIN_TTIS, default 256: short test launches are not worth a hiprtc run;
+     * RS_JIT_LEAN=0 switches it off); if hiprtc fails the general kernel stays in use. */
+    const char* const e_min = getenv("RS_JIT_LEAN_MIN_TTIS");
+    const char* const e_on = getenv("RS_JIT_LEAN");
+    const int lean_min = e_min ? atoi(e_min) : 256;
+    const bool lean_on = !e_on || atoi(e_on) != 0;
+    const bool lean_ok = lean_on && n_ttis >= lean_min && L.cqi_mode == RS_CQI_EPOCHS && !L.epochs_prb && !d_map && !d_quota && !d_target &&
+                         !d_tbs && !d_uinfo && !d_keys && !L.phy_draws && !L.synthetic;
+    if (lean_ok) {
+      if (!b->jit_lean_tried) {
+        b->jit_lean_tried = true;
+        char msg[512] = "";
+        b->jit_lean = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, slice_window(b), msg, sizeof msg,
+                                 (b->cfg.cqi_refresh <= 4 ? 2 : 0) | 4);
+      }
+      if (b->jit_lean) k = b->jit_lean;
+    }
+  }
+  if (k) HIP_TRY(rs_jit_launch(k, &L, b->stream));
   else HIP_TRY(rs_launch_cells(&L, b->threads, b->stream));
   b->ttis_done += n_ttis;
   return RS_OK;

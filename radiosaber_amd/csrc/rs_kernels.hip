@@ -698,6 +698,16 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
 #define RS_JIT_WPE 4
 #endif
 extern "C" __global__ void __launch_bounds__(RS_JIT_NT, RS_JIT_WPE) rs_cell_kernel_jit(RsLaunch p) {
+#if defined(RS_JIT_LEAN) && RS_JIT_LEAN
+  /* The lean build of a batch kernel: the launch's run-time options that the long runs never use are constants here -- epoch grids
+   * (no trace rows, no per-PRB twins), no per-TTI decision log, no error-model draws, no synthetic-experiment transport blocks --
+   * so their branches, pointers and live scalars are gone (the kernels are bound by registers and issue slots, not by HBM).  The
+   * host launches it only when the launch block says exactly this (rs_api.cpp). */
+  p.cqi_mode = RS_CQI_EPOCHS;
+  p.trace = nullptr; p.trace_prb = nullptr; p.epochs_prb = nullptr; p.user_trace = nullptr;
+  p.log_map = nullptr; p.log_quota = nullptr; p.log_target = nullptr; p.log_tbs = nullptr; p.log_uinfo = nullptr; p.log_keys = nullptr;
+  p.phy_draws = 0; p.synthetic = 0;
+#endif
   constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_CARVEQ);
   __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
   constexpr int kEpt = (RS_JIT_SCHED != 9 && RS_JIT_SCHED != 10) ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);

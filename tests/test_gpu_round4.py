@@ -195,6 +195,40 @@ def test_next_cqi_grid_fetched_during_the_serial_phase(rs, oracle, sched, ues, R
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sched,ues,R,G,refresh,threads", [
+    (9, [25] * 20, 25, 4, 40, 0), (9, [5] * 20, 64, 8, 40, 0), (8, [25] * 20, 25, 4, 40, 0), (8, [50] * 20, 25, 4, 1, 0),
+    (7, [25] * 20, 25, 4, 40, 0), (1, [25] * 20, 25, 4, 40, 0), (1, [50] * 20, 25, 4, 2, 0), (103, [12, 30, 9], 33, 3, 40, 128),
+    (101, [25] * 20, 25, 4, 40, 0), (10, [5] * 20, 25, 4, 40, 0), (11, [5] * 20, 25, 4, 40, 0),
+])
+def test_lean_build_of_the_batch_kernel(rs, oracle, sched, ues, R, G, refresh, threads, monkeypatch):
+    """Round 4: unlogged launches on epoch grids run the LEAN build of the shape-specialised kernel (the launch's unused run-time
+    options -- trace rows, per-PRB twins, the decision log, error-model draws, synthetic-experiment blocks -- as compile-time
+    constants; rs_api.cpp's launch(), from RS_JIT_LEAN_MIN_TTIS TTIs per launch on: 1 here).  Logged launches stay on the general
+    build: the two alternate on one batch, and the final state must be the oracle's."""
+    monkeypatch.setenv("RS_JIT_LEAN_MIN_TTIS", "1")
+    sc = rs.SliceConfig(ues)
+    n_cells, n_ttis = 2, 131
+    grids = synth_cqi(5200 + sched + R, (n_cells, (n_ttis + refresh - 1) // refresh, sc.n_users, R), HIST)
+    seeds = np.arange(n_cells, dtype=np.uint32) * 13 + 3
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=True, cqi_refresh=refresh, threads_per_cell=threads)
+    assert b.kernel_name == "rs_cell_kernel_jit"
+    b.seed(seeds)
+    b.upload_cqi_epochs(grids)
+    b.run(37)                 # lean
+    got = b.run_logged(21)    # general (logs)
+    for n in (1, 2, 70):      # lean again
+        b.run(n)
+    st = b.state()
+    for c in range(n_cells):
+        cell = oracle.Cell(ues, R, G, sched)
+        logs = cell.run_synth(grids[c], int(seeds[c]), n_ttis, refresh=refresh)
+        np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"][37:58], err_msg=f"cell {c} RBG map")
+        np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"][37:58], err_msg=f"cell {c} TBS")
+        _assert_state_equal(st, c, cell.state(), f"sched {sched} lean")
+    b.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sched", [9, 8])
 def test_held_winners_long_run_uneven_launches(rs, oracle, sched):
     """the optimisation whose exactness rests on a numerical margin gets a driver-visible long run --
