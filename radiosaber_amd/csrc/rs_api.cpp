@@ -1384,7 +1384,11 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   const bool want_upper = b->sched == RS_SCHED_UPPERBOUND && (out->upper_rbg || out->upper_user);
   L.log_upper = want_upper ? (int32_t*)(dev_out + l.upper) : nullptr;
   /* direct mode: the kernel clears its per-user outputs itself and reads the single grid on every call */
-  if (b->jit) HIP_TRY(rs_jit_launch(b->jit, &L, st)); /* rs_ctx_specialize: this context's own build of the one-TTI kernel */
+  /* rs_ctx_specialize: this context's own build of the one-TTI kernel -- its lean form for the plain call (per-RBG CQI, no customised
+   * slices, no gates, exponents in {0, 1}, every input inside the FP32 filter's range), the general one otherwise */
+  RsJitKernel* kd = b->jit;
+  if (b->jit_lean && !L.prb_cqi && !L.queue_mode && !L.gate && !L.exact_scan && !L.gen_exp && !L.log_upper && !L.synthetic) kd = b->jit_lean;
+  if (kd) HIP_TRY(rs_jit_launch(kd, &L, st));
   else HIP_TRY(rs_launch_cells(&L, b->threads, st));
   if (!zc) HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, l.out_total, hipMemcpyDeviceToHost, st));
   const clk::time_point t2 = c->timing ? clk::now() : clk::time_point();
@@ -1446,6 +1450,12 @@ int rs_ctx_specialize(rs_ctx* c) {
   b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, gate_scratch ? 1 : 0, 0, b->jit_msg, sizeof b->jit_msg, 1);
   if (!b->jit) return fail(RS_ERR_HIP, "%s", b->jit_msg[0] ? b->jit_msg : "hiprtc build failed");
   b->jit_msg[0] = 0;
+  /* ... and its lean form (the per-call options of the plain call as constants); without it the general build serves every call */
+  const char* const e_on = getenv("RS_JIT_LEAN");
+  if (!e_on || atoi(e_on) != 0) {
+    char msg[512] = "";
+    b->jit_lean = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, gate_scratch ? 1 : 0, 0, msg, sizeof msg, 1 | 4);
+  }
   return RS_OK;
 }
 

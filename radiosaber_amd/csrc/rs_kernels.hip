@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(512, 4) rs_cell_kernel(RsLaunch p) {
 #define RS_JIT_WPE 4
 #endif
 extern "C" __global__ void __launch_bounds__(RS_JIT_NT, RS_JIT_WPE) rs_cell_kernel_jit(RsLaunch p) {
-#if defined(RS_JIT_LEAN) && RS_JIT_LEAN
+#if defined(RS_JIT_LEAN) && RS_JIT_LEAN && !RS_JIT_DIRECT
   /* The lean build of a batch kernel: the launch's run-time options that the long runs never use are constants here -- epoch grids
    * (no trace rows, no per-PRB twins), no per-TTI decision log, no error-model draws, no synthetic-experiment transport blocks --
    * so their branches, pointers and live scalars are gone (the kernels are bound by registers and issue slots, not by HBM).  The
@@ -707,6 +707,14 @@ extern "C" __global__ void __launch_bounds__(RS_JIT_NT, RS_JIT_WPE) rs_cell_kern
   p.trace = nullptr; p.trace_prb = nullptr; p.epochs_prb = nullptr; p.user_trace = nullptr;
   p.log_map = nullptr; p.log_quota = nullptr; p.log_target = nullptr; p.log_tbs = nullptr; p.log_uinfo = nullptr; p.log_keys = nullptr;
   p.phy_draws = 0; p.synthetic = 0;
+#elif defined(RS_JIT_LEAN) && RS_JIT_LEAN
+  /* ... and of a drop-in context's one-TTI kernel: the plain call -- per-RBG reports, no customised slices, no m_requiredRBs /
+   * dataToTransmit gates, exponents in {0, 1}, every input an ordinary FP32 number, no UpperBound lists, no synthetic-experiment
+   * blocks (rs_schedule_tti picks it per call) */
+  p.cqi_mode = RS_CQI_EPOCHS;
+  p.prb_cqi = nullptr; p.queue_mode = 0; p.alpha = nullptr; p.beta = nullptr; p.hol = nullptr; p.prio = nullptr;
+  p.gate = nullptr; p.exact_scan = 0; p.gen_exp = 0; p.gen_num = nullptr; p.log_upper = nullptr; p.synthetic = 0;
+  p.trace = nullptr; p.trace_prb = nullptr; p.epochs_prb = nullptr; p.log_keys = nullptr;
 #endif
   constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_CARVEQ);
   __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
