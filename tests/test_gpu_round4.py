@@ -74,7 +74,7 @@ def test_jit_builds_without_the_llvm_tuning_options_and_for_640_threads(rs):
     assert rs.jit_selfcheck(20, 500, 25, 4, 512, rs.RS_SCHED_MAXCELL, untuned=True) > 0
     assert rs.jit_selfcheck(20, 500, 64, 8, 640, rs.RS_SCHED_MAXCELL) > 0
     src = (ROOT / "radiosaber_amd" / "csrc" / "rs_jit.cpp").read_text()
-    assert "rs_jit_compile(S, U, R, G, NT, sched, log2, qmode, win, false, direct != 0, streamed)" in src  # the retry in rs_jit_get
+    assert "rs_jit_compile(S, U, R, G, NT, sched, log2, qmode, win, false, " in src  # the retry in rs_jit_get: same arguments, tuned = false
     assert rs.lds_bytes_per_cell(20, 500, 64, rs.RS_SCHED_MAXCELL, 640) <= 80 * 1024  # two cells per CU
 
 
@@ -191,6 +191,31 @@ def test_next_cqi_grid_fetched_during_the_serial_phase(rs, oracle, sched, ues, R
         np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"][:21], err_msg=f"cell {c} RBG map")
         np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"][:21], err_msg=f"cell {c} TBS")
         _assert_state_equal(st, c, cell.state(), f"sched {sched} refresh {refresh}")
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sched,extra", [(9, "-DRS_GRID_AHEAD_ALL"), (8, "-DRS_NO_GRID_AHEAD"), (103, "-DRS_NO_GRID_AHEAD")])
+def test_fetch_ahead_switched_the_other_way(rs, oracle, sched, extra, monkeypatch):
+    """The fetch-ahead switch the other way from the default (MaximizeCell with it, the others without) stays bit-exact: both
+    forms are some shape's product path."""
+    monkeypatch.setenv("RS_JIT_EXTRA", extra)
+    monkeypatch.setenv("RS_JIT_LEAN_MIN_TTIS", "1")
+    ues, R, G, refresh, n_cells, n_ttis = [25] * 20, 25, 4, 1, 2, 45
+    sc = rs.SliceConfig(ues)
+    grids = synth_cqi(6100 + sched, (n_cells, n_ttis, sc.n_users, R), HIST)
+    seeds = np.arange(n_cells, dtype=np.uint32) + 71
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=True, cqi_refresh=refresh)
+    b.seed(seeds)
+    b.upload_cqi_epochs(grids)
+    got = b.run_logged(19)
+    b.run(26)
+    st = b.state()
+    for c in range(n_cells):
+        cell = oracle.Cell(ues, R, G, sched)
+        logs = cell.run_synth(grids[c], int(seeds[c]), n_ttis, refresh=refresh)
+        np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"][:19])
+        _assert_state_equal(st, c, cell.state(), f"sched {sched} {extra}")
     b.close()
 
 
