@@ -6,6 +6,7 @@ set -x
 python -c "import radiosaber_amd as rs; print('device sources', rs.device_source_hash())"
 timeout 1500 python tools/fuzz_parity.py 7000 150
 timeout 900 python tools/fuzz_queues.py 11000 60
+timeout 1200 python tools/fuzz_lean.py 13000 60
 for a in "--sched 9 --jit 1 --ttis 8000" "--sched 9 --jit 0" "--sched 8 --jit 1 --ttis 8000" "--sched 9 --jit 1 --rbgs 64 --rbg-size 8 --cells 16" \
          "--sched 7 --jit 1 --ttis 20000" "--sched 7 --jit 1 --ttis 8000 --phy 1 --launch 37" "--sched 7 --jit 1 --rbgs 64 --rbg-size 8 --ttis 8000" \
          "--sched 7 --jit 1 --ues-per-slice 50 --ttis 8000" "--sched 7 --jit 1 --slices 3 --ues-per-slice 40 --ttis 8000" "--sched 7 --jit 1 --threads 128 --ttis 8000" \
