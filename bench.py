@@ -342,6 +342,7 @@ def main():
         b.seed(sharding.seeds_for_cells(sharding.cell_ids_for_rank(rank, world, args.cells)))
         b.synthesize_cqi(0x5AB3, n_epochs,  # generated on the device, stay in HBM
                          first_cell=sharding.first_cell_for_rank(rank, world, args.cells))
+        b.prepare_launch(ttis)  # the lean build of the kernel is compiled here, not inside a (possibly timed) first launch
         return b
 
     batch = make_batch(R, args.rbg_size, args.steps + args.warmup, args.ttis, args.cqi_refresh)

@@ -195,8 +195,10 @@ typedef struct rs_tti_out {
 int rs_schedule_tti(rs_ctx* ctx, const rs_tti_in* in, rs_tti_out* out);
 /* Optional, once after rs_create: compile this context's own build of the one-TTI kernel (hiprtc, ~2 s per shape and process,
  * cached) -- slices, RBGs, PRBs per RBG, scheduler and the user capacity as compile-time constants, the users of a call still a
- * launch argument.  Results are identical; a call gets shorter.  RS_OK, or RS_ERR_HIP with the context left on the
- * kernels built into the library.  The C++ adapter calls it from its constructor.  (ABI 9) */
+ * launch argument.  Results are identical; a call gets shorter.  Two builds (~2 s each): the general one and a lean
+ * one that serves the plain call -- per-RBG CQI, no customised slices, no gates, exponents in {0, 1}, every input an ordinary
+ * FP32 number -- with those per-call options as constants (RS_JIT_LEAN=0: the general one only).  RS_OK, or RS_ERR_HIP with the
+ * context left on the kernels built into the library.  The C++ adapter calls it from its constructor.  (ABI 9) */
 int rs_ctx_specialize(rs_ctx* ctx);
 /* build check without a GPU: does that kernel compile for a context of this shape? (code size or a negative value) */
 int rs_jit_selfcheck_dropin(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, char* err, size_t errlen);
@@ -230,7 +232,11 @@ typedef struct rs_batch_config {
   int32_t jit;               /* 1: compile the cell kernel for this batch's exact shape at create time
                                 (hiprtc, ~2 s, cached per process); results are identical, the built-in
                                 kernels are used if the compilation fails (rs_batch_jit_status tells).  0: built-in kernels.
-                                The environment variable RS_JIT=0|1 overrides.                    */
+                                The environment variable RS_JIT=0|1 overrides.  Unlogged launches of at least 256 TTIs
+                                (RS_JIT_LEAN_MIN_TTIS) on epoch grids without per-PRB twins, error-model draws or synthetic-experiment
+                                blocks run the LEAN build of that kernel (those launch options as compile-time constants; compiled at
+                                the first such launch, ~2 s; identical results; RS_JIT_LEAN=0 keeps the general build).  A batch with
+                                cqi_refresh <= 4 gets kernels that fetch the next grid during the serial end of the TTI.        */
   int32_t cqi_epoch_wrap;    /* epoch sources (upload / synthesize): 0 = running past the last epoch is RS_ERR_RANGE;
                                 1 = the epochs cycle (epoch index modulo n_epochs) -- a bounded set of grids serves a
                                 run of any length, e.g. the streamed-CQI measurement with cqi_refresh = 1 (ABI 9)  */
@@ -385,6 +391,10 @@ int rs_batch_read_clock(rs_batch* b, double* t, double* last_update);
  * 0: it was not asked for; -1: it was asked for and could not be built -- the built-in kernels run instead and msg
  * receives the reason */
 int rs_batch_jit_status(rs_batch* b, char* msg, size_t msglen);
+/* Optional: build now whatever kernel an unlogged rs_batch_run of n_ttis TTIs would otherwise build at its first launch (the lean
+ * build of the shape-specialised kernel, see rs_batch_config.jit), so that no timed launch carries a hiprtc run.  Call it once the
+ * CQI source is set.  RS_OK also when there is nothing to build. */
+int rs_batch_prepare_launch(rs_batch* b, int32_t n_ttis);
 /* per-slice cumulative bytes summed over the batch's cells, reduced on the device into
  * d_out[S] (device pointer, uint64) on the batch's stream -- the vector the multi-GPU run
  * all-reduces over RCCL (the reference's plot_throughput.py:26-56 sums it per slice post hoc) */

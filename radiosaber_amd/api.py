@@ -89,7 +89,7 @@ ABI_SYMBOLS = [
     "rs_batch_slice_bytes", "rs_jit_selfcheck", "rs_jit_selfcheck_queue", "rs_batch_debug_stamps", "rs_batch_ttis_done", "rs_batch_stream", "rs_batch_kernel_name",
     "rs_trace_read_mapping", "rs_trace_read_ue_log", "rs_trace_load_dir", "rs_hbm_copy_probe", "rs_lds_bytes_per_cell",
     "rs_get_rbg_size", "rs_dl_prbs_for_bandwidth", "rs_batch_synthesize_cqi_at", "rs_batch_run_logged_ex",
-    "rs_batch_read_clock", "rs_batch_jit_status",
+    "rs_batch_read_clock", "rs_batch_jit_status", "rs_batch_prepare_launch",
     "rs_batch_upload_cqi_epochs_prb", "rs_batch_set_trace_prb",
     "rs_batch_set_bearers", "rs_batch_set_arrivals", "rs_batch_read_bearer_state", "rs_internet_flow_arrivals",
     "rs_device_source_hash",
@@ -134,6 +134,7 @@ def lib():
     L.rs_batch_run_logged_ex.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_BatchLog)]
     L.rs_batch_read_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rs_batch_jit_status.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.rs_batch_prepare_launch.argtypes = [C.c_void_p, C.c_int32]
     L.rs_batch_upload_cqi_epochs_prb.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32]
     L.rs_batch_set_trace_prb.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     L.rs_batch_set_bearers.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
@@ -647,6 +648,10 @@ class BatchScheduler:
         lu = np.zeros(self.n_cells, np.float64)
         _check(lib().rs_batch_read_clock(self._h, _p(t, C.c_double), _p(lu, C.c_double)))
         return t, lu
+
+    def prepare_launch(self, n_ttis):
+        """Build now the kernel an unlogged run(n_ttis) would build at its first launch (the lean build): keeps hiprtc out of timed runs."""
+        _check(lib().rs_batch_prepare_launch(self._h, int(n_ttis)))
 
     def jit_status(self):
         """(code, message): 1 = shape-specialised kernel in use, 0 = not requested, -1 = requested but the build failed."""

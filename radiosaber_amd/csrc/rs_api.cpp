@@ -561,6 +561,27 @@ int check_device_err(rs_batch* b) {
   return RS_OK;
 }
 
+/* Long unlogged runs on epoch grids -- what the measurements and any production batch are -- go to the LEAN build of the
+ * shape-specialised kernel: the options such a launch does not use (trace rows, per-PRB twins, the decision log, error-model draws,
+ * synthetic-experiment blocks) are compile-time constants there.  Compiled once, at the first launch that qualifies
+ * (RS_JIT_LEAN_MIN_TTIS, default 256: short test launches are not worth a hiprtc run; RS_JIT_LEAN=0 switches it off) or by
+ * rs_batch_prepare_launch; nullptr = the general kernel (or the built-in ones) serves this launch. */
+RsJitKernel* lean_kernel(rs_batch* b, int n_ttis, bool logged) {
+  if (!b->jit || b->queues || b->direct || logged) return nullptr;
+  const char* const e_min = getenv("RS_JIT_LEAN_MIN_TTIS");
+  const char* const e_on = getenv("RS_JIT_LEAN");
+  const int lean_min = e_min ? atoi(e_min) : 256;
+  if (e_on && atoi(e_on) == 0) return nullptr;
+  if (n_ttis < lean_min || b->cqi_mode != RS_CQI_EPOCHS || b->d_epochs_prb || b->cfg.phy_error_draws || b->synthetic) return nullptr;
+  if (!b->jit_lean_tried) {
+    b->jit_lean_tried = true;
+    char msg[512] = "";
+    b->jit_lean = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, slice_window(b), msg, sizeof msg,
+                             (b->cfg.cqi_refresh <= 4 ? 2 : 0) | 4);
+  }
+  return b->jit_lean;
+}
+
 int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d_target, int32_t* d_tbs, int32_t* d_uinfo,
            uint32_t* d_keys = nullptr) {
   if (n_ttis < 1) return fail(RS_ERR_INVALID, "n_ttis %d < 1", n_ttis);
@@ -599,28 +620,8 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
     L.b_avg = b->d_bavg; L.b_cumb = b->d_bcum; L.b_cumr = b->d_bcum + n;
     L.q_flags = b->d_qflags; L.q_hol = b->d_qhol;
   }
-  RsJitKernel* k = b->jit;
-  if (k && !b->queues && !b->direct) {
-    /* Long unlogged runs on epoch grids -- what the measurements and any production batch are -- go to the LEAN build of the
-     * shape-specialised kernel: the options this launch does not use are compile-time constants there.  Compiled once, at the
-     * first launch that qualifies (RS_JIT_LEAN_MIN_TTIS, default 256: short test launches are not worth a hiprtc run;
-     * RS_JIT_LEAN=0 switches it off); if hiprtc fails the general kernel stays in use. */
-    const char* const e_min = getenv("RS_JIT_LEAN_MIN_TTIS");
-    const char* const e_on = getenv("RS_JIT_LEAN");
-    const int lean_min = e_min ? atoi(e_min) : 256;
-    const bool lean_on = !e_on || atoi(e_on) != 0;
-    const bool lean_ok = lean_on && n_ttis >= lean_min && L.cqi_mode == RS_CQI_EPOCHS && !L.epochs_prb && !d_map && !d_quota && !d_target &&
-                         !d_tbs && !d_uinfo && !d_keys && !L.phy_draws && !L.synthetic;
-    if (lean_ok) {
-      if (!b->jit_lean_tried) {
-        b->jit_lean_tried = true;
-        char msg[512] = "";
-        b->jit_lean = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, slice_window(b), msg, sizeof msg,
-                                 (b->cfg.cqi_refresh <= 4 ? 2 : 0) | 4);
-      }
-      if (b->jit_lean) k = b->jit_lean;
-    }
-  }
+  RsJitKernel* k = lean_kernel(b, n_ttis, d_map || d_quota || d_target || d_tbs || d_uinfo || d_keys);
+  if (!k) k = b->jit;
   if (k) HIP_TRY(rs_jit_launch(k, &L, b->stream));
   else HIP_TRY(rs_launch_cells(&L, b->threads, b->stream));
   b->ttis_done += n_ttis;
@@ -1085,6 +1086,14 @@ int rs_batch_read_clock(rs_batch* b, double* t, double* last_update) {
     if (t) t[c] = sc[c].t;
     if (last_update) last_update[c] = sc[c].last_update;
   }
+  return RS_OK;
+}
+
+int rs_batch_prepare_launch(rs_batch* b, int32_t n_ttis) {
+  if (!b || n_ttis < 1) return fail(RS_ERR_INVALID, "bad argument");
+  if (b->cqi_mode == RS_CQI_NONE) return fail(RS_ERR_STATE, "no CQI source set");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  (void)lean_kernel(b, n_ttis > RS_MAX_TTIS_PER_LAUNCH ? RS_MAX_TTIS_PER_LAUNCH : n_ttis, false);
   return RS_OK;
 }
 

@@ -239,6 +239,7 @@ def test_lean_build_of_the_batch_kernel(rs, oracle, sched, ues, R, G, refresh, t
     assert b.kernel_name == "rs_cell_kernel_jit"
     b.seed(seeds)
     b.upload_cqi_epochs(grids)
+    b.prepare_launch(37)      # the lean build is compiled here (rs_batch_prepare_launch), not inside the first launch
     b.run(37)                 # lean
     got = b.run_logged(21)    # general (logs)
     for n in (1, 2, 70):      # lean again
