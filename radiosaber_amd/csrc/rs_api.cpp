@@ -567,7 +567,7 @@ int check_device_err(rs_batch* b) {
  * (RS_JIT_LEAN_MIN_TTIS, default 256: short test launches are not worth a hiprtc run; RS_JIT_LEAN=0 switches it off) or by
  * rs_batch_prepare_launch; nullptr = the general kernel (or the built-in ones) serves this launch. */
 RsJitKernel* lean_kernel(rs_batch* b, int n_ttis, bool logged) {
-  if (!b->jit || b->queues || b->direct || logged) return nullptr;
+  if (!b->jit || b->direct || logged) return nullptr;
   const char* const e_min = getenv("RS_JIT_LEAN_MIN_TTIS");
   const char* const e_on = getenv("RS_JIT_LEAN");
   const int lean_min = e_min ? atoi(e_min) : 256;
@@ -576,8 +576,8 @@ RsJitKernel* lean_kernel(rs_batch* b, int n_ttis, bool logged) {
   if (!b->jit_lean_tried) {
     b->jit_lean_tried = true;
     char msg[512] = "";
-    b->jit_lean = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, 0, slice_window(b), msg, sizeof msg,
-                             (b->cfg.cqi_refresh <= 4 ? 2 : 0) | 4);
+    b->jit_lean = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, b->queues ? b->qmode : 0, slice_window(b), msg,
+                             sizeof msg, (b->cfg.cqi_refresh <= 4 ? 2 : 0) | 4);
   }
   return b->jit_lean;
 }
@@ -968,6 +968,8 @@ int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
   carve_lds(b, &b->base); /* schedulers 1 and 7 keep per-bearer scratch in LDS in this mode */
   if (b->jit_wanted) {
     b->jit = qjit; /* nullptr: the built-in queue kernels run, rs_batch_jit_status says why */
+    b->jit_lean = nullptr; /* the lean build belongs to the kernel it is a build of: the queue model's is compiled on demand */
+    b->jit_lean_tried = false;
     snprintf(b->jit_msg, sizeof b->jit_msg, "%s", qmsg);
   }
   return RS_OK;

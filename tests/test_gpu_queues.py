@@ -36,7 +36,7 @@ def _random_bursts(rng, n_ttis, mean_gap_ms, mean_bytes, start_after=0):
 
 
 def _run_case(rs, oracle, sched, ues, slice_kinds, alpha, beta, R, G, n_cells, launches, jit, seed, threads=0,
-              mean_gap_ms=6, mean_bytes=2500, psi=None):
+              mean_gap_ms=6, mean_bytes=2500, psi=None, logged=True):
     S = len(ues)
     sc = rs.SliceConfig(ues, algo_alpha=alpha, algo_beta=beta, algo_psi=psi or [])
     U = sc.n_users
@@ -65,9 +65,14 @@ def _run_case(rs, oracle, sched, ues, slice_kinds, alpha, beta, R, G, n_cells, l
         assert b.jit_status()[0] == 1, b.jit_status()
     b.seed(seeds)
     b.upload_cqi_epochs(grids)
-    got = [b.run_logged(n) for n in launches]
-    maps = np.concatenate([g["rbg_to_user"] for g in got], axis=1)
-    tbs = np.concatenate([g["tbs_bits"] for g in got], axis=1)
+    maps = tbs = None
+    if logged:
+        got = [b.run_logged(n) for n in launches]
+        maps = np.concatenate([g["rbg_to_user"] for g in got], axis=1)
+        tbs = np.concatenate([g["tbs_bits"] for g in got], axis=1)
+    else:  # unlogged launches (the lean build of the kernel when RS_JIT_LEAN_MIN_TTIS allows): final state only
+        for n in launches:
+            b.run(n)
     st, bst = b.state(), b.bearer_state()
     b.close()
     idle_ttis = 0
@@ -79,8 +84,9 @@ def _run_case(rs, oracle, sched, ues, slice_kinds, alpha, beta, R, G, n_cells, l
                 cell.set_arrivals(u, k, t, nf, la)
         logs = cell.run_synth_queues(grids[c], int(seeds[c]), n_ttis)
         ob = cell.bearer_state()
-        np.testing.assert_array_equal(maps[c], logs["rbg_to_user"], err_msg=f"cell {c} RBG map")
-        np.testing.assert_array_equal(tbs[c], logs["tbs_bits"], err_msg=f"cell {c} TBS")
+        if logged:
+            np.testing.assert_array_equal(maps[c], logs["rbg_to_user"], err_msg=f"cell {c} RBG map")
+            np.testing.assert_array_equal(tbs[c], logs["tbs_bits"], err_msg=f"cell {c} TBS")
         for key in ("cum_bytes", "cum_rbs", "queue_bytes", "queue_packets"):
             np.testing.assert_array_equal(bst[key][c], ob[key], err_msg=f"cell {c} {key}")
         live = kinds != rs.BEARER_NONE
@@ -89,6 +95,21 @@ def _run_case(rs, oracle, sched, ues, slice_kinds, alpha, beta, R, G, n_cells, l
         assert (st["cum_bytes"][c] == ob["cum_bytes"].sum(1)).all()
         idle_ttis += int((logs["rbg_to_user"] < 0).all(1).sum())
     return idle_ttis, maps
+
+
+@pytest.mark.parametrize("sched", [9, 8, 7, 1, 103])
+def test_lean_build_of_the_queue_model_kernels(rs, oracle, sched, monkeypatch):
+    """Round 4: unlogged launches of a queue-model batch run the lean build of ITS shape-specialised kernel too (the launch's unused
+    options as constants; RS_JIT_LEAN_MIN_TTIS = 1 here): bearers' counters, queues, averages and slice offsets against the oracle."""
+    monkeypatch.setenv("RS_JIT_LEAN_MIN_TTIS", "1")
+    kinds = ["B-", "Q-", "QQ", "BQ", "Q-", "QQ"]
+    custom = sched in (9, 8, 7, 103)
+    alpha = [0, 1, 1, 1, 0, 1] if custom else [0] * 6
+    beta = [0, 0, 1, 1, 0, 0] if custom else [0] * 6
+    _run_case(rs, oracle, sched, [9, 12, 7, 10, 3, 11], kinds, alpha, beta, 25, 4, n_cells=3, launches=[1, 39, 60, 47], jit=True, seed=77 + sched,
+              logged=False)
+    _run_case(rs, oracle, sched, [20] * 3, ["Q-", "QQ", "B-"], [0, 0, 0], [0, 0, 0], 64, 8, n_cells=2, launches=[120], jit=True, seed=80 + sched,
+              mean_gap_ms=5, mean_bytes=1500, logged=False)
 
 
 @pytest.mark.parametrize("sched", [9, 8])
