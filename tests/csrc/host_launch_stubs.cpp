@@ -6,6 +6,6 @@
 struct RsLaunch;
 extern "C" hipError_t rs_launch_cells(const RsLaunch*, int, hipStream_t) { return hipErrorNotSupported; }
 extern "C" hipError_t rs_prepare_kernels(int) { return hipErrorNotSupported; }
-extern "C" hipError_t rs_launch_synth(uint8_t*, int64_t, int, int, int, int, uint64_t, int64_t, const uint32_t*, hipStream_t) { return hipErrorNotSupported; }
+extern "C" hipError_t rs_launch_synth(uint8_t*, int64_t, int, int, int, int, int, uint64_t, int64_t, const uint32_t*, hipStream_t) { return hipErrorNotSupported; }
 extern "C" hipError_t rs_launch_copy_probe(const void*, void*, size_t, hipStream_t) { return hipErrorNotSupported; }
 extern "C" hipError_t rs_launch_slice_bytes(const int64_t*, const uint8_t*, int, int, int, unsigned long long*, hipStream_t) { return hipErrorNotSupported; }

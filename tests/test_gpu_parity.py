@@ -534,6 +534,10 @@ def test_nvs_nongreedy_sampler_on_the_device(rs, oracle):
     _check_batch(rs, oracle, 11, [3, 7, 0, 1, 12], 33, 3, n_cells=2, n_ttis=45)          # ragged, one empty slice
     _check_batch(rs, oracle, 11, [70, 300], 25, 4, n_cells=1, n_ttis=42, jit=True)       # a batch holds 27 samples of 300 UEs
     _check_batch(rs, oracle, 11, [30] * 4, 25, 4, n_cells=2, n_ttis=45, jit=True, threads=256)
+    # round 4: slices of up to 64 users compare 16-bit keys (ranked metrics) instead of doubles -- 64 users exactly, a 200-user slice
+    # on doubles in the same cell, every user starting from one average (whole classes of equal metrics share a rank)
+    _check_batch(rs, oracle, 11, [64, 40, 200], 12, 2, n_cells=2, n_ttis=60, jit=True)
+    _check_batch(rs, oracle, 11, [64, 40, 200], 12, 2, n_cells=1, n_ttis=40)
 
 
 def test_nvs_nongreedy_drop_in(rs, oracle):
