@@ -30,7 +30,7 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes);
 struct RsJitKernel;
 extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, int qmode, int win, char* err, size_t errlen,
-                                   int direct);
+                                   int flags); /* bit 0: drop-in (one-TTI) kernel, bit 1: streamed batch (cqi_refresh <= 4), bit 2: lean build */
 extern "C" int rs_jit_is_untuned(const RsJitKernel* k);
 extern "C" hipError_t rs_jit_launch(RsJitKernel* k, const RsLaunch* p, hipStream_t stream);
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R, int Upad,
