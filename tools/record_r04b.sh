@@ -5,5 +5,6 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R
 python -m pytest tests -m gpu -q > $O/r04_gputests.log 2>&1; echo "pytest rc $?" >> $O/r04_gputests.log; tail -2 $O/r04_gputests.log
 bash tools/profile_queue_mode.sh r04q > $O/prof_queue.log 2>&1
 cd $R
+python3 -c "import __graft_entry__ as g; g.smoke()" > $O/r04_smoke.log 2>&1; tail -1 $O/r04_smoke.log
 python3 bench.py > $O/r04_bench_default.log 2> $O/r04_bench_default.err
 cut -c1-200 $O/r04_bench_default.log
