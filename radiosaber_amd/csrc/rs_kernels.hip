@@ -5,7 +5,8 @@
  * CQI grid u8[R][Upad], PF averages f64[U], the CQI->rate / EESM / TBS tables, slice quotas) and runs
  * n_ttis complete DoSchedule() iterations back to back:
  *
- *   P0  CQI refresh (every 40 TTIs)        HBM -> LDS, 16 B per lane, transposed on the way in
+ *   P0  CQI refresh (every 40 TTIs)        HBM -> LDS, a straight 16-byte copy per lane (the device-resident grids are stored as
+ *                                          the LDS image; the drop-in entry point transposes the caller's [U][R] block)
  *   P1  PF EWMA update per user            ref: src/flows/radio-bearer.cpp:139-164
  *   P2  slice quotas (one wave, lanes = slices, beside P3)   ref: downlink-transport-scheduler.cpp:463-521
  *   P3  best user per (RBG, slice)         ref: :530-567   exact two-stage arg-max: FP32 ranking of 8 users
@@ -31,8 +32,9 @@
  * EPT = sort positions per thread (0: state in LDS, any size), FIXED = shape-specialised build, DIRECT = the drop-in
  * entry point's one-TTI form on caller-provided state.  Wave-level building blocks live in rs_wave.h.
  *
- * The same source is compiled twice: into the library with the cell shape as launch arguments, and at
- * run time (hiprtc, rs_jit.cpp) with the shape as compile-time constants (RS_JIT_*).
+ * The same source is compiled three ways: into the library with the cell shape as launch arguments; at run time (hiprtc,
+ * rs_jit.cpp) with the shape as compile-time constants (RS_JIT_*); and as the LEAN build of that kernel (RS_JIT_LEAN), in which the
+ * launch's unused run-time options are constants too (rs_cell_kernel_jit below).
  *
  * No MFMA: the only matrix-shaped object (metric[R][U]) is consumed by an argmax.  All floating
  * point is IEEE FP64 add/mul/div in the reference's operation order; the file MUST be compiled with
