@@ -137,15 +137,21 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
   c.lds_bytes = off;
   return c;
 }
+#ifndef RS_NVS_WHOLE_SLICE
+#define RS_NVS_WHOLE_SLICE 64 /* sched 7: up to this many users per slice on average the slice is scanned whole -- the shape-specialised
+                                * kernels scan it four lanes per item during the previous TTI's serial phase (kQuad7, windows of up to 64 users):
+                                * 1 000 UEs in 20 slices 215.1 against 179.9 M TTIs/s with split runs, 106.4 against 85.3 at 64 RBGs; the built-in
+                                * kernels, which have no such scan, lose 6 % there (88.9 against 94.2; tools/r04_run45.sh) */
+#endif
 constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads, int queue = 0) {
   if (queue) return rs_carve_with(S, U, R, sched, threads, 0, queue); /* (sched 7 with queues: no split runs, no metric scan) */
-  if (sched == 7 && U > 32 * S) { /* slices of more than 32 users on average: one run per work item is too long */
+  if (sched == 7 && U > RS_NVS_WHOLE_SLICE * S) { /* slices of more users than that on average: one run per work item is too long */
     for (int seg = 8; seg <= 16; seg *= 2) {
       const RsCarve c = rs_carve_with(S, U, R, sched, threads, seg);
       if (c.lds_bytes <= 80 * 1024) return c;
     }
   }
-  if (sched == 7 && U > 32 * S) return rs_carve_with(S, U, R, sched, threads, 32);
+  if (sched == 7 && U > RS_NVS_WHOLE_SLICE * S) return rs_carve_with(S, U, R, sched, threads, 32);
   if (sched == 11) {
     /* the sampler's batch (carried in nvs_seg, which scheduler 7 alone reads as a run length): 64 samples -- half the barriers,
      * fuller scan rounds: 15.3 against 13.0 M TTIs/s at 500 UEs x 25 RBGs -- unless that is what takes the cell over 80 KB (two

@@ -550,8 +550,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
      * to scan again.  The top of the next TTI is then one pass over those lists.
      * Same-box A/B (512 cells, 25 RBGs): GreedyByRow 94.8 against 93.4 M TTIs/s (its TTI is short: the top of the TTI is a large
      * share), MaximizeCell 32.86 against 33.16 -- the waves that work beside wave 0 slow its greedy scan and link adaptation by
-     * what the shorter top saves, as round 2 found for its speculation -- so: GreedyByRow only. */
-    const bool ewma_next = quota_next && SCHED == 8;
+     * what the shorter top saves, as round 2 found for its speculation -- so: GreedyByRow, and MaximizeCell from two users per thread on. */
+    /* (MaximizeCell re-measured on the lean build, tools/r04_run44.sh: 34.45 against 34.64 M at one user per thread, 31.9 against 31.0 at two:
+     * from two users per thread on the shorter top of the TTI outweighs what the busy waves cost wave 0) */
+    const bool ewma_next = quota_next && (SCHED == 8 || (SCHED == 9 && FIXED && RS_JIT_U > RS_JIT_NT));
     /* ... and pack their lists for TTI t+1 (a one-chunk shape: at most 64 items per wave).  Packing them for MaximizeCell too,
      * without the early EWMA, was measured in round 4: 33.34 against 33.38 M TTIs/s -- the top of its TTI does not wait for it. */
     const bool prelist_next = kHoldSched && ewma_next && hold_ok && n_items_rt <= 64 * nwaves;
