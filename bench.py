@@ -435,7 +435,8 @@ def main():
             # unlogged launches of >= RS_JIT_LEAN_MIN_TTIS (256) TTIs on epoch grids run the LEAN build of that kernel: the launch's unused
             # run-time options (trace rows, per-PRB twins, decision log, error-model draws) compiled out, results identical
             "kernel_build": ("lean" if (want_jit and os.environ.get("RS_JIT_LEAN", "1") != "0"
-                                        and args.ttis >= int(os.environ.get("RS_JIT_LEAN_MIN_TTIS", "256"))) else "general"),
+                                        and args.ttis >= int(os.environ.get("RS_JIT_LEAN_MIN_TTIS", "256"))
+                                        and "lean build unavailable" not in batch.jit_status()[1]) else "general"),
             # who reduced: the process-group backend ("nccl" IS RCCL on ROCm), the ranks it saw, the library version
             "backend": backend if world > 1 else None, "ranks_in_group": ranks_in_group,
             "rccl_version": _rccl_version(torch) if (world > 1 and backend == "nccl") else None,

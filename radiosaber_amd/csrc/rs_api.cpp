@@ -578,6 +578,8 @@ RsJitKernel* lean_kernel(rs_batch* b, int n_ttis, bool logged) {
     char msg[512] = "";
     b->jit_lean = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, b->queues ? b->qmode : 0, slice_window(b), msg,
                              sizeof msg, (b->cfg.cqi_refresh <= 4 ? 2 : 0) | 4);
+    /* not an error of the launch -- the general build serves it -- but nothing silent either: rs_batch_jit_status carries the reason */
+    if (!b->jit_lean) snprintf(b->jit_msg, sizeof b->jit_msg, "lean build unavailable, the general build serves every launch (%.400s)", msg);
   }
   return b->jit_lean;
 }
