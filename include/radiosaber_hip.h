@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 9 /* 9: rs_create_checked / rs_batch_create_checked (RS_CREATE / RS_BATCH_CREATE: the caller's ABI version and struct size are
+#define RS_ABI_VERSION 10 /* 10: rs_batch_debug_heap_sorts / rs_ctx_debug_heap_sorts (the sort emulation's heap-sort fallback counted per device site);
+                            9: rs_create_checked / rs_batch_create_checked (RS_CREATE / RS_BATCH_CREATE: the caller's ABI version and struct size are
                             checked), rs_batch_config.cqi_epoch_wrap / queue_state_lds, threads_per_cell up to 1024 with jit, rs_jit_selfcheck_untuned, rs_batch_write_state, rs_ctx_specialize, rs_jit_selfcheck_dropin;
                             8: rs_jit_selfcheck_queue, rs_config.synthetic_exp, any integer algo_epsilon / algo_psi in drop-in contexts; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
                             6: rs_tti_in.required_rbs / data_to_transmit (the gates of schedulers 7 and 1 in the drop-in mode);
@@ -414,6 +415,14 @@ int rs_jit_selfcheck_queue(int n_slices, int n_users, int n_rbgs, int rbg_size, 
 /* 16 hex digits: FNV-1a hash of the device sources this library was built from (and compiles at run time); measurement
  * records under profiles/ carry it so that a record taken on other kernel code can be told apart (bench.py: "stale") */
 const char* rs_device_source_hash(void);
+/* diagnostics: how often the std::sort emulation (MaximizeCell, UpperBound) took libstdc++'s heap-sort fallback -- std::__partial_sort,
+ * when std::__introsort_loop's depth limit 2 * floor(log2 n) runs out on a range longer than 16 (bits/stl_algo.h:1937-1957; the
+ * reference's call: downlink-transport-scheduler.cpp:354-361) -- since the batch / context was created, per device site:
+ * [0] workgroup level of the register form, [1] inside a single wave's finish of the last levels, [2] workgroup level of the LDS
+ * form (more than four sort records per thread).  Random CQI grids never get there; tests/golden/sort_killers.npz holds grids that
+ * do.  out = [n_cells][3] / [3].  (ABI 10) */
+int rs_batch_debug_heap_sorts(rs_batch* b, int64_t* out);
+int rs_ctx_debug_heap_sorts(rs_ctx* ctx, int64_t* out);
 /* diagnostics: cycles per kernel phase of one cell's first thread, summed over the last launch;
  * only in the separate -DRS_STAMPS build (RS_ERR_STATE in the product library) */
 int rs_batch_debug_stamps(rs_batch* b, int32_t cell, uint64_t* out20);

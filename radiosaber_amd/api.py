@@ -52,7 +52,7 @@ class _BatchConfig(C.Structure):
                 ("cqi_epoch_wrap", C.c_int32), ("queue_state_lds", C.c_int32)]
 
 
-RS_ABI_VERSION = 9  # the include/radiosaber_hip.h these ctypes structs mirror; passed to the *_checked create functions
+RS_ABI_VERSION = 10  # the include/radiosaber_hip.h these ctypes structs mirror; passed to the *_checked create functions
 
 
 class _TtiIn(C.Structure):
@@ -95,6 +95,7 @@ ABI_SYMBOLS = [
     "rs_device_source_hash",
     "rs_create_checked", "rs_batch_create_checked", "rs_jit_selfcheck_untuned", "rs_batch_write_state",
     "rs_ctx_specialize", "rs_jit_selfcheck_dropin",
+    "rs_batch_debug_heap_sorts", "rs_ctx_debug_heap_sorts",
 ]
 
 _lib = None
@@ -163,6 +164,8 @@ def lib():
     L.rs_jit_selfcheck.argtypes = [C.c_int] * 6 + [C.c_char_p, C.c_size_t]
     L.rs_jit_selfcheck_queue.argtypes = [C.c_int] * 6 + [C.c_char_p, C.c_size_t]
     L.rs_batch_debug_stamps.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]
+    L.rs_batch_debug_heap_sorts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.rs_ctx_debug_heap_sorts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.rs_batch_ttis_done.restype = C.c_int64
     L.rs_batch_ttis_done.argtypes = [C.c_void_p]
     L.rs_batch_stream.restype = C.c_void_p
@@ -474,6 +477,12 @@ class TtiScheduler:
         _check(lib().rs_schedule_tti(self._h, C.byref(tin), C.byref(tout)))
         return res
 
+    def heap_sorts(self):
+        """int64[3]: heap-sort fallbacks of the std::sort emulation so far, per device site (rs_ctx_debug_heap_sorts)."""
+        out = np.zeros(3, np.int64)
+        _check(lib().rs_ctx_debug_heap_sorts(self._h, _p(out, C.c_int64)))
+        return out
+
     @property
     def slice_offset(self):
         out = np.zeros(self.slices.n_slices, np.float64)
@@ -667,6 +676,13 @@ class BatchScheduler:
     def slice_bytes_into(self, device_ptr):
         """Reduce per-slice cumulative bytes into a device buffer (uint64[S]) on the batch's stream."""
         _check(lib().rs_batch_slice_bytes_device(self._h, C.c_void_p(device_ptr)))
+
+    def heap_sorts(self):
+        """int64[n_cells][3]: heap-sort fallbacks of the std::sort emulation so far, per cell and device site
+        (0 workgroup level of the register form, 1 inside one wave's finish, 2 workgroup level of the LDS form)."""
+        out = np.zeros((self.n_cells, 3), np.int64)
+        _check(lib().rs_batch_debug_heap_sorts(self._h, _p(out, C.c_int64)))
+        return out
 
     def debug_stamps(self, cell=0):
         out = np.zeros(20, np.uint64)

@@ -1093,6 +1093,17 @@ int rs_batch_read_clock(rs_batch* b, double* t, double* last_update) {
   return RS_OK;
 }
 
+int rs_batch_debug_heap_sorts(rs_batch* b, int64_t* out) {
+  if (!b || !out) return fail(RS_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  std::vector<RsCellScalars> sc(b->n_cells);
+  HIP_TRY(hipMemcpy(sc.data(), b->d_scal, sizeof(RsCellScalars) * b->n_cells, hipMemcpyDeviceToHost));
+  for (int c = 0; c < b->n_cells; c++)
+    for (int k = 0; k < 3; k++) out[c * 3 + k] = sc[c].heap_sorts[k];
+  return RS_OK;
+}
+
 int rs_batch_prepare_launch(rs_batch* b, int32_t n_ttis) {
   if (!b || n_ttis < 1) return fail(RS_ERR_INVALID, "bad argument");
   if (b->cqi_mode == RS_CQI_NONE) return fail(RS_ERR_STATE, "no CQI source set");
@@ -1213,6 +1224,11 @@ CtxLayout ctx_layout(int n, int R, int S, int G, bool with_draws) {
 }  // namespace
 
 extern "C" {
+
+int rs_ctx_debug_heap_sorts(rs_ctx* ctx, int64_t* out) {
+  if (!ctx || !ctx->b) return fail(RS_ERR_INVALID, "null context");
+  return rs_batch_debug_heap_sorts(ctx->b, out);
+}
 
 rs_ctx* rs_create_checked(const rs_config* cfg, int abi_version, size_t cfg_size) {
   if (abi_version != RS_ABI_VERSION || cfg_size != sizeof(rs_config)) {

@@ -58,7 +58,7 @@ struct RsMisc {
   int32_t rcp_off[64];           /* per slice: window start in the reciprocal array minus the slice's 8-aligned first user */
   RsSpecFlags spec[2];           /* by TTI parity */
   int32_t grid_free;             /* TTIs of this launch whose serial wave is done reading the CQI grid (the next grid may be written over it) */
-  int32_t pad2[3];
+  int32_t heap_sorts[3];         /* diagnostics: std::__partial_sort fallbacks of this launch, per device site (rs_sort_device.h) */
 };
 
 /* LDS carve of one cell (byte offsets from the dynamic LDS base), a pure function of the cell shape so
@@ -191,6 +191,7 @@ struct RsCellScalars {
   uint32_t rng_r[32];  /* glibc TYPE_3 ring (31 words used)                            */
   int32_t cqi_row;     /* trace row of the last CQI report (reloaded when a launch starts between reports) */
   int32_t pad_;
+  int64_t heap_sorts[3]; /* diagnostics: heap-sort fallbacks of the sort emulation so far, per device site (rs_batch_debug_heap_sorts) */
 };
 
 enum { RS_CQI_NONE = 0, RS_CQI_EPOCHS = 1, RS_CQI_TRACE = 2 };

@@ -375,6 +375,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   }
   if (tid < 2) { m->spec[tid].ctr_p1 = 0; m->spec[tid].ctr_p3 = 0; m->spec[tid].greedy_done = 0; m->spec[tid].n_fix = 0; }
   if (tid == 0) m->grid_free = 0;
+  if ((SCHED == 9 || SCHED == 10) && tid < 3) m->heap_sorts[tid] = 0;
   if (tid < S) {
     /* bit 0 = algo_epsilon, bit 1 = algo_psi, bit 2 = algo_alpha, bit 3 = algo_beta */
     m->eps_psi[tid] = (uint8_t)((p.eps[tid] ? 1 : 0) | (p.psi[tid] ? 2 : 0) | ((p.alpha && p.alpha[tid]) ? 4 : 0) | ((p.beta && p.beta[tid]) ? 8 : 0));
@@ -664,6 +665,11 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     scal->served_prev = served_prev;
     scal->n_done = n_done;
     if (local_err) atomicExch(p.err, local_err);
+    if constexpr (SCHED == 9 || SCHED == 10) { /* diagnostics: the sort emulation's heap-sort fallbacks (rs_sort_device.h), normally none */
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (m->heap_sorts[k] != 0) scal->heap_sorts[k] += m->heap_sorts[k];
+    }
 #ifdef RS_STAMPS
     if (p.stamps) {
       for (int i = 0; i < 12; ++i) p.stamps[(size_t)cell * 20 + i] = stamp_acc[i];

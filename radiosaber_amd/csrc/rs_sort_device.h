@@ -28,6 +28,31 @@ namespace {
  *      most 16 elements retire
  * Four workgroup barriers per level, no queue, cost independent of the number of sub-ranges.
  */
+/*
+ * std::__partial_sort (the heap-sort fallback of std::__introsort_loop when the depth limit runs out) is a serial walk.  It runs
+ * on EVERY lane of the wave that owns the sub-range, on wave-uniform operands: the bounds and each element read are scalar values
+ * (v_readfirstlane of a same-address LDS read), so the walk is scalar control flow, and every lane stores the same word to the
+ * same address.  No divergent single-lane region: round 4 met a long one (SubOpt's hashtable walk under `if (lane == 0)`) that
+ * went wrong once the kernel's spill pattern changed (profiles/r05_onelane.md).  RsMisc::heap_sorts counts the calls per site
+ * (0 workgroup level of the register form, 1 inside finish_subranges_on_wave, 2 workgroup level of the LDS form) so that a test
+ * can tell the branch ran (rs_batch_debug_heap_sorts).
+ */
+struct UniLdsRef {
+  uint32_t* p;
+  __device__ __forceinline__ operator uint32_t() const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)*p); }
+  __device__ __forceinline__ UniLdsRef& operator=(uint32_t x) { *p = x; return *this; }
+  __device__ __forceinline__ UniLdsRef& operator=(const UniLdsRef& o) { *p = (uint32_t)__builtin_amdgcn_readfirstlane((int)*o.p); return *this; }
+};
+struct UniLdsArr {
+  uint32_t* p;
+  __device__ __forceinline__ UniLdsRef operator[](int i) const { return UniLdsRef{p + i}; }
+};
+__device__ __forceinline__ void heap_sort_on_wave(uint32_t* v, int first, int last, Misc* m, int site) {
+  UniLdsArr a{v};
+  rs_sort::heap_sort(a, __builtin_amdgcn_readfirstlane(first), __builtin_amdgcn_readfirstlane(last));
+  if (lane_id() == 0) atomicAdd(&m->heap_sorts[site], 1);
+}
+
 __device__ __forceinline__ int count_bits_in(const unsigned long long* masks, int lo, int hi) {
   /* number of set mask bits at positions [lo, hi) */
   if (hi <= lo) return 0;
@@ -54,23 +79,34 @@ __device__ void introsort_loop_levels(uint32_t* v, int N, uint16_t* posA, uint16
     segL[x] = (uint16_t)(N > 16 ? N : 0);
   }
   if (tid < 48) m->n_level[tid] = (tid == 0 && N > 16) ? 1 : 0;
+  if (tid == 0) m->pad[0] = 0; /* entries in the list of sub-ranges to heap-sort */
   int depth = 2 * rs_sort::floor_log2(N > 1 ? N : 1);
   for (int level = 0; level < 47; ++level, --depth) {
     /* M */
+    uint32_t* const heap_list = (uint32_t*)posA; /* depth 0: first | last << 16 of the sub-ranges still alive (posA is free here) */
     for (int x = tid; x < N; x += nt) {
       const int L = segL[x];
       if (L != 0 && segF[x] == x) {
-        LdsArr a{v};
         if (depth == 0) {
-          rs_sort::heap_sort(a, x, L);
+          heap_list[atomicAdd(&m->pad[0], 1)] = (uint32_t)x | ((uint32_t)L << 16);
         } else {
+          LdsArr a{v};
           rs_sort::median_to_first(a, x, x + 1, x + (L - x) / 2, L - 1);
           pkbuf[x] = (uint16_t)(v[x] >> 16);
         }
       }
     }
     __syncthreads();
-    if (m->n_level[level] == 0 || depth == 0) break;
+    if (depth == 0) { /* std::__partial_sort fallback: the waves take the listed sub-ranges in turn (heap_sort_on_wave) */
+      const int n_list = m->pad[0];
+      for (int j = wave; j < n_list; j += nwaves) {
+        const uint32_t ent = heap_list[j];
+        heap_sort_on_wave(v, (int)(ent & 0xffffu), (int)(ent >> 16), m, 2);
+      }
+      __syncthreads();
+      break;
+    }
+    if (m->n_level[level] == 0) break;
     /* F */
     for (int c = wave; c < n_chunks; c += nwaves) {
       const int x = (c << 6) + lane;
@@ -192,7 +228,7 @@ __device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
  * when it runs out).  Used for the last, sparsely populated levels: at 500 records they hold 9 / 4 / 2 / 1 sub-ranges of
  * 20-30 elements on average.
  */
-__device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* xbuf, int fb, int lb, int l0, int depth) {
+__device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* xbuf, int fb, int lb, int l0, int depth, Misc* m) {
   const int lane = lane_id();
   const bool mine = l0 != 0;
   const int x = fb + lane - lb, shift = lb - fb; /* lane = position + shift */
@@ -201,13 +237,15 @@ __device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* 
   int F = fb, L = l0; /* my piece; L == 0: retired */
   while (__ballot(L != 0) != 0ull) {
     const bool active = L != 0;
-    if (depth == 0) { /* std::__partial_sort fallback */
+    if (depth == 0) { /* std::__partial_sort fallback: one piece after the other, each on every lane (heap_sort_on_wave) */
       if (mine) v[x] = e;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (active && x == F) {
-        LdsArr a{v};
-        rs_sort::heap_sort(a, F, L);
+      unsigned long long lead = __ballot(active && x == F);
+      while (lead != 0ull) {
+        const int j = __ffsll((long long)lead) - 1;
+        lead &= lead - 1ull;
+        heap_sort_on_wave(v, __builtin_amdgcn_readlane(F, j), __builtin_amdgcn_readlane(L, j), m, 1);
       }
       return;
     }
@@ -328,7 +366,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
           used += l - f;
           ++t;
         } while (t < n_mine);
-        finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth);
+        finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth, m);
       }
       } else {
       /* Every wave reads the whole list (at most kFinishMax * nwaves <= 32 entries, lane j = entry j), ranks the entries
@@ -363,21 +401,32 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
           used += l - f;
           mine &= ~(1ull << j);
         }
-        finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth);
+        finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth, m);
       }
       }
       __syncthreads();
       break;
     }
     if (depth == 0) {
-      /* std::__partial_sort fallback for every sub-range still longer than 16 */
+      /* std::__partial_sort fallback for every sub-range still longer than 16: their first positions publish them (the list of
+       * the hand-off above; `v` is current, every level writes what it moves), the waves take them in turn (heap_sort_on_wave) */
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
         const int x = i * nt + tid;
-        if (L[i] != 0 && F[i] == x) {
-          LdsArr a{v};
-          rs_sort::heap_sort(a, x, L[i]);
+        const bool leader = L[i] != 0 && x == F[i];
+        const unsigned long long mL = __ballot(leader);
+        if (mL != 0ull) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&m->pad[0], __popcll(mL));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (leader) cuts[base + __popcll(mL & lt_lane)] = F[i] | (L[i] << 16);
         }
+      }
+      __syncthreads();
+      const int n_list = n_alive & 0xffff;
+      for (int j = wave; j < n_list; j += nwaves) {
+        const int ent = cuts[j];
+        heap_sort_on_wave(v, ent & 0xffff, ent >> 16, m, 0);
       }
       __syncthreads();
       break;

@@ -1,0 +1,245 @@
+"""tests/golden/sort_killers.npz: key arrays that take libstdc++'s std::sort -- the reference's MaximizeCell / UpperBound sort
+(downlink-transport-scheduler.cpp:223-246, 351-376) -- into its heap-sort fallback (std::__partial_sort, bits/stl_algo.h:1937-1957).
+
+CPU side: every array still does that, the product's emulation (rs_sort_emul.h) leaves std::sort's permutation on it, the site
+it reaches in the device's level-synchronous loop is the recorded one, and the oracle's MaximizeCell on it equals the reference's
+own (oracle/_ref/libref_tp_algos.so).  GPU side (-m gpu): the same arrays as CQI grids with one UE per slice, every device site,
+against the oracle -- with the device's own counter saying that the fallback ran."""
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def killers():
+    d = np.load(GOLDEN / "sort_killers.npz")
+    meta = json.loads(bytes(d["meta"]).decode())
+    return {k: d[k] for k in meta}, meta
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("sk") / "sort_killer"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe), str(ROOT / "tools" / "sort_killer.cpp")], check=True)
+
+    def check(keys, waves=8, ept=0):
+        r = subprocess.run([str(exe), "check", str(waves), str(ept)], input=" ".join(str(int(k)) for k in keys), capture_output=True,
+                           text=True, check=True)
+        site, calls, longest, same = r.stdout.split()
+        return site, int(calls), int(longest), int(same)
+    return check
+
+
+def test_every_array_reaches_the_heap_sort_and_the_emulation_follows_std_sort(checker):
+    arrays, meta = killers()
+    sites = set()
+    for name, keys in arrays.items():
+        site, calls, longest, same = checker(keys)
+        assert calls == meta[name]["heap_calls"] > 0 and longest > 16, name
+        assert same == 1, f"{name}: emulation and std::sort disagree"
+        assert site == meta[name]["site_512_threads"], name
+        sites.add((len(keys) > 64, site))
+    # both register-form sites at both MaximizeCell sizes; the per-slice arrays (UpperBound) are finished on single waves
+    assert {(True, "wg"), (True, "wave")} <= sites
+    # 128 threads (two waves): 500 records keep four positions per thread; 1 280 records use the LDS form, which always falls
+    # back at workgroup level (its counter is [2])
+    for name in ("n500_wg", "n500_wave"):
+        assert checker(arrays[name], waves=2, ept=4)[1] > 0
+
+
+def test_uniform_and_random_arrays_do_not(checker):
+    rng = np.random.default_rng(5)
+    for n in (500, 1280, 64):
+        assert checker(np.full(n, 7))[1] == 0
+        assert checker(rng.integers(1, 16, n))[1] == 0
+
+
+@pytest.mark.parametrize("name,R,S", [("n500_wg", 25, 20), ("n500_wg_long", 25, 20), ("n500_wave", 25, 20), ("n500_climb", 25, 20),
+                                      ("n1280_wg", 64, 20), ("n1280_wave", 64, 20)])
+def test_oracle_maximize_cell_matches_reference_on_killer_arrays(oracle, name, R, S):
+    """The oracle's MaximizeCell (real std::sort) against the reference's own unit code on grids whose sort heap-sorts."""
+    L = oracle.ref_lib("libref_tp_algos.so")
+    if L is None:
+        pytest.skip("oracle/_ref/libref_tp_algos.so not built (needs /root/reference)")
+    from test_oracle_pins import KA, ref_maximize_cell
+    arrays, _ = killers()
+    keys = np.ascontiguousarray(arrays[name].reshape(R, S), np.int32)
+    eff = np.array([0.0] + KA["eff_of_cqi"])[keys]
+    rng = np.random.default_rng(1)
+    for it in range(6):
+        quota = rng.multinomial(R, np.ones(S) / S).astype(np.int32)
+        if it == 0:
+            quota[:] = [R // S + (1 if s < R % S else 0) for s in range(S)]
+        want = ref_maximize_cell(L, keys, quota)
+        got = oracle.interslice("maximize_cell", eff, quota)
+        assert (got == want).all(), (name, it)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# GPU: the arrays as CQI grids, one UE per slice
+
+HIST = (152600, 56656, 270880, 2088792, 3509504, 1595568, 4145392, 5295816, 1903424,
+        6890232, 4770864, 2842552, 3579624, 96000, 1227696)
+
+
+def _grid_maxcell(keys, R, S):
+    """MaximizeCell's array index is rbg * S + slice; with one UE per slice grid[u][r] = keys[r * S + u]."""
+    return np.ascontiguousarray(keys.reshape(R, S).T, np.uint8)
+
+
+def _run_batch(rs, oracle, sched, grids, R, G, threads, jit, n_ttis, lean=False):
+    """grids [n_cells][n_epochs][U][R], one UE per slice; returns the heap-sort counters [n_cells][3] after full parity."""
+    n_cells, n_epochs, U, _ = grids.shape
+    ues = [1] * U
+    sc = rs.SliceConfig(ues)
+    seeds = np.arange(n_cells, dtype=np.uint32) * 31 + 7
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, threads_per_cell=threads, jit=jit)
+    if jit:
+        assert b.kernel_name == "rs_cell_kernel_jit", b.jit_status()
+    b.seed(seeds)
+    b.upload_cqi_epochs(grids)
+    if lean:
+        b.prepare_launch(n_ttis)
+        b.run(n_ttis)
+        got = None
+    else:
+        got = b.run_logged(n_ttis)
+    st, hs = b.state(), b.heap_sorts()
+    b.close()
+    for c in range(n_cells):
+        cell = oracle.Cell(ues, R, G, sched)
+        logs = cell.run_synth(grids[c], int(seeds[c]), n_ttis, log=not lean)
+        ost = cell.state()
+        if got is not None:
+            np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"], err_msg=f"cell {c} RBG map")
+            np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"], err_msg=f"cell {c} TBS")
+        np.testing.assert_array_equal(st["cum_bytes"][c], ost["cum_bytes"])
+        np.testing.assert_array_equal(st["cum_rbs"][c], ost["cum_rbs"])
+        assert st["avg_rate"][c].tobytes() == ost["avg_rate"].tobytes(), f"cell {c} PF averages differ"
+        assert st["slice_state"][c].tobytes() == ost["slice_state"].tobytes(), f"cell {c} slice state differs"
+    return hs
+
+
+MAXCELL_CASES = [  # name, R, G, S, threads, counter that must move (0 wg / register form, 1 single wave, 2 wg / LDS form)
+    ("n500_wg", 25, 4, 20, 0, 0), ("n500_wg_long", 25, 4, 20, 0, 0), ("n500_wave", 25, 4, 20, 0, 1), ("n500_climb", 25, 4, 20, 0, 1),
+    ("n1280_wg", 64, 8, 20, 0, 0), ("n1280_wave", 64, 8, 20, 0, 1),
+    ("n500_wg", 25, 4, 20, 128, None), ("n500_wave", 25, 4, 20, 128, None),
+    ("n1280_wg", 64, 8, 20, 128, 2), ("n1280_wave", 64, 8, 20, 128, 2),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jit", [False, True])
+@pytest.mark.parametrize("name,R,G,S,threads,site", MAXCELL_CASES)
+def test_maximize_cell_heap_sort_fallback_on_the_device(rs, oracle, name, R, G, S, threads, site, jit):
+    """Batches whose every TTI sorts a killer array (epoch 0 and 2; epoch 1 is a random grid), a second cell with the epochs the
+    other way round: RBG map, TBS, counters, PF and slice state against the oracle (which calls the real std::sort), and the
+    device's own count of heap-sort fallbacks at the expected site."""
+    arrays, _ = killers()
+    k = _grid_maxcell(arrays[name], R, S)
+    rnd = np.random.default_rng(3).choice(np.arange(1, 16, dtype=np.uint8), size=(S, R), p=np.asarray(HIST) / np.sum(HIST)).astype(np.uint8)
+    grids = np.stack([np.stack([k, rnd, k]), np.stack([rnd, k, rnd])])
+    n_ttis = 100
+    hs = _run_batch(rs, oracle, 9, grids, R, G, threads, jit, n_ttis)
+    assert hs.sum() > 0, "the heap-sort fallback never ran"
+    # cell 0 sorts the killer in epochs 0 and 2 (60 TTIs), cell 1 in epoch 1 (40 TTIs): at least one fallback per such TTI
+    assert hs[0].sum() >= 60 and hs[1].sum() >= 40, hs
+    if site is not None:
+        assert hs[0, site] >= 60 and hs[1, site] >= 40, (site, hs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,R,G,S", [("n500_wg", 25, 4, 20), ("n1280_wave", 64, 8, 20)])
+def test_heap_sort_fallback_in_the_lean_build(rs, oracle, name, R, G, S):
+    """The long unlogged launch (the lean build of the shape-specialised kernel, what bench.py times) on the same grids."""
+    arrays, _ = killers()
+    k = _grid_maxcell(arrays[name], R, S)
+    grids = np.stack([np.stack([k] * 8)] * 2)
+    hs = _run_batch(rs, oracle, 9, grids, R, G, 0, True, 300, lean=True)
+    assert (hs.sum(axis=1) >= 300).all(), hs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jit", [False, True])
+@pytest.mark.parametrize("name,R,G,S,site", [("n64_seg", 64, 8, 20, 1), ("n64_seg_b", 64, 8, 32, 1), ("n48_seg", 48, 4, 20, 1),
+                                             ("n40_seg", 40, 4, 40, 0)])
+def test_upper_bound_heap_sort_fallback_on_the_device(rs, oracle, name, R, G, S, site, jit):
+    """UpperBound sorts each slice's R RBGs by itself: every slice gets the killer (40 slices x 40 RBGs keep more sub-ranges
+    alive than the single waves take, so the fallback comes at workgroup level, 40 heap sorts side by side), or every second
+    slice a random row."""
+    arrays, _ = killers()
+    k = arrays[name]
+    rng = np.random.default_rng(9)
+    rnd = rng.choice(np.arange(1, 16, dtype=np.uint8), size=(S, R), p=np.asarray(HIST) / np.sum(HIST)).astype(np.uint8)
+    all_k = np.tile(k, (S, 1)).astype(np.uint8)
+    mixed = all_k.copy()
+    if site == 1:
+        mixed[1::2] = rnd[1::2]
+    grids = np.stack([np.stack([all_k, mixed])])
+    hs = _run_batch(rs, oracle, 10, grids, R, G, 0, jit, 80)
+    assert hs[0, site] >= 80, hs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jit", [False, True])
+@pytest.mark.parametrize("sched,name,R,G,S", [(9, "n500_wg", 25, 4, 20), (9, "n500_wave", 25, 4, 20), (9, "n1280_wg", 64, 8, 20),
+                                              (9, "n1280_wave", 64, 8, 20), (10, "n64_seg", 64, 8, 20)])
+def test_drop_in_call_heap_sort_fallback(rs, oracle, sched, name, R, G, S, jit):
+    """rs_schedule_tti on the killer grids (built-in one-TTI kernel and the context's own hiprtc build)."""
+    arrays, _ = killers()
+    cqi = _grid_maxcell(arrays[name], R, S) if sched == 9 else np.tile(arrays[name], (S, 1)).astype(np.uint8)
+    ues = [1] * S
+    sc = rs.SliceConfig(ues)
+    ts = rs.TtiScheduler(sc, R, G, sched=sched, jit=jit)
+    cell = oracle.Cell(ues, R, G, sched)
+    rng = np.random.default_rng(11)
+    for it in range(6):
+        avg = rng.uniform(1e3, 5e6, S)
+        r0, r1 = int(rng.integers(0, 2**31 - 1)), int(rng.integers(0, 2**31 - 1))
+        cell.set_cqi(cqi)
+        out = cell.new_out()
+        assert cell.allocate(avg, r0, r1, out) == 0
+        res = ts.schedule_tti(cqi, avg, r0, r1)
+        np.testing.assert_array_equal(res.rbg_to_user, out.rbg_to_user, err_msg=f"call {it}")
+        np.testing.assert_array_equal(res.quota_rbgs, out.quota_rbgs)
+        np.testing.assert_array_equal(res.user_nprb, out.user_nprb)
+        np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits)
+        if sched == 10:
+            np.testing.assert_array_equal(res.upper_rbg, out.upper_rbg)
+            np.testing.assert_array_equal(res.upper_user, out.upper_user)
+    assert ts.heap_sorts().sum() >= 6, ts.heap_sorts()
+    ts.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,R,S", [("n500_wg", 25, 20), ("n1280_wave", 64, 20)])
+def test_device_maximize_cell_on_killer_grid_matches_reference_unit_code(rs, oracle, name, R, S):
+    """The keys and quotas the device handed to its inter-slice step go through the reference's own MaximizeCell
+    (oracle/_ref/libref_tp_algos.so): its RBG -> slice map is the one the device applied."""
+    L = oracle.ref_lib("libref_tp_algos.so")
+    if L is None:
+        pytest.skip("oracle/_ref/libref_tp_algos.so did not travel")
+    from test_oracle_pins import ref_maximize_cell
+    arrays, _ = killers()
+    G = 4 if R == 25 else 8
+    grids = np.stack([np.stack([_grid_maxcell(arrays[name], R, S)])])
+    sc = rs.SliceConfig([1] * S)
+    for jit in (False, True):
+        b = rs.BatchScheduler(sc, R, G, 1, sched=9, jit=jit)
+        b.seed(np.array([3], np.uint32))
+        b.upload_cqi_epochs(grids)
+        got = b.run_logged(40, slice_keys=True)
+        assert b.heap_sorts().sum() >= 40
+        b.close()
+        for n in range(40):
+            keys = np.ascontiguousarray(got["slice_cqi"][0, n], np.int32)
+            assert (keys == arrays[name].reshape(R, S)).all()
+            want = ref_maximize_cell(L, keys, got["quota"][0, n].astype(np.int32))
+            m = got["rbg_to_user"][0, n].astype(np.int64)  # one UE per slice: user id = slice id
+            assert (m == want).all(), n
