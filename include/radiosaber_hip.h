@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 10 /* 10: rs_batch_debug_heap_sorts / rs_ctx_debug_heap_sorts (the sort emulation's heap-sort fallback counted per device site);
+#define RS_ABI_VERSION 10 /* 10: rs_batch_debug_heap_sorts / rs_ctx_debug_heap_sorts (the sort emulation's heap-sort fallback counted per device site),
+                               rs_jit_cache_stats / _file / _warm (code objects cached on disk);
                             9: rs_create_checked / rs_batch_create_checked (RS_CREATE / RS_BATCH_CREATE: the caller's ABI version and struct size are
                             checked), rs_batch_config.cqi_epoch_wrap / queue_state_lds, threads_per_cell up to 1024 with jit, rs_jit_selfcheck_untuned, rs_batch_write_state, rs_ctx_specialize, rs_jit_selfcheck_dropin;
                             8: rs_jit_selfcheck_queue, rs_config.synthetic_exp, any integer algo_epsilon / algo_psi in drop-in contexts; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
@@ -412,6 +413,19 @@ int rs_jit_selfcheck_untuned(int n_slices, int n_users, int n_rbgs, int rbg_size
 /* the same for the queue-model kernel (the code object rs_batch_set_bearers switches a batch to; schedulers 1, 7, 8, 9, 101, 103) */
 int rs_jit_selfcheck_queue(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, char* err,
                            size_t errlen);
+/* ---- the run-time compiled kernels' cache on disk (ABI 10) ----
+ * Every code object hiprtc produces (rs_batch_create with jit = 1, the lean / streamed variants, rs_ctx_specialize) is kept in
+ * $RS_JIT_CACHE_DIR (default $XDG_CACHE_HOME/radiosaber_amd, else ~/.cache/radiosaber_amd), one file per (device source hash, full
+ * hiprtc option list, hiprtc version); a later process loads it instead of compiling (~2 s per variant -> a few ms).  Files are
+ * written under a temporary name and renamed; a file that does not check out (magic, key text, length, checksum) is compiled again
+ * and replaced.  RS_JIT_CACHE=0 switches the cache off.
+ * rs_jit_cache_stats: this process's hits, misses (= hiprtc runs), files written, files rejected.
+ * rs_jit_cache_file: the file the batch kernel of a shape lives in (flags: 2 = streamed-CQI variant, 4 = lean build); returns its
+ *   length, 0 when no cache directory can be named.
+ * rs_jit_cache_warm: that kernel THROUGH the cache (compiles and stores on a miss); needs no GPU; code size or -1 with the log. */
+void rs_jit_cache_stats(long long out[4]);
+int rs_jit_cache_file(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, int flags, char* out, size_t outlen);
+int rs_jit_cache_warm(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, int flags, char* err, size_t errlen);
 /* 16 hex digits: FNV-1a hash of the device sources this library was built from (and compiles at run time); measurement
  * records under profiles/ carry it so that a record taken on other kernel code can be told apart (bench.py: "stale") */
 const char* rs_device_source_hash(void);

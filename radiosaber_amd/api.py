@@ -96,6 +96,7 @@ ABI_SYMBOLS = [
     "rs_create_checked", "rs_batch_create_checked", "rs_jit_selfcheck_untuned", "rs_batch_write_state",
     "rs_ctx_specialize", "rs_jit_selfcheck_dropin",
     "rs_batch_debug_heap_sorts", "rs_ctx_debug_heap_sorts",
+    "rs_jit_cache_stats", "rs_jit_cache_file", "rs_jit_cache_warm",
 ]
 
 _lib = None
@@ -166,6 +167,10 @@ def lib():
     L.rs_batch_debug_stamps.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]
     L.rs_batch_debug_heap_sorts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.rs_ctx_debug_heap_sorts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.rs_jit_cache_stats.argtypes = [C.POINTER(C.c_longlong)]
+    L.rs_jit_cache_stats.restype = None
+    L.rs_jit_cache_file.argtypes = [C.c_int] * 7 + [C.c_char_p, C.c_size_t]
+    L.rs_jit_cache_warm.argtypes = [C.c_int] * 7 + [C.c_char_p, C.c_size_t]
     L.rs_batch_ttis_done.restype = C.c_int64
     L.rs_batch_ttis_done.argtypes = [C.c_void_p]
     L.rs_batch_stream.restype = C.c_void_p
@@ -208,6 +213,29 @@ def jit_selfcheck(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCH
     if dropin:  # the drop-in entry point's one-TTI kernel of a context of this shape (rs_ctx_specialize)
         fn = lib().rs_jit_selfcheck_dropin
     n = fn(n_slices, n_users, n_rbgs, rbg_size, threads, sched, buf, 4096)
+    if n < 0:
+        raise RadioSaberError(n, buf.value.decode(errors="replace"))
+    return n
+
+
+def jit_cache_stats():
+    """This process's disk-cache counters of the run-time compiled kernels: dict(hits, misses, stores, rejected)."""
+    out = (C.c_longlong * 4)()
+    lib().rs_jit_cache_stats(out)
+    return dict(zip(("hits", "misses", "stores", "rejected"), (int(x) for x in out)))
+
+
+def jit_cache_file(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCHED_MAXCELL, lean=False, streamed=False):
+    """Path of the cache file the batch kernel of this shape lives in ('' when no cache directory can be named)."""
+    buf = C.create_string_buffer(4096)
+    lib().rs_jit_cache_file(n_slices, n_users, n_rbgs, rbg_size, threads, sched, (4 if lean else 0) | (2 if streamed else 0), buf, 4096)
+    return buf.value.decode()
+
+
+def jit_cache_warm(n_slices, n_users, n_rbgs, rbg_size, threads=512, sched=RS_SCHED_MAXCELL, lean=False, streamed=False):
+    """Compile (or load) the batch kernel of this shape through the disk cache; no GPU needed.  Returns the code size."""
+    buf = C.create_string_buffer(4096)
+    n = lib().rs_jit_cache_warm(n_slices, n_users, n_rbgs, rbg_size, threads, sched, (4 if lean else 0) | (2 if streamed else 0), buf, 4096)
     if n < 0:
         raise RadioSaberError(n, buf.value.decode(errors="replace"))
     return n
