@@ -74,7 +74,7 @@ def test_jit_builds_without_the_llvm_tuning_options_and_for_640_threads(rs):
     assert rs.jit_selfcheck(20, 500, 25, 4, 512, rs.RS_SCHED_MAXCELL, untuned=True) > 0
     assert rs.jit_selfcheck(20, 500, 64, 8, 640, rs.RS_SCHED_MAXCELL) > 0
     src = (ROOT / "radiosaber_amd" / "csrc" / "rs_jit.cpp").read_text()
-    assert "rs_jit_compile(S, U, R, G, NT, sched, log2, qmode, win, false, " in src  # the retry in rs_jit_get: same arguments, tuned = false
+    assert "rs_jit_options(S, U, R, G, NT, sched, qmode, win, false, " in src  # the retry in rs_jit_get: same arguments, tuned = false
     assert rs.lds_bytes_per_cell(20, 500, 64, rs.RS_SCHED_MAXCELL, 640) <= 80 * 1024  # two cells per CU
 
 
