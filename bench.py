@@ -256,6 +256,10 @@ def main():
     ap.add_argument("--no-streamed", action="store_true", help="skip the extra streamed-CQI measurement (roofline.streamed)")
     ap.add_argument("--no-jit", action="store_true", help="use the kernels built into the library instead of the "
                     "shape-specialised one compiled at create time")
+    ap.add_argument("--config-key", default=None,
+                    help="one of the reference's shipped experiment configurations (a key of tests/golden/experiment_configs.json, "
+                         "e.g. exp-fixranues/20slices/config-pf.json): ragged ues_per_slice, weights and algo parameters from the "
+                         "fixture, on the as-shipped 64-RBG grid unless --rbgs says otherwise; every flow backlogged")
     ap.add_argument("--allow-variant", action="store_true",
                     help="run although RS_JIT_EXTRA / RS_JIT is set in the environment (tuning experiments; the line says so)")
     args = ap.parse_args()
@@ -305,8 +309,20 @@ def main():
         ranks_in_group = dist.get_world_size()
 
     red_dev = "cuda" if backend == "nccl" else "cpu"  # where the tiny reductions live
-    S, U, R = args.slices, args.slices * args.ues_per_slice, args.rbgs
-    slices = rs.SliceConfig([args.ues_per_slice] * S, weight=[1.0 / S] * S)
+    if args.config_key:
+        cfgs = json.loads((ROOT / "tests" / "golden" / "experiment_configs.json").read_text())
+        if args.config_key not in cfgs:
+            raise SystemExit(f"bench.py: --config-key {args.config_key!r} is not in tests/golden/experiment_configs.json ({len(cfgs)} keys, "
+                             f"e.g. {sorted(cfgs)[0]})")
+        c = cfgs[args.config_key]
+        slices = rs.SliceConfig(c["ues_per_slice"], weight=c["weight"], algo_epsilon=c["algo_epsilon"], algo_psi=c["algo_psi"])
+        if not any(a.startswith("--rbgs") for a in sys.argv):
+            args.rbgs, args.rbg_size = 64, 8  # the reference's 100 MHz carrier: 512 PRBs in RBGs of 8
+        args.slices, args.ues_per_slice = slices.n_slices, None
+        S, U, R = slices.n_slices, slices.n_users, args.rbgs
+    else:
+        S, U, R = args.slices, args.slices * args.ues_per_slice, args.rbgs
+        slices = rs.SliceConfig([args.ues_per_slice] * S, weight=[1.0 / S] * S)
     want_jit = not args.no_jit
 
     EPOCH_BYTES_CAP = 8 << 30  # HBM spent on CQI epochs before they start to cycle (far beyond the 256 MiB Infinity Cache)
@@ -317,11 +333,11 @@ def main():
         stride = (8 * (k8 if k8 & 1 else k8 + 1) * n_rbgs + 15) // 16 * 16  # device-resident grids are RBG-major [R][Upad]
         n_epochs = need
         wrap = False
-        if refresh != 40 and need * args.cells * stride > EPOCH_BYTES_CAP:
+        if need * args.cells * stride > EPOCH_BYTES_CAP:  # (at the reference's 40-TTI refresh too: --steps is not bounded by HBM)
             n_epochs, wrap = max(2, EPOCH_BYTES_CAP // (args.cells * stride)), True
         b = rs.BatchScheduler(slices, n_rbgs, rbg_size, args.cells, sched=args.sched, device=local_rank,
                               threads_per_cell=args.threads, jit=want_jit, cqi_refresh=refresh, cqi_epoch_wrap=wrap)
-        b.n_epochs_resident, b.epoch_stride = n_epochs, stride
+        b.n_epochs_resident, b.epoch_stride, b.epochs_wrap = n_epochs, stride, wrap
         code, msg = b.jit_status()
         ok = (not want_jit) or code == 1
         if world > 1:
@@ -382,7 +398,8 @@ def main():
     sharding.all_reduce_slice_bytes(slice_bytes, dist if world > 1 else None)
     total_bytes = int(slice_bytes.sum().item())
     kernel_name = batch.kernel_name
-    batch_epochs = batch.n_epochs_resident
+    batch_epochs, batch_wrap = batch.n_epochs_resident, batch.epochs_wrap
+    jit_code, jit_msg = batch.jit_status()  # (before close: a closed batch has no status to read)
     batch.close()
 
     if rank == 0:
@@ -424,10 +441,12 @@ def main():
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"sched={args.sched} ({'RadioSaber/MaximizeCell' if args.sched == 9 else 'see --sched'}), "
-                                   f"{args.cells} independent cells per GPU x ({S} slices x {args.ues_per_slice} UEs "
+                                   f"{args.cells} independent cells per GPU x ({S} slices x "
+                                   f"{args.ues_per_slice if args.ues_per_slice else 'the shipped ' + str(args.config_key) + ' mix of'} UEs "
                                    f"= {U} UEs x {R} RBGs), {args.ttis} TTIs per step, CQI i.i.d. from the trace "
                                    f"histogram redrawn every {args.cqi_refresh} TTIs (BASELINE.json configs[3]; configs[4] at 8 GPUs)",
-                       "cqi_refresh": args.cqi_refresh, "cqi_epochs_resident": batch_epochs,
+                       "cqi_refresh": args.cqi_refresh, "cqi_epochs_resident": batch_epochs, "cqi_epochs_cycle": batch_wrap,
+                       "config_key": args.config_key, "ues_per_slice": slices.ues_per_slice,
                        "cells_per_gpu": args.cells, "ttis_per_step": args.ttis, "slices": S, "ues": U, "rbgs": R,
                        "sched": args.sched, "parallelism": f"cells sharded over {world} GPU(s), no data-path collective"},
             "us_per_tti_per_cell": launch_s / args.ttis * 1e6,
@@ -436,7 +455,8 @@ def main():
             # run-time options (trace rows, per-PRB twins, decision log, error-model draws) compiled out, results identical
             "kernel_build": ("lean" if (want_jit and os.environ.get("RS_JIT_LEAN", "1") != "0"
                                         and args.ttis >= int(os.environ.get("RS_JIT_LEAN_MIN_TTIS", "256"))
-                                        and "lean build unavailable" not in batch.jit_status()[1]) else "general"),
+                                        and "lean build unavailable" not in jit_msg) else "general"),
+            "jit_status": [jit_code, jit_msg],
             # who reduced: the process-group backend ("nccl" IS RCCL on ROCm), the ranks it saw, the library version
             "backend": backend if world > 1 else None, "ranks_in_group": ranks_in_group,
             "rccl_version": _rccl_version(torch) if (world > 1 and backend == "nccl") else None,

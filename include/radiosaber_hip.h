@@ -228,9 +228,9 @@ typedef struct rs_batch_config {
                                 reference's PHY error model does on the shared libc stream
                                 (ref: src/phy/wideband-cqi-eesm-error-model.cpp:69)              */
   int32_t threads_per_cell;  /* workgroup size, multiple of 64 in [64,512] ([64,1024] with jit = 1: the built-in kernels
-                                are bounded at 512); 0 = default: 512, 256 once the batch puts 4 or more cells on
-                                every CU, 640 for a shape-specialised MaximizeCell batch of 1 025..1 280 sort records
-                                (the 64-RBG grid: two sort positions per lane on every wave)                      */
+                                are bounded at 512); 0 = default: 512, or 256 once the batch puts 4 or more cells on
+                                every CU.  More than 512 threads work with jit = 1 but are never chosen automatically
+                                (640 on the 64-RBG grid: 8.55 against 13.58 M TTIs/s, profiles/r04_r64.md)          */
   int32_t jit;               /* 1: compile the cell kernel for this batch's exact shape at create time
                                 (hiprtc, ~2 s, cached per process); results are identical, the built-in
                                 kernels are used if the compilation fails (rs_batch_jit_status tells).  0: built-in kernels.
@@ -382,9 +382,11 @@ int rs_batch_run_timed(rs_batch* b, int32_t n_ttis, int32_t launches, float* ms_
  * slice_state [n_cells][S] (slice_rbs_offset_, or slice_ewma_time_ for NVS) */
 int rs_batch_read_state(rs_batch* b, double* avg_rate, int64_t* cum_bytes, int64_t* cum_rbs,
                         double* slice_state);
-/* the inverse for what a restart (or a test) sets: avg_rate [n_cells][U] (every value >= 1, the EWMA's clamp) and
- * slice_state [n_cells][S]; either may be NULL = left alone.  Between launches only; not with the queue model (one average per
- * bearer there).  (ABI 9) */
+/* An initialisation / test hook, NOT a checkpoint: sets avg_rate [n_cells][U] (every value >= 1, the EWMA's clamp) and
+ * slice_state [n_cells][S]; either may be NULL = left alone.  It does not touch the rest of a cell's state -- the grant of the last
+ * TTI that the next EWMA update consumes, the clock, the rand() ring, the cumulative counters -- so it is exact before the first
+ * launch (or on a batch whose last grant was zero); after a launch the pending grant is applied on top of the new averages.  Not
+ * with the queue model (one average per bearer there).  (ABI 9) */
 int rs_batch_write_state(rs_batch* b, const double* avg_rate, const double* slice_state);
 /* the simulated clock of every cell (ref: src/core/eventScheduler/simulator.cc:117-126): t [n_cells] = time stamp of the next
  * TTI, last_update [n_cells] = RadioBearer::m_lastUpdate; either may be NULL */

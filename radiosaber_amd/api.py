@@ -692,6 +692,8 @@ class BatchScheduler:
 
     def jit_status(self):
         """(code, message): 1 = shape-specialised kernel in use, 0 = not requested, -1 = requested but the build failed."""
+        if not getattr(self, "_h", None):
+            raise RadioSaberError(-4, "jit_status() of a closed batch")
         buf = C.create_string_buffer(512)
         rc = lib().rs_batch_jit_status(self._h, buf, 512)
         return rc, buf.value.decode(errors="replace")

@@ -944,7 +944,8 @@ int rs_batch_set_bearers(rs_batch* b, const uint8_t* bearer_kind) {
   RsJitKernel* qjit = nullptr;
   char qmsg[sizeof b->jit_msg] = {0};
   if (b->jit_wanted) { /* the shape-specialised kernel of the queue model is a different code object */
-    qjit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, qmode, slice_window(b), qmsg, sizeof qmsg, 0);
+    qjit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, qmode, slice_window(b), qmsg, sizeof qmsg,
+                      b->cfg.cqi_refresh <= 4 ? 2 : 0); /* (the streamed bit as batch_new and lean_kernel set it: the general and the lean build differ in the lean bit only) */
     if (!qjit && !qmsg[0]) snprintf(qmsg, sizeof qmsg, "hiprtc build of the queue-model kernel failed");
     if (!qjit && b->threads > 512) return fail(RS_ERR_INVALID, "threads_per_cell %d needs the shape-specialised queue-model kernel: %s", b->threads, qmsg);
   }
