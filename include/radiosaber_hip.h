@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define RS_ABI_VERSION 10 /* 10: rs_batch_debug_heap_sorts / rs_ctx_debug_heap_sorts (the sort emulation's heap-sort fallback counted per device site),
-                               rs_jit_cache_stats / _file / _warm (code objects cached on disk);
+                               rs_jit_cache_stats / _file / _warm (code objects cached on disk), rs_batch_config.autotune + rs_batch_autotune_report;
                             9: rs_create_checked / rs_batch_create_checked (RS_CREATE / RS_BATCH_CREATE: the caller's ABI version and struct size are
                             checked), rs_batch_config.cqi_epoch_wrap / queue_state_lds, threads_per_cell up to 1024 with jit, rs_jit_selfcheck_untuned, rs_batch_write_state, rs_ctx_specialize, rs_jit_selfcheck_dropin;
                             8: rs_jit_selfcheck_queue, rs_config.synthetic_exp, any integer algo_epsilon / algo_psi in drop-in contexts; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
@@ -246,6 +246,14 @@ typedef struct rs_batch_config {
                                 0 = automatic: LDS when the cell still fits the CU's 160 KB, except when that is what
                                 takes the cell over 80 KB (one cell per CU instead of two) in a batch of more cells
                                 than CUs; 1 = LDS whenever it fits; -1 = HBM (ABI 9)                              */
+  int32_t autotune;          /* 1 (with jit = 1; schedulers 8, 9, 101, 103 without the queue model): before the batch's first long
+                                unlogged launch (or in rs_batch_prepare_launch) the lean kernel is built in two or three variants
+                                the library's rule table chooses between -- LLVM scheduler strategy, speculative next-TTI scan /
+                                held winners on or off, users per stage-1 block --, each is timed on the batch's next
+                                min(n_ttis, 512) TTIs from a snapshot of the whole cell state that is put back afterwards, and the
+                                fastest serves the batch.  Every variant is exact, so results do not depend on the choice; cost
+                                ~2 s of hiprtc per variant once per shape and machine (the code objects are cached on disk).
+                                rs_batch_autotune_report tells what was measured.  0 = the rule table alone.  (ABI 10)    */
 } rs_batch_config;
 
 rs_batch* rs_batch_create(const rs_batch_config* cfg);
@@ -395,6 +403,9 @@ int rs_batch_read_clock(rs_batch* b, double* t, double* last_update);
  * 0: it was not asked for; -1: it was asked for and could not be built -- the built-in kernels run instead and msg
  * receives the reason */
 int rs_batch_jit_status(rs_batch* b, char* msg, size_t msglen);
+/* what rs_batch_config.autotune measured: one line "variant: ms" per candidate and the one kept; empty before the tuning ran or
+ * when it does not apply.  Returns the number of candidates timed (0: none). */
+int rs_batch_autotune_report(rs_batch* b, char* msg, size_t msglen);
 /* Optional: build now whatever kernel an unlogged rs_batch_run of n_ttis TTIs would otherwise build at its first launch (the lean
  * build of the shape-specialised kernel, see rs_batch_config.jit), so that no timed launch carries a hiprtc run.  Call it once the
  * CQI source is set.  RS_OK also when there is nothing to build. */

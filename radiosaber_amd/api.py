@@ -49,7 +49,7 @@ class _BatchConfig(C.Structure):
     _fields_ = [("cell", _Config), ("n_cells", C.c_int32), ("first_tti", C.c_int32),
                 ("cqi_refresh", C.c_int32), ("phy_error_draws", C.c_int32),
                 ("threads_per_cell", C.c_int32), ("jit", C.c_int32),
-                ("cqi_epoch_wrap", C.c_int32), ("queue_state_lds", C.c_int32)]
+                ("cqi_epoch_wrap", C.c_int32), ("queue_state_lds", C.c_int32), ("autotune", C.c_int32)]
 
 
 RS_ABI_VERSION = 10  # the include/radiosaber_hip.h these ctypes structs mirror; passed to the *_checked create functions
@@ -96,7 +96,7 @@ ABI_SYMBOLS = [
     "rs_create_checked", "rs_batch_create_checked", "rs_jit_selfcheck_untuned", "rs_batch_write_state",
     "rs_ctx_specialize", "rs_jit_selfcheck_dropin",
     "rs_batch_debug_heap_sorts", "rs_ctx_debug_heap_sorts",
-    "rs_jit_cache_stats", "rs_jit_cache_file", "rs_jit_cache_warm",
+    "rs_jit_cache_stats", "rs_jit_cache_file", "rs_jit_cache_warm", "rs_batch_autotune_report",
 ]
 
 _lib = None
@@ -171,6 +171,7 @@ def lib():
     L.rs_jit_cache_stats.restype = None
     L.rs_jit_cache_file.argtypes = [C.c_int] * 7 + [C.c_char_p, C.c_size_t]
     L.rs_jit_cache_warm.argtypes = [C.c_int] * 7 + [C.c_char_p, C.c_size_t]
+    L.rs_batch_autotune_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.rs_batch_ttis_done.restype = C.c_int64
     L.rs_batch_ttis_done.argtypes = [C.c_void_p]
     L.rs_batch_stream.restype = C.c_void_p
@@ -529,14 +530,15 @@ class BatchScheduler:
     def __init__(self, slices: SliceConfig, n_rbgs: int, rbg_size: int, n_cells: int,
                  sched: int = RS_SCHED_MAXCELL, device: int = 0, first_tti: int = 100, cqi_refresh: int = 40,
                  phy_error_draws: bool = False, threads_per_cell: int = 0, stream: Optional[int] = None,
-                 jit: bool = False, synthetic_exp: bool = False, cqi_epoch_wrap: bool = False, queue_state_lds: int = 0):
+                 jit: bool = False, synthetic_exp: bool = False, cqi_epoch_wrap: bool = False, queue_state_lds: int = 0,
+                 autotune: bool = False):
         """synthetic_exp: the reference built with FIRST/SECOND_SYNTHETIC_EXP (transport blocks PRB by PRB; rs_config.synthetic_exp).
         cqi_epoch_wrap: the uploaded / synthesized epochs cycle instead of ending the run.  queue_state_lds: 0 auto, 1 LDS, -1 HBM."""
         self.slices, self.R, self.rbg_size, self.sched, self.n_cells = slices, n_rbgs, rbg_size, sched, n_cells
         self.S, self.U = slices.n_slices, slices.n_users
         self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream, synthetic_exp)
         bc = _BatchConfig(self._cfg.c, n_cells, first_tti, cqi_refresh, int(phy_error_draws), threads_per_cell,
-                          int(jit), int(bool(cqi_epoch_wrap)), int(queue_state_lds))
+                          int(jit), int(bool(cqi_epoch_wrap)), int(queue_state_lds), int(bool(autotune)))
         self._h = lib().rs_batch_create_checked(C.byref(bc), RS_ABI_VERSION, C.sizeof(_BatchConfig))
         if not self._h:
             raise RadioSaberError(-1, lib().rs_last_error().decode())
@@ -689,6 +691,12 @@ class BatchScheduler:
     def prepare_launch(self, n_ttis):
         """Build now the kernel an unlogged run(n_ttis) would build at its first launch (the lean build): keeps hiprtc out of timed runs."""
         _check(lib().rs_batch_prepare_launch(self._h, int(n_ttis)))
+
+    def autotune_report(self):
+        """(candidates timed, text): what rs_batch_config.autotune measured and kept."""
+        buf = C.create_string_buffer(1024)
+        n = lib().rs_batch_autotune_report(self._h, buf, 1024)
+        return n, buf.value.decode(errors="replace")
 
     def jit_status(self):
         """(code, message): 1 = shape-specialised kernel in use, 0 = not requested, -1 = requested but the build failed."""

@@ -30,7 +30,8 @@ extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_
 extern "C" hipError_t rs_prepare_kernels(int max_lds_bytes);
 struct RsJitKernel;
 extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int NT, int sched, int qmode, int win, char* err, size_t errlen,
-                                   int flags); /* bit 0: drop-in (one-TTI) kernel, bit 1: streamed batch (cqi_refresh <= 4), bit 2: lean build */
+                                   int flags, /* bit 0: drop-in (one-TTI) kernel, bit 1: streamed batch (cqi_refresh <= 4), bit 2: lean build */
+                                   const char* variant = nullptr); /* an autotune candidate: extra -D options and / or "ss=<LLVM scheduler strategy>" */
 extern "C" int rs_jit_is_untuned(const RsJitKernel* k);
 extern "C" hipError_t rs_jit_launch(RsJitKernel* k, const RsLaunch* p, hipStream_t stream);
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R, int Upad,
@@ -262,6 +263,10 @@ struct rs_batch {
   RsJitKernel* jit = nullptr; /* shape-specialised kernel (owned by the process-wide cache) */
   RsJitKernel* jit_lean = nullptr; /* its lean build, compiled at the first launch that can use it (launch()) */
   bool jit_lean_tried = false;
+  bool autotuned = false;       /* rs_batch_config.autotune: the candidates were timed (or the tuning does not apply) */
+  int autotune_n = 0;
+  char autotune_msg[768] = "";
+  void* d_snapshot = nullptr;   /* autotune: the whole cell state, put back after every trial */
   bool jit_wanted = false;
   char jit_msg[512] = ""; /* why the shape-specialised kernel is not in use (empty: it is, or it was not asked for) */
   int64_t ttis_done = 0;
@@ -320,7 +325,10 @@ int slice_window(const rs_batch* b) {
 void carve_lds(rs_batch* b, RsLaunch* L) {
   /* (drop-in contexts of schedulers 1 and 7 carry the gate scratch too: rs_tti_in.required_rbs / data_to_transmit) */
   const bool gate_scratch = b->direct && (b->sched == RS_SCHED_PF || b->sched == RS_SCHED_NVS);
-  const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads, b->queues ? b->qmode : (gate_scratch ? 1 : 0));
+  /* the same arguments the batch's shape-specialised kernels are compiled with (rs_jit_get: slice_window() for batches, 0 for
+   * drop-in contexts); a batch that runs the built-in kernels splits NVS slices earlier (RS_NVS_WHOLE_SLICE_BUILTIN) */
+  const RsCarve c = rs_carve(b->S, b->U, b->R, b->sched, b->threads, b->queues ? b->qmode : (gate_scratch ? 1 : 0),
+                             b->direct ? 0 : slice_window(b), (b->jit_wanted || b->direct) ? RS_NVS_WHOLE_SLICE : RS_NVS_WHOLE_SLICE_BUILTIN);
   L->Upad = c.Upad;
   L->nvs_seg = c.nvs_seg;
   L->off_avgk = c.off_avgk; L->off_rcp = c.off_rcp; L->off_tab = c.off_tab; L->off_slice = c.off_slice;
@@ -496,6 +504,7 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
     return nullptr;
   }
   if ((cfg->cqi_epoch_wrap | 1) != 1) { fail(RS_ERR_INVALID, "cqi_epoch_wrap %d is not 0 or 1", cfg->cqi_epoch_wrap); return nullptr; }
+  if ((cfg->autotune | 1) != 1) { fail(RS_ERR_INVALID, "autotune %d is not 0 or 1", cfg->autotune); return nullptr; }
   if (cfg->queue_state_lds < -1 || cfg->queue_state_lds > 1) { fail(RS_ERR_INVALID, "queue_state_lds %d outside -1..1", cfg->queue_state_lds); return nullptr; }
   if (cfg->cell.sched == RS_SCHED_UPPERBOUND) {
     /* the per-slice sorts use the register form of the sort emulation: at most four array positions per thread */
@@ -532,6 +541,7 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   b->u2s.assign(c.user_to_slice, c.user_to_slice + b->U);
   b->cfg.cell.slice_weight = nullptr; b->cfg.cell.algo_alpha = nullptr; b->cfg.cell.algo_beta = nullptr;
   b->cfg.cell.algo_epsilon = nullptr; b->cfg.cell.algo_psi = nullptr; b->cfg.cell.user_to_slice = nullptr;
+  b->jit_wanted = want_jit && !direct; /* (before the LDS carve: its NVS rule depends on which kernels will run) */
   if (batch_alloc(b)) { rs_batch_destroy(b); return nullptr; }
   if (want_jit && !direct) {
     /* failure is not an error of this call: the built-in kernels stay in use and the batch keeps the reason
@@ -585,7 +595,98 @@ RsJitKernel* lean_kernel(rs_batch* b, int n_ttis, bool logged) {
 }
 
 int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d_target, int32_t* d_tbs, int32_t* d_uinfo,
-           uint32_t* d_keys = nullptr) {
+           uint32_t* d_keys = nullptr);
+
+/* rs_batch_config.autotune: time the lean kernel in the variants the rule table of rs_jit.cpp chooses between, on this batch's own
+ * next TTIs, and keep the fastest.  Every trial starts from the same snapshot of the whole cell state (PF averages, pending
+ * grants, counters, slice state, clock / rand() ring / CQI report state) and the snapshot is put back at the end, so the tuning
+ * leaves no trace in the run; all variants compute the same results anyway (the parity tests run them against the oracle). */
+int autotune(rs_batch* b, int n_ttis) {
+  if (b->autotuned || !b->cfg.autotune) return RS_OK;
+  if (!lean_kernel(b, n_ttis, false)) return RS_OK; /* this launch does not qualify for the lean build: try again at a later one */
+  b->autotuned = true;
+  const int sched = b->sched;
+  if (b->queues || b->direct || !(sched == 8 || sched == 9 || sched == 101 || sched == 103)) return RS_OK;
+  const int win = slice_window(b);
+  std::vector<std::string> cand = {""};
+  const bool ilp_by_rule = sched == 9 || (sched == 8 && (b->R > 32 || win > 0));
+  cand.push_back(ilp_by_rule ? "ss=default" : "ss=iterative-ilp");
+  cand.push_back(b->R > 32 ? "-DRS_NO_SPEC" : "-DRS_NO_HOLD");
+  if (sched == 9) cand.push_back("-DRS_P3_BLOCK=8");
+  const size_t cells = b->n_cells, U = b->U, S = b->S;
+  struct Part { void* p; size_t n; };
+  const Part parts[] = {{b->d_avg, 8 * cells * U}, {b->d_tx, 4 * cells * U}, {b->d_cumb, 8 * cells * U}, {b->d_cumr, 8 * cells * U},
+                        {b->d_sstate, 8 * cells * S}, {b->d_scal, sizeof(RsCellScalars) * cells}};
+  size_t total = 0;
+  for (const Part& q : parts) total += (q.n + 255) & ~(size_t)255;
+  HIP_TRY(hipMalloc(&b->d_snapshot, total));
+  auto copy_state = [&](bool save) -> hipError_t {
+    size_t off = 0;
+    for (const Part& q : parts) {
+      void* snap = (char*)b->d_snapshot + off;
+      const hipError_t e = hipMemcpyAsync(save ? snap : q.p, save ? q.p : snap, q.n, hipMemcpyDeviceToDevice, b->stream);
+      if (e != hipSuccess) return e;
+      off += (q.n + 255) & ~(size_t)255;
+    }
+    return hipSuccess;
+  };
+  const int64_t done0 = b->ttis_done;
+  const int trial = n_ttis < 512 ? n_ttis : 512;
+  RsJitKernel* const k_default = b->jit_lean;
+  RsJitKernel* best = k_default;
+  float best_ms = 0;
+  int rc = RS_OK;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(copy_state(true));
+  std::string report;
+  for (size_t i = 0; i < cand.size() && rc == RS_OK; i++) {
+    char msg[512] = "";
+    RsJitKernel* k = i == 0 ? k_default
+                            : rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, sched, 0, win, msg, sizeof msg,
+                                         (b->cfg.cqi_refresh <= 4 ? 2 : 0) | 4, cand[i].c_str());
+    if (!k) { report += cand[i] + ": not built; "; continue; }
+    b->jit_lean = k;
+    float ms = 0;
+    for (int rep = 0; rep < 3 && rc == RS_OK; rep++) { /* one warm launch, then the faster of two */
+      if (copy_state(false) != hipSuccess || hipEventRecord(e0, b->stream) != hipSuccess) { rc = fail(RS_ERR_HIP, "autotune: state restore failed"); break; }
+      rc = launch(b, trial, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+      if (rc) break;
+      float t = 0;
+      if (hipEventRecord(e1, b->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) {
+        rc = fail(RS_ERR_HIP, "autotune: timing failed");
+        break;
+      }
+      if (rep == 1 || (rep == 2 && t < ms)) ms = t;
+    }
+    if (rc) break;
+    char line[160];
+    snprintf(line, sizeof line, "%s: %.3f ms; ", i == 0 ? "rule table" : cand[i].c_str(), ms);
+    report += line;
+    b->autotune_n++;
+    if (i == 0 || ms < best_ms) { best = k; best_ms = ms; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  /* the run continues from where it was, whatever happened above */
+  const hipError_t back = copy_state(false);
+  const hipError_t sync = hipStreamSynchronize(b->stream);
+  b->ttis_done = done0;
+  (void)hipFree(b->d_snapshot);
+  b->d_snapshot = nullptr;
+  b->jit_lean = rc == RS_OK ? best : k_default;
+  if (back != hipSuccess || sync != hipSuccess) return fail(RS_ERR_HIP, "autotune: the cell state could not be put back");
+  if (rc) return rc;
+  rc = check_device_err(b);
+  if (rc) return rc;
+  snprintf(b->autotune_msg, sizeof b->autotune_msg, "autotune over %d TTIs: %skept %s", trial, report.c_str(),
+           best == k_default ? "the rule table's build" : "the fastest");
+  return RS_OK;
+}
+
+int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d_target, int32_t* d_tbs, int32_t* d_uinfo,
+           uint32_t* d_keys) {
   if (n_ttis < 1) return fail(RS_ERR_INVALID, "n_ttis %d < 1", n_ttis);
   if (b->cqi_mode == RS_CQI_NONE) return fail(RS_ERR_STATE, "no CQI source set");
   if (b->any_alpha && !b->direct && !b->queues)
@@ -622,7 +723,12 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
     L.b_avg = b->d_bavg; L.b_cumb = b->d_bcum; L.b_cumr = b->d_bcum + n;
     L.q_flags = b->d_qflags; L.q_hol = b->d_qhol;
   }
-  RsJitKernel* k = lean_kernel(b, n_ttis, d_map || d_quota || d_target || d_tbs || d_uinfo || d_keys);
+  const bool logged = d_map || d_quota || d_target || d_tbs || d_uinfo || d_keys;
+  if (b->cfg.autotune && !b->autotuned && !logged) {
+    const int rc = autotune(b, n_ttis); /* (its trials come back through here with `autotuned` set) */
+    if (rc) return rc;
+  }
+  RsJitKernel* k = lean_kernel(b, n_ttis, logged);
   if (!k) k = b->jit;
   if (k) HIP_TRY(rs_jit_launch(k, &L, b->stream));
   else HIP_TRY(rs_launch_cells(&L, b->threads, b->stream));
@@ -1105,11 +1211,21 @@ int rs_batch_debug_heap_sorts(rs_batch* b, int64_t* out) {
   return RS_OK;
 }
 
+int rs_batch_autotune_report(rs_batch* b, char* msg, size_t msglen) {
+  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  if (msg && msglen) snprintf(msg, msglen, "%s", b->autotune_msg);
+  return b->autotune_n;
+}
+
 int rs_batch_prepare_launch(rs_batch* b, int32_t n_ttis) {
   if (!b || n_ttis < 1) return fail(RS_ERR_INVALID, "bad argument");
   if (b->cqi_mode == RS_CQI_NONE) return fail(RS_ERR_STATE, "no CQI source set");
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   (void)lean_kernel(b, n_ttis > RS_MAX_TTIS_PER_LAUNCH ? RS_MAX_TTIS_PER_LAUNCH : n_ttis, false);
+  if (b->cfg.autotune && !b->autotuned) {
+    const int rc = autotune(b, n_ttis > RS_MAX_TTIS_PER_LAUNCH ? RS_MAX_TTIS_PER_LAUNCH : n_ttis);
+    if (rc) return rc;
+  }
   return RS_OK;
 }
 
@@ -1186,6 +1302,16 @@ struct rs_ctx {
   bool timing = false;
   double t_prep = 0, t_enq = 0, t_wait = 0, t_unpack = 0;
   long n_calls = 0;
+  /* Completion by a word in the pinned output block (round 5): the kernel's last store writes the call's sequence number there and
+   * the host spins on it -- the stream's completion signal (interrupt or the runtime's own polling, then its bookkeeping) costs a
+   * few microseconds more per call (profiles/r05_dropin_split.md).  Zero-copy calls only; RS_DROPIN_POLL=0 keeps
+   * hipStreamSynchronize; a call that does not see its number within RS_DROPIN_POLL_US (default 2 000) microseconds falls back to
+   * it (and reports whatever error the stream holds). */
+  bool poll = false;
+  uint32_t seq = 0;
+  size_t flag_off = 0; /* offset of the word in h_out / z_out: behind the largest layout, on its own cache line */
+  long poll_us = 2000;
+  long n_polled = 0, n_fallback = 0;
 };
 
 namespace {
@@ -1254,10 +1380,11 @@ rs_ctx* rs_create(const rs_config* cfg) {
   c->b = b;
   const CtxLayout l = ctx_layout(b->U, b->R, b->S, b->G, b->sched == RS_SCHED_NVS_NONGREEDY);
   c->in_bytes = l.in_total;
-  c->out_bytes = l.out_total;
+  c->flag_off = round_up(l.out_total, 64);
+  c->out_bytes = c->flag_off + 64;
   bool ok = hipMalloc(&c->d_in, c->in_bytes) == hipSuccess && hipMalloc(&c->d_out, c->out_bytes) == hipSuccess &&
             hipHostMalloc((void**)&c->h_in, c->in_bytes, hipHostMallocMapped) == hipSuccess &&
-            hipHostMalloc((void**)&c->h_out, c->out_bytes, hipHostMallocMapped) == hipSuccess;
+            hipHostMalloc((void**)&c->h_out, c->out_bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
   const char* force_copy = getenv("RS_DROPIN_COPY");
   if (ok && !(force_copy && force_copy[0] == '1')) {
     void *zi = nullptr, *zo = nullptr;
@@ -1269,14 +1396,18 @@ rs_ctx* rs_create(const rs_config* cfg) {
   if (!ok) { fail(RS_ERR_HIP, "allocation of the staging blocks failed"); rs_destroy(c); return nullptr; }
   const char* tm = getenv("RS_DROPIN_TIMING");
   c->timing = tm && tm[0] == '1';
+  const char* pl = getenv("RS_DROPIN_POLL");
+  c->poll = c->z_out != nullptr && !(pl && pl[0] == '0');
+  if (const char* pu = getenv("RS_DROPIN_POLL_US")) c->poll_us = atol(pu) > 0 ? atol(pu) : 2000;
+  if (c->h_out) memset(c->h_out + c->flag_off, 0, 64);
   return c;
 }
 
 void rs_destroy(rs_ctx* c) {
   if (!c) return;
   if (c->timing && c->n_calls)
-    fprintf(stderr, "rs_schedule_tti x %ld: prepare %.2f us, enqueue %.2f us, wait %.2f us, unpack %.2f us per call\n", c->n_calls,
-            c->t_prep / c->n_calls, c->t_enq / c->n_calls, c->t_wait / c->n_calls, c->t_unpack / c->n_calls);
+    fprintf(stderr, "rs_schedule_tti x %ld: prepare %.2f us, enqueue %.2f us, wait %.2f us, unpack %.2f us per call (%ld completed by the polled word, %ld fell back to the stream)\n", c->n_calls,
+            c->t_prep / c->n_calls, c->t_enq / c->n_calls, c->t_wait / c->n_calls, c->t_unpack / c->n_calls, c->n_polled, c->n_fallback);
   if (c->b && c->b->stream) (void)hipStreamSynchronize(c->b->stream);
   if (c->d_in) (void)hipFree(c->d_in);
   if (c->d_out) (void)hipFree(c->d_out);
@@ -1418,11 +1549,35 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
    * slices, no gates, exponents in {0, 1}, every input inside the FP32 filter's range), the general one otherwise */
   RsJitKernel* kd = b->jit;
   if (b->jit_lean && !L.prb_cqi && !L.queue_mode && !L.gate && !L.exact_scan && !L.gen_exp && !L.log_upper && !L.synthetic) kd = b->jit_lean;
+  const bool poll = zc && c->poll;
+  volatile uint32_t* const h_flag = (volatile uint32_t*)(c->h_out + c->flag_off);
+  if (poll) {
+    if (++c->seq == 0) c->seq = 1; /* (0 is the word's initial value) */
+    L.done_flag = (uint32_t*)(c->z_out + c->flag_off);
+    L.done_seq = c->seq;
+  }
   if (kd) HIP_TRY(rs_jit_launch(kd, &L, st));
   else HIP_TRY(rs_launch_cells(&L, b->threads, st));
   if (!zc) HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, l.out_total, hipMemcpyDeviceToHost, st));
   const clk::time_point t2 = c->timing ? clk::now() : clk::time_point();
-  HIP_TRY(hipStreamSynchronize(st));
+  bool seen = false;
+  if (poll) {
+    /* the kernel's last store publishes the sequence number after its outputs (release, system scope): spin on the pinned word */
+    const clk::time_point give_up = clk::now() + std::chrono::microseconds(c->poll_us);
+    for (unsigned spins = 0;; ++spins) {
+      if (__atomic_load_n((const uint32_t*)h_flag, __ATOMIC_ACQUIRE) == c->seq) { seen = true; break; }
+      __builtin_ia32_pause();
+      if ((spins & 255u) == 255u && clk::now() > give_up) break;
+    }
+    if (seen) {
+      c->n_polled++;
+      /* the stream's own bookkeeping is settled without waiting: every 64th call asks it, so that nothing piles up in the runtime */
+      if ((c->n_polled & 63) == 0) (void)hipStreamQuery(st);
+    } else {
+      c->n_fallback++;
+    }
+  }
+  if (!seen) HIP_TRY(hipStreamSynchronize(st));
   const clk::time_point t3 = c->timing ? clk::now() : clk::time_point();
   const int16_t* h_map = (const int16_t*)(c->h_out + l.map);
   const int16_t* h_quota = (const int16_t*)(c->h_out + l.quota);

@@ -138,20 +138,28 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
   return c;
 }
 #ifndef RS_NVS_WHOLE_SLICE
-#define RS_NVS_WHOLE_SLICE 64 /* sched 7: up to this many users per slice on average the slice is scanned whole -- the shape-specialised
-                                * kernels scan it four lanes per item during the previous TTI's serial phase (kQuad7, windows of up to 64 users):
-                                * 1 000 UEs in 20 slices 215.1 against 179.9 M TTIs/s with split runs, 106.4 against 85.3 at 64 RBGs; the built-in
-                                * kernels, which have no such scan, lose 6 % there (88.9 against 94.2; tools/r04_run45.sh) */
+#define RS_NVS_WHOLE_SLICE 64 /* sched 7: up to this many users per slice the slice is scanned whole -- the shape-specialised kernels scan it
+                                * four lanes per item during the previous TTI's serial phase (kQuad7, windows of up to 64 users): 1 000 UEs in
+                                * 20 slices 215.1 against 179.9 M TTIs/s with split runs, 106.4 against 85.3 at 64 RBGs */
 #endif
-constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads, int queue = 0) {
+#ifndef RS_NVS_WHOLE_SLICE_BUILTIN
+#define RS_NVS_WHOLE_SLICE_BUILTIN 32 /* ... the kernels built into the library have no such scan: split runs from 32 users per slice on
+                                        * (whole slices lose 6 % at 50 users per slice there: 88.9 against 94.2 M TTIs/s, tools/experiments/r04/run45.sh) */
+#endif
+/* win: the batch's longest 8-aligned slice window when the caller knows it (batches: slice_window(); RS_JIT_WIN in their kernels), 0 = not
+ * known (drop-in contexts, the build checks): the NVS rule is keyed on it, so that ONE long slice of a ragged batch gets split runs
+ * (round 5; the average was the key before, and such a batch got neither split runs nor the four-lane scan).  nvs_whole: the
+ * threshold of that rule -- RS_NVS_WHOLE_SLICE for a batch that asked for its shape-specialised kernel, _BUILTIN otherwise. */
+constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads, int queue = 0, int win = 0, int nvs_whole = RS_NVS_WHOLE_SLICE) {
   if (queue) return rs_carve_with(S, U, R, sched, threads, 0, queue); /* (sched 7 with queues: no split runs, no metric scan) */
-  if (sched == 7 && U > RS_NVS_WHOLE_SLICE * S) { /* slices of more users than that on average: one run per work item is too long */
+  const bool nvs_long = sched == 7 && (win > 0 ? win > nvs_whole : U > nvs_whole * S);
+  if (nvs_long) { /* a slice of more users than that: one run per work item is too long */
     for (int seg = 8; seg <= 16; seg *= 2) {
       const RsCarve c = rs_carve_with(S, U, R, sched, threads, seg);
       if (c.lds_bytes <= 80 * 1024) return c;
     }
   }
-  if (sched == 7 && U > RS_NVS_WHOLE_SLICE * S) return rs_carve_with(S, U, R, sched, threads, 32);
+  if (nvs_long) return rs_carve_with(S, U, R, sched, threads, 32);
   if (sched == 11) {
     /* the sampler's batch (carried in nvs_seg, which scheduler 7 alone reads as a run length): 64 samples -- half the barriers,
      * fuller scan rounds: 15.3 against 13.0 M TTIs/s at 500 UEs x 25 RBGs -- unless that is what takes the cell over 80 KB (two
@@ -273,6 +281,10 @@ struct RsLaunch {
   int32_t off_avgk, off_rcp, off_tx, off_tab, off_slice, off_items, off_elems,
       off_sorted, off_sortx, off_misc, off_tbs, off_cqi, off_queue, off_qstate, q_lds, lds_bytes;
   int32_t n_seg, n_items;    /* segments per RBG scan, R*n_seg */
+  /* drop-in mode, optional: a word in the caller's pinned output block that the kernel's very last store sets to done_seq (system
+   * scope, after every thread's outputs): rs_schedule_tti polls it instead of waiting for the stream's completion signal */
+  uint32_t* done_flag;
+  uint32_t done_seq;
 };
 
 #endif /* RS_DEVICE_H_ */

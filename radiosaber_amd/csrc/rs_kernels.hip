@@ -151,7 +151,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * (bit 0: the prioritized bearer has data; queue model only, bit 1: the user has any queued data = is in UsersToSchedule) */
   /* The queue model's per-bearer words (RS_QSTATE_BYTES_PER_USER per user) stay in LDS for the whole launch when the carve has
    * room (q_lds; a compile-time fact in a shape-specialised build, so its pointers are plain LDS pointers), else in HBM. */
-  constexpr RsCarve kCvQ = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_CARVEQ);
+  constexpr RsCarve kCvQ = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_CARVEQ, RS_JIT_WIN);
   const bool q_lds = QUEUE && (FIXED ? kCvQ.q_lds != 0 : p.q_lds != 0);
   const int qU = FIXED ? RS_JIT_U : p.U;
   unsigned char* const qs = lds + (FIXED ? kCvQ.off_qstate : p.off_qstate);
@@ -175,7 +175,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   /* (a shape-specialised drop-in kernel: RS_JIT_U is the context's user capacity -- it fixes the LDS carve -- while the users of one
    * call, their grid stride and, per-flow PF, their segments are launch arguments) */
   const int S = FIXED ? RS_JIT_S : p.S, U = (FIXED && !DIRECT) ? RS_JIT_U : p.U, R = FIXED ? RS_JIT_R : p.R, G = FIXED ? RS_JIT_G : p.G;
-  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_CARVEQ);
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_CARVEQ, RS_JIT_WIN);
   /* byte offsets of the LDS arrays: constants in a shape-specialised build */
   struct Offs { int avgk, rcp, tab, slice, tx, misc, tbs, elems, sorted, items, sortx, cqi, queue, Upad, n_seg, n_items; };
   const Offs o = FIXED ? Offs{kCv.off_avgk, kCv.off_rcp, kCv.off_tab, kCv.off_slice, kCv.off_tx, kCv.off_misc, kCv.off_tbs,
@@ -687,6 +687,14 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     scal->rng_f = rng.f;
     scal->rng_b = rng.b;
   }
+  if constexpr (DIRECT) {
+    /* rs_schedule_tti's completion word: every thread's outputs are out (system scope) before thread 0 publishes the sequence number */
+    if (p.done_flag) {
+      __threadfence_system();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(p.done_flag, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 }  // namespace
@@ -726,7 +734,7 @@ extern "C" __global__ void __launch_bounds__(RS_JIT_NT, RS_JIT_WPE) rs_cell_kern
   p.gate = nullptr; p.exact_scan = 0; p.gen_exp = 0; p.gen_num = nullptr; p.log_upper = nullptr; p.synthetic = 0;
   p.trace = nullptr; p.trace_prb = nullptr; p.epochs_prb = nullptr; p.log_keys = nullptr;
 #endif
-  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_CARVEQ);
+  constexpr RsCarve kCv = rs_carve(RS_JIT_S, RS_JIT_U, RS_JIT_R, RS_JIT_SCHED, RS_JIT_NT, RS_JIT_CARVEQ, RS_JIT_WIN);
   __shared__ __align__(16) unsigned char lds[kCv.lds_bytes];
   constexpr int kEpt = (RS_JIT_SCHED != 9 && RS_JIT_SCHED != 10) ? 0 : (kCv.ept <= 4 ? kCv.ept : 0);
   rs_cell_body<RS_JIT_SCHED, kEpt, true, RS_JIT_DIRECT != 0, (RS_JIT_CARVEQ >= 2)>(p, lds);

@@ -558,6 +558,7 @@ __device__ void counting_sort_desc(const uint32_t* v, uint32_t* out, int N, Misc
   }
   __syncthreads();
   if (wave == 0) {
+#ifdef RS_COUNTING_SORT_V1
     int total = 0;
     if (lane < 16)
       for (int c = 0; c < n_chunks; ++c) total += m->hist[c * 16 + lane];
@@ -574,6 +575,22 @@ __device__ void counting_sort_desc(const uint32_t* v, uint32_t* out, int N, Misc
         m->hist[c * 16 + lane] = (uint16_t)run;
         run += h;
       }
+#else
+    /* lanes = chunks (at most 64: 4 096 records): per key one prefix scan over the chunks instead of a serial walk of two loops
+     * over them on 16 lanes (round 5) */
+    int excl[16], base = 0;
+#pragma unroll
+    for (int q = 15; q >= 0; --q) { /* larger keys first */
+      const int h = lane < n_chunks ? (int)m->hist[lane * 16 + q] : 0;
+      const int incl = wave_scan_incl(h);
+      excl[q] = base + incl - h;
+      base += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (lane < n_chunks) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) m->hist[lane * 16 + q] = (uint16_t)excl[q];
+    }
+#endif
   }
   __syncthreads();
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -593,8 +610,109 @@ __device__ void counting_sort_desc(const uint32_t* v, uint32_t* out, int N, Misc
  * register introsort): one ballot pass gives both the per-chunk counts and every element's rank among
  * equal keys in its chunk; after one barrier every wave derives the output offsets of its own chunks
  * from the count table (lane q = key q), so there is no single-wave step and no second barrier. */
+/* Round 5, from two chunks per wave on (the 64-RBG grid: 1 280 records = 20 chunks, three per wave -- the phase took 8 100-8 900 cycles
+ * there against 1 550 at 500 records, profiles/r04_phase_stamps.log):
+ *   A  lanes holding my key = valid & ~OR_b (plane_b ^ -bit_b(my key)): four XORs and three ORs per 32-bit half instead of four
+ *      64-bit selects; rank = v_mbcnt of it.  The chunk's count of a key is written by the LAST lane holding it (rank + 1) into rows
+ *      the wave has just zeroed itself (its LDS operations execute in order) -- no second mask per key.
+ *   B  every wave still derives its chunks' offsets itself (no single-wave step, one barrier), but on all 64 lanes: lane = key +
+ *      16 * group, group g adds up chunks g, g + 4, ...; two lane exchanges fold the four groups (values packed two per word).
+ *   C  as before.  -DRS_COUNTING_SORT_V1 keeps the round-4 form. */
+__device__ __forceinline__ int xor_lanes_sum(int x) { /* x summed over lanes l, l ^ 16, l ^ 32, l ^ 48 */
+  const int lane = lane_id();
+  x += __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, x);
+  x += __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, x);
+  return x;
+}
+
+template <int CPW>
+__device__ __forceinline__ void counting_sort_desc_owned_v2(const uint32_t* v, uint32_t* out, int N, Misc* m) {
+  static_assert(CPW >= 1 && CPW <= 4, "at most four chunks per wave");
+  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
+  const int n_chunks = (N + 63) >> 6;
+  const unsigned long long gt_lane = lane == 63 ? 0ull : (~0ull << (lane + 1));
+  uint32_t* const hist32 = (uint32_t*)m->hist;
+  uint32_t e[CPW];
+  int rank[CPW];
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int c = j * nwaves + wave, i = (c << 6) + lane;
+    const bool valid = c < n_chunks && i < N;
+    e[j] = valid ? v[i] : 0u;
+    const int k = (int)(e[j] >> 16);
+    if (lane < 8 && c < n_chunks) hist32[c * 8 + lane] = 0u; /* the chunk's 16 counts */
+    uint32_t dl = 0u, dh = 0u; /* lanes whose key differs from mine in some bit, as two 32-bit halves */
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t mine = (uint32_t)(((int)(e[j] << (15 - b))) >> 31); /* all ones when my key has bit b (one v_bfe_i32) */
+      const unsigned long long plane = __ballot(mine != 0u);
+      dl |= (uint32_t)plane ^ mine;
+      dh |= (uint32_t)(plane >> 32) ^ mine;
+    }
+    const unsigned long long vm = __ballot(valid);
+    const uint32_t sl = (uint32_t)vm & ~dl, sh = (uint32_t)(vm >> 32) & ~dh;
+    rank[j] = (int)__builtin_amdgcn_mbcnt_hi(sh, __builtin_amdgcn_mbcnt_lo(sl, 0u));
+    if (valid && ((sl & (uint32_t)gt_lane) | (sh & (uint32_t)(gt_lane >> 32))) == 0u) m->hist[c * 16 + k] = (uint16_t)(rank[j] + 1);
+  }
+  __syncthreads();
+  const int q = lane & 15, g = lane >> 4;
+  int total = 0, below[CPW];
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) below[j] = 0;
+  for (int t = 0; t < (n_chunks + 3) >> 2; ++t) { /* (a wave-uniform trip count: unrolled in a shape-specialised build) */
+    const int c = 4 * t + g;
+    const int h = c < n_chunks ? (int)m->hist[c * 16 + q] : 0;
+    total += h;
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) below[j] += c < j * nwaves + wave ? h : 0;
+  }
+  /* fold the four groups: counts are at most 4 096, two per word */
+  {
+    const int w0 = xor_lanes_sum(total | (below[0] << 16));
+    total = w0 & 0xffff;
+    below[0] = (int)((unsigned)w0 >> 16);
+    if constexpr (CPW >= 2) {
+      const int w1 = xor_lanes_sum(below[1] | ((CPW >= 3 ? below[CPW >= 3 ? 2 : 0] : 0) << 16));
+      below[1] = w1 & 0xffff;
+      if constexpr (CPW >= 3) below[2] = (int)((unsigned)w1 >> 16);
+    }
+    if constexpr (CPW >= 4) below[3] = xor_lanes_sum(below[3]);
+  }
+  /* elements with a larger key come first: lane q needs the sum of total over keys > q (prefix inside each row of 16) */
+  int inc = total;
+  {
+    int v_ = inc;
+    const int identity = 0;
+#define RS_ROW_STEP(ctrl, bmask) v_ = v_ + __builtin_amdgcn_update_dpp(identity, v_, ctrl, 0xf, bmask, false)
+    RS_ROW_STEP(0x111, 0xf);
+    RS_ROW_STEP(0x112, 0xf);
+    RS_ROW_STEP(0x114, 0xe);
+    RS_ROW_STEP(0x118, 0xc);
+#undef RS_ROW_STEP
+    inc = v_;
+  }
+  const int all = __builtin_amdgcn_readlane(inc, 15);
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int c = j * nwaves + wave, i = (c << 6) + lane;
+    const int base_q = all - inc + below[j]; /* lane q < 16 */
+    const int base = __builtin_amdgcn_ds_bpermute((int)(e[j] >> 16) << 2, base_q); /* every lane: no branch around it */
+    if (c < n_chunks && i < N) out[base + rank[j]] = e[j];
+  }
+  __syncthreads();
+}
+
 template <int CPW>
 __device__ __forceinline__ void counting_sort_desc_owned(const uint32_t* v, uint32_t* out, int N, Misc* m) {
+#ifndef RS_COUNTING_SORT_V1
+#ifndef RS_COUNTING_SORT_V2_MIN_CPW
+#define RS_COUNTING_SORT_V2_MIN_CPW 2
+#endif
+  if constexpr (CPW >= RS_COUNTING_SORT_V2_MIN_CPW) {
+    counting_sort_desc_owned_v2<CPW>(v, out, N, m);
+    return;
+  }
+#endif
   const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
   const int n_chunks = (N + 63) >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;

@@ -1,0 +1,122 @@
+"""GPU tests added in round 5 (through the C ABI, bit-exact against the oracle): the rewritten counting sorts at two, three and four
+chunks per wave and in the LDS form, the NVS carve rule keyed on the longest slice window (ragged batches), the built-in NVS
+threshold, the batch autotune (state untouched, results identical), the drop-in call's polled completion word."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import synth_cqi
+from test_gpu_parity import HIST, _check_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("jit", [False, True])
+@pytest.mark.parametrize("ues,R,G,threads", [
+    ([3] * 40, 25, 4, 0),      # 1 000 sort records: two chunks per wave
+    ([5] * 20, 64, 8, 0),      # 1 280: three (the as-shipped grid)
+    ([2] * 32, 64, 8, 0),      # 2 048: four, every chunk full
+    ([2] * 30, 61, 8, 0),      # 1 830: four, the last chunk partial
+    ([5] * 20, 64, 8, 256),    # 1 280 records on four waves: five chunks per wave -> the LDS form (lanes = chunks prefix)
+    ([1] * 64, 64, 8, 128),    # 4 096 records: 64 chunks, the LDS form's widest table
+])
+def test_counting_sort_forms(rs, oracle, ues, R, G, threads, jit):
+    if threads == 128 and not jit:
+        pytest.skip("one shape of the LDS form per build is enough")
+    _check_batch(rs, oracle, 9, ues, R, G, n_cells=2, n_ttis=85, threads=threads, jit=jit, seed=5)
+
+
+def test_counting_sort_round4_form_still_agrees(rs, oracle, monkeypatch):
+    """-DRS_COUNTING_SORT_V1 keeps the previous form for A/B runs: same results."""
+    monkeypatch.setenv("RS_JIT_EXTRA", "-DRS_COUNTING_SORT_V1")
+    _check_batch(rs, oracle, 9, [5] * 20, 64, 8, n_cells=2, n_ttis=60, jit=True, seed=6)
+
+
+@pytest.mark.parametrize("jit", [False, True])
+@pytest.mark.parametrize("ues", [[70, 5, 5, 5, 5, 5, 5, 5, 5, 5], [10, 90, 10, 10], [40, 41, 39]])
+def test_nvs_ragged_batch_with_one_long_slice(rs, oracle, ues, jit):
+    """The average slice is short, one window is longer than 64 users: split runs (round 5: rs_carve keyed on the longest window)."""
+    _check_batch(rs, oracle, 7, ues, 25, 4, n_cells=3, n_ttis=130, jit=jit, seed=7)
+    _check_batch(rs, oracle, 7, ues, 64, 8, n_cells=2, n_ttis=90, jit=jit, seed=8)
+
+
+@pytest.mark.parametrize("ues", [[50] * 20, [33] * 8])
+def test_builtin_nvs_kernels_split_from_32_users_per_slice(rs, oracle, ues):
+    _check_batch(rs, oracle, 7, ues, 25, 4, n_cells=2, n_ttis=90, jit=False, seed=9)
+    _check_batch(rs, oracle, 7, ues, 25, 4, n_cells=2, n_ttis=90, jit=True, seed=9)
+
+
+@pytest.mark.parametrize("sched,ues,R,G", [(9, [25] * 20, 25, 4), (8, [10] * 20, 64, 8), (9, [13, 13, 6, 11, 10], 64, 8), (103, [5] * 20, 25, 4)])
+def test_autotune_leaves_no_trace_and_keeps_results(rs, oracle, sched, ues, R, G):
+    """rs_batch_config.autotune: the trials run on the batch's own next TTIs from a snapshot that is put back; the batch then
+    continues exactly like one that was never tuned, whatever variant was kept -- counters, PF averages, slice state, clock and the
+    run that follows, all against the oracle."""
+    n_cells, n1, n2 = 3, 300, 340
+    sc = rs.SliceConfig(ues)
+    U = sc.n_users
+    grids = synth_cqi(77, (n_cells, (n1 + n2 + 39) // 40 + 1, U, R), HIST)
+    seeds = np.arange(n_cells, dtype=np.uint32) + 99
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=True, autotune=True)
+    b.seed(seeds)
+    b.upload_cqi_epochs(grids)
+    assert b.autotune_report()[0] == 0
+    b.run(40)                       # a short launch first: below the lean build's threshold, no tuning yet
+    assert b.autotune_report()[0] == 0
+    b.prepare_launch(n1)            # tunes here: >= 3 candidates timed on TTIs 40 .. 40 + 300, state put back
+    n_cand, text = b.autotune_report()
+    assert n_cand >= 3 and "rule table" in text and "kept" in text, text
+    assert b.ttis_done == 40
+    t, lu = b.clock()
+    b.run(n1 - 40)
+    got = b.run_logged(n2)          # logged launches use the general build
+    st = b.state()
+    b.close()
+    for c in range(n_cells):
+        cell = oracle.Cell(ues, R, G, sched)
+        logs = cell.run_synth(grids[c], int(seeds[c]), n1 + n2)
+        ost = cell.state()
+        np.testing.assert_array_equal(got["rbg_to_user"][c], logs["rbg_to_user"][n1:], err_msg=f"cell {c}")
+        np.testing.assert_array_equal(got["tbs_bits"][c], logs["tbs_bits"][n1:])
+        np.testing.assert_array_equal(st["cum_bytes"][c], ost["cum_bytes"])
+        np.testing.assert_array_equal(st["cum_rbs"][c], ost["cum_rbs"])
+        assert st["avg_rate"][c].tobytes() == ost["avg_rate"].tobytes()
+        assert st["slice_state"][c].tobytes() == ost["slice_state"].tobytes()
+
+
+def test_autotune_is_a_no_op_where_it_does_not_apply(rs):
+    sc = rs.SliceConfig([5] * 20)
+    for sched, jit in ((7, True), (1, True), (9, False)):
+        b = rs.BatchScheduler(sc, 25, 4, 2, sched=sched, jit=jit, autotune=True)
+        b.seed(np.array([1, 2], np.uint32))
+        b.synthesize_cqi(3, 16)
+        b.prepare_launch(400)
+        b.run(400)
+        assert b.autotune_report() == (0, "")
+        b.close()
+
+
+@pytest.mark.parametrize("poll", ["1", "0"])
+@pytest.mark.parametrize("jit", [False, True])
+def test_drop_in_completion_word(rs, oracle, monkeypatch, poll, jit):
+    """RS_DROPIN_POLL: the kernel's last store publishes the call's sequence number in the pinned output block and the host spins
+    on it (default), or the stream's completion is waited for (0): the same results either way, over many back-to-back calls."""
+    monkeypatch.setenv("RS_DROPIN_POLL", poll)
+    ues, R, G = [25] * 20, 25, 4
+    sc = rs.SliceConfig(ues)
+    U = sc.n_users
+    ts = rs.TtiScheduler(sc, R, G, sched=9, jit=jit)
+    cell = oracle.Cell(ues, R, G, 9)
+    rng = np.random.default_rng(13)
+    for it in range(300):
+        cqi = synth_cqi(500 + it % 7, (U, R), HIST)
+        avg = rng.uniform(1e3, 5e6, U)
+        r0, r1 = int(rng.integers(0, 2**31 - 1)), int(rng.integers(0, 2**31 - 1))
+        res = ts.schedule_tti(cqi, avg, r0, r1)
+        cell.set_cqi(cqi)
+        out = cell.new_out()
+        assert cell.allocate(avg, r0, r1, out) == 0
+        np.testing.assert_array_equal(res.rbg_to_user, out.rbg_to_user, err_msg=f"call {it}")
+        np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits, err_msg=f"call {it}")
+        np.testing.assert_array_equal(res.quota_rbgs, out.quota_rbgs, err_msg=f"call {it}")
+    ts.close()
