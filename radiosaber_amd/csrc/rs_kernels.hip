@@ -254,7 +254,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * with the FP32 product of DESIGN.md 3.2, reduces over the wave (DPP) and settles ties exactly: an RBG's winner is final when its
    * wave is done with it -- no per-item exact metric, no reduction over run winners on wave 0 (rs_phase_p3.inc).
    * The scan is VALU-bound either way (five instructions per (user, RBG) product on every SIMD of the CU); what this form saves is
-   * the second stage.  Same-box A/B, 512 cells (tools/r04_run17.sh): 1 000 UEs x 25 RBGs 112.7 against 96.5 M TTIs/s, 500 x 25 161.5
+   * the second stage.  Same-box A/B, 512 cells (tools/experiments/r04/run17.sh): 1 000 UEs x 25 RBGs 112.7 against 96.5 M TTIs/s, 500 x 25 161.5
    * against 163.3, 500 x 64 96.7 against 96.3 -- so: from 16 users per lane on (-DRS_PF1_ALWAYS: every shape). */
 #if defined(RS_NO_PF1_LANES)
   constexpr bool kPf1 = false;
@@ -498,12 +498,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * has read what its link adaptation needs of it (m->grid_free).  The device-resident grids are stored as the LDS image, RBG-major
    * [R][Upad], so a refresh is a straight 16-byte copy either way; with the fetch ahead TTI t+1 starts with its grid in place -- no
    * HBM latency at the top of the TTI.  Streamed-CQI mode (cqi_refresh = 1), 512 cells x 500 UEs x 25 RBGs, same box
-   * (tools/r04_run20.sh, against -DRS_NO_GRID_AHEAD, which keeps the straight copy at the top): GreedyByRow 59.9 against 53.9 M
+   * (tools/experiments/r04/run20.sh, against -DRS_NO_GRID_AHEAD, which keeps the straight copy at the top): GreedyByRow 59.9 against 53.9 M
    * TTIs/s, NVS 148.9 against 124.4, per-flow PF 156.3 against 125.9; MaximizeCell LOSES (26.7 against 28.5 streamed, 31.2 against
    * 33.4 with the grid resident: its kernel is register-bound and the extra live scalars cost more spills than the fetch saves),
    * so it keeps the copy at the top of the TTI (-DRS_GRID_AHEAD_ALL: MaximizeCell too).
    * The code costs the kernels that never use it (same box, grid resident, with / without it compiled in: NVS 218.7 / 232.4 M TTIs/s,
-   * GreedyByRow at 64 RBGs 44.4 / 48.0 -- tools/r04_run30.sh), so only the kernels of a streamed batch carry it: rs_jit.cpp defines
+   * GreedyByRow at 64 RBGs 44.4 / 48.0 -- tools/experiments/r04/run30.sh), so only the kernels of a streamed batch carry it: rs_jit.cpp defines
    * RS_JIT_STREAMED when the batch's cqi_refresh is at most 4 (the built-in kernels copy at the top of the TTI). */
 #ifndef RS_JIT_STREAMED
 #define RS_JIT_STREAMED 0
@@ -552,7 +552,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
      * Same-box A/B (512 cells, 25 RBGs): GreedyByRow 94.8 against 93.4 M TTIs/s (its TTI is short: the top of the TTI is a large
      * share), MaximizeCell 32.86 against 33.16 -- the waves that work beside wave 0 slow its greedy scan and link adaptation by
      * what the shorter top saves, as round 2 found for its speculation -- so: GreedyByRow, and MaximizeCell from two users per thread on. */
-    /* (MaximizeCell re-measured on the lean build, tools/r04_run44.sh: 34.45 against 34.64 M at one user per thread, 31.9 against 31.0 at two:
+    /* (MaximizeCell re-measured on the lean build, tools/experiments/r04/run44.sh: 34.45 against 34.64 M at one user per thread, 31.9 against 31.0 at two:
      * from two users per thread on the shorter top of the TTI outweighs what the busy waves cost wave 0) */
     const bool ewma_next = quota_next && (SCHED == 8 || (SCHED == 9 && FIXED && RS_JIT_U > RS_JIT_NT));
     /* ... and pack their lists for TTI t+1 (a one-chunk shape: at most 64 items per wave).  Packing them for MaximizeCell too,
