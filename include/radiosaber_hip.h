@@ -450,6 +450,10 @@ const char* rs_device_source_hash(void);
  * do.  out = [n_cells][3] / [3].  (ABI 10) */
 int rs_batch_debug_heap_sorts(rs_batch* b, int64_t* out);
 int rs_ctx_debug_heap_sorts(rs_ctx* ctx, int64_t* out);
+/* diagnostics: the shader clock the LAST launch really ran at, per cell: (s_memtime cycles) / (s_memrealtime ticks at 100 MHz) between
+ * the first and the last instruction of the cell's thread 0 -> shader_mhz [n_cells]; kernel_ms [n_cells] = that span in milliseconds
+ * (a cell's own run time: cells that waited for a free CU start later).  Either may be NULL.  (ABI 10) */
+int rs_batch_debug_clocks(rs_batch* b, double* shader_mhz, double* kernel_ms);
 /* diagnostics: cycles per kernel phase of one cell's first thread, summed over the last launch;
  * only in the separate -DRS_STAMPS build (RS_ERR_STATE in the product library) */
 int rs_batch_debug_stamps(rs_batch* b, int32_t cell, uint64_t* out20);

@@ -96,7 +96,7 @@ ABI_SYMBOLS = [
     "rs_create_checked", "rs_batch_create_checked", "rs_jit_selfcheck_untuned", "rs_batch_write_state",
     "rs_ctx_specialize", "rs_jit_selfcheck_dropin",
     "rs_batch_debug_heap_sorts", "rs_ctx_debug_heap_sorts",
-    "rs_jit_cache_stats", "rs_jit_cache_file", "rs_jit_cache_warm", "rs_batch_autotune_report",
+    "rs_jit_cache_stats", "rs_jit_cache_file", "rs_jit_cache_warm", "rs_batch_autotune_report", "rs_batch_debug_clocks",
 ]
 
 _lib = None
@@ -172,6 +172,7 @@ def lib():
     L.rs_jit_cache_file.argtypes = [C.c_int] * 7 + [C.c_char_p, C.c_size_t]
     L.rs_jit_cache_warm.argtypes = [C.c_int] * 7 + [C.c_char_p, C.c_size_t]
     L.rs_batch_autotune_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.rs_batch_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rs_batch_ttis_done.restype = C.c_int64
     L.rs_batch_ttis_done.argtypes = [C.c_void_p]
     L.rs_batch_stream.restype = C.c_void_p
@@ -691,6 +692,13 @@ class BatchScheduler:
     def prepare_launch(self, n_ttis):
         """Build now the kernel an unlogged run(n_ttis) would build at its first launch (the lean build): keeps hiprtc out of timed runs."""
         _check(lib().rs_batch_prepare_launch(self._h, int(n_ttis)))
+
+    def debug_clocks(self):
+        """(shader MHz [n_cells], ms [n_cells]) of the last launch, from the kernel's own two clocks (rs_batch_debug_clocks)."""
+        mhz = np.zeros(self.n_cells, np.float64)
+        ms = np.zeros(self.n_cells, np.float64)
+        _check(lib().rs_batch_debug_clocks(self._h, _p(mhz, C.c_double), _p(ms, C.c_double)))
+        return mhz, ms
 
     def autotune_report(self):
         """(candidates timed, text): what rs_batch_config.autotune measured and kept."""

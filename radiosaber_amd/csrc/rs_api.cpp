@@ -1211,6 +1211,20 @@ int rs_batch_debug_heap_sorts(rs_batch* b, int64_t* out) {
   return RS_OK;
 }
 
+int rs_batch_debug_clocks(rs_batch* b, double* shader_mhz, double* kernel_ms) {
+  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  std::vector<RsCellScalars> sc(b->n_cells);
+  HIP_TRY(hipMemcpy(sc.data(), b->d_scal, sizeof(RsCellScalars) * b->n_cells, hipMemcpyDeviceToHost));
+  for (int c = 0; c < b->n_cells; c++) {
+    const double real = (double)(sc[c].real_end - sc[c].real_begin), clk = (double)(sc[c].clk_end - sc[c].clk_begin);
+    if (shader_mhz) shader_mhz[c] = real > 0 ? clk / real * 100.0 : 0.0; /* s_memrealtime ticks at 100 MHz */
+    if (kernel_ms) kernel_ms[c] = real / 1e5;
+  }
+  return RS_OK;
+}
+
 int rs_batch_autotune_report(rs_batch* b, char* msg, size_t msglen) {
   if (!b) return fail(RS_ERR_INVALID, "null batch");
   if (msg && msglen) snprintf(msg, msglen, "%s", b->autotune_msg);

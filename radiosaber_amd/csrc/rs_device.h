@@ -121,7 +121,9 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
   c.off_misc = off; off += rs_round_up((int)sizeof(RsMisc), 16);
   c.off_tbs = off; off += rs_round_up(4 * 16 * (R + 1), 16); /* TBS bits of n RBGs at a final CQI */
   c.off_elems = off; off += rs_round_up(pf_like ? 8 * c.n_items : 4 * R * S, 16);
-  c.off_sorted = off; off += (sched == 7 && nvs_seg != 0) ? 0 : rs_round_up(4 * R * S, 16);
+  /* (the sorted / alternate record array: the transport schedulers only -- 1, 7 and 11 keep winner tables; without it a 600-UE x 64-RBG
+   * cell of the per-flow PF scheduler is 77 824 B instead of 82 944: two cells per CU, round 5) */
+  c.off_sorted = off; off += (sched == 1 || sched == 7 || sched == 11) ? 0 : rs_round_up(4 * R * S, 16);
   /* winners per work item; the schedulers with a speculative next-TTI scan keep two TTIs' worth (by parity) */
   const bool spec = sched == 8 || sched == 9 || sched == 101 || sched == 103;
   c.off_items = off; off += rs_round_up((spec ? 4 : 2) * c.n_items, 16);
@@ -200,6 +202,9 @@ struct RsCellScalars {
   int32_t cqi_row;     /* trace row of the last CQI report (reloaded when a launch starts between reports) */
   int32_t pad_;
   int64_t heap_sorts[3]; /* diagnostics: heap-sort fallbacks of the sort emulation so far, per device site (rs_batch_debug_heap_sorts) */
+  /* diagnostics: the last launch's first and last instruction of this cell's thread 0 on the shader clock (s_memtime) and on the
+   * constant 100 MHz clock (s_memrealtime): their ratio is the shader clock the kernel really ran at (rs_batch_debug_clocks) */
+  uint64_t clk_begin, clk_end, real_begin, real_end;
 };
 
 enum { RS_CQI_NONE = 0, RS_CQI_EPOCHS = 1, RS_CQI_TRACE = 2 };

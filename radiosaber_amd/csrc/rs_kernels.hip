@@ -288,6 +288,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 
   const RsTables* tab = p.tab;
   RsCellScalars* scal = p.scal + cell;
+  if (!DIRECT && tid == 0) { /* (stored at once: nothing stays live across the launch) */
+    scal->clk_begin = __builtin_readcyclecounter();
+    scal->real_begin = __builtin_amdgcn_s_memrealtime();
+  }
 
   /* RadioBearer::m_cumulativeBytes / m_cumulativeRBs (ref: src/flows/radio-bearer.cpp:100-124).  A shape-specialised build
    * keeps them in registers of the thread that owns the user in P1: the serving lane of P5 leaves bytes | nPRB << 20 in
@@ -664,6 +668,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     scal->cqi_row = cqi_row;
     scal->served_prev = served_prev;
     scal->n_done = n_done;
+    if (!DIRECT) {
+      scal->clk_end = __builtin_readcyclecounter();
+      scal->real_end = __builtin_amdgcn_s_memrealtime();
+    }
     if (local_err) atomicExch(p.err, local_err);
     if constexpr (SCHED == 9 || SCHED == 10) { /* diagnostics: the sort emulation's heap-sort fallbacks (rs_sort_device.h), normally none */
 #pragma unroll

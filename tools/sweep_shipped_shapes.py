@@ -50,8 +50,8 @@ def distinct_shapes(cfgs, only=None):
     return sorted(by.values(), key=lambda n: (sum(cfgs[n]["ues_per_slice"]), n))
 
 
-def measure(rs, sc, sched, cells, threads, ttis, launches):
-    b = rs.BatchScheduler(sc, 64, 8, cells, sched=sched, threads_per_cell=threads, jit=True, cqi_epoch_wrap=True)
+def measure(rs, sc, sched, cells, threads, ttis, launches, autotune=False):
+    b = rs.BatchScheduler(sc, 64, 8, cells, sched=sched, threads_per_cell=threads, jit=True, cqi_epoch_wrap=True, autotune=autotune)
     try:
         code, msg = b.jit_status()
         if code != 1:
@@ -63,7 +63,7 @@ def measure(rs, sc, sched, cells, threads, ttis, launches):
         ms = b.run_timed(ttis, launches)
         code, msg = b.jit_status()
         return {"ttis_per_s": cells * ttis / (float(np.mean(ms)) / 1e3), "us_per_tti": float(np.mean(ms)) * 1e3 / ttis,
-                "ms": [round(float(x), 3) for x in ms], "jit_msg": msg}
+                "ms": [round(float(x), 3) for x in ms], "jit_msg": msg, "autotune": b.autotune_report()[1] if autotune else None}
     finally:
         b.close()
 
@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--out", default="gpurun_out/r05_shipped.json")
     ap.add_argument("--cells", type=int, default=512)
     ap.add_argument("--ab", action="store_true")
+    ap.add_argument("--autotune", action="store_true", help="one more run per (shape, scheduler 8 / 9) with rs_batch_config.autotune")
     ap.add_argument("--only", default=None)
     ap.add_argument("--scheds", default="9,8,7,1")
     args = ap.parse_args()
@@ -86,15 +87,17 @@ def main():
         for sched in [int(x) for x in args.scheds.split(",")]:
             ttis = 2000 if sched == 9 else 6000
             variants = [("default", {})] + (sorted(AB[sched].items()) if args.ab else [])
+            if args.autotune and sched in (8, 9):
+                variants.append(("autotune", {"autotune": True}))
             for vname, env in variants:
                 for k in ("RS_JIT_EXTRA", "RS_JIT_SCHED_STRATEGY"):
                     os.environ.pop(k, None)
                 for k, v in env.items():
-                    if k != "threads":
+                    if k not in ("threads", "autotune"):
                         os.environ[k] = v
                 t0 = time.time()
                 try:
-                    r = measure(rs, sc, sched, args.cells, env.get("threads", 0), ttis, 3)
+                    r = measure(rs, sc, sched, args.cells, env.get("threads", 0), ttis, 3, autotune=bool(env.get("autotune")))
                 except Exception as e:  # a variant that does not build or fit is a result too
                     r = {"error": str(e)[:300]}
                 r.update({"config": name, "slices": sc.n_slices, "ues": sc.n_users, "max_slice": max(c["ues_per_slice"]), "sched": sched,
