@@ -400,6 +400,7 @@ def main():
     kernel_name = batch.kernel_name
     batch_epochs, batch_wrap = batch.n_epochs_resident, batch.epochs_wrap
     jit_code, jit_msg = batch.jit_status()  # (before close: a closed batch has no status to read)
+    clk_mhz, cell_ms = batch.debug_clocks()  # the last timed launch, from the kernel's own s_memtime / s_memrealtime readings
     batch.close()
 
     if rank == 0:
@@ -463,6 +464,9 @@ def main():
             "jit_extra": jit_extra, "jit_env": jit_env,
             "kernel_ms_per_launch": [round(float(x), 4) for x in ms],
             "kernel_ms_mean_per_rank": rank_kernel_ms,
+            # the shader clock the last timed launch ran at (mean over the cells; the kernel reads both of its clocks at its first and
+            # last instruction) and the longest single cell's own run time: a lease whose GPU clocks lower shows here, not as a mystery
+            "shader_mhz": float(np.mean(clk_mhz)), "cell_ms_max": float(np.max(cell_ms)),
             "total_slice_bytes": total_bytes,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -30,3 +30,6 @@ shape s1_r25 --sched 1
 shape s1_u1000 --sched 1 --ues-per-slice 50
 shape s7_r25 --sched 7
 shape s7_u1000 --sched 7 --ues-per-slice 50
+# two of the reference's own experiment shapes (64 RBGs, ragged slices; profiles/r05_shipped_shapes.md)
+shape cfg_fixranues20_s9 --config-key exp-fixranues/20slices-ip/config-pf.json
+shape cfg_fix15_s8 --config-key exp-fix20slices/15ues-ip/config-pf.json --sched 8

@@ -17,7 +17,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 G = ROOT / "gpurun_out"
-ROUND = next((a for a in sys.argv[1:] if a.startswith("r") and a[1:].isdigit()), "r04")
+ROUND = next((a for a in sys.argv[1:] if a.startswith("r") and a[1:].isdigit()), "r05")
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 tags = sorted({Path(p).name[3:-len("_insts.log")] for p in glob.glob(str(G / "ps_*_insts.log"))})
 tf, inf = ROOT / "profiles" / "traffic.json", ROOT / "profiles" / "inst_counts.json"
