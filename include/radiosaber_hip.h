@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define RS_ABI_VERSION 10 /* 10: rs_batch_debug_heap_sorts / rs_ctx_debug_heap_sorts (the sort emulation's heap-sort fallback counted per device site),
-                               rs_jit_cache_stats / _file / _warm (code objects cached on disk), rs_batch_config.autotune + rs_batch_autotune_report;
+                               rs_jit_cache_stats / _file / _warm (code objects cached on disk), rs_batch_config.autotune + rs_batch_autotune_report, rs_batch_config.selfcheck, rs_batch_debug_clocks;
                             9: rs_create_checked / rs_batch_create_checked (RS_CREATE / RS_BATCH_CREATE: the caller's ABI version and struct size are
                             checked), rs_batch_config.cqi_epoch_wrap / queue_state_lds, threads_per_cell up to 1024 with jit, rs_jit_selfcheck_untuned, rs_batch_write_state, rs_ctx_specialize, rs_jit_selfcheck_dropin;
                             8: rs_jit_selfcheck_queue, rs_config.synthetic_exp, any integer algo_epsilon / algo_psi in drop-in contexts; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
@@ -253,7 +253,15 @@ typedef struct rs_batch_config {
                                 min(n_ttis, 512) TTIs from a snapshot of the whole cell state that is put back afterwards, and the
                                 fastest serves the batch.  Every variant is exact, so results do not depend on the choice; cost
                                 ~2 s of hiprtc per variant once per shape and machine (the code objects are cached on disk).
-                                rs_batch_autotune_report tells what was measured.  0 = the rule table alone.  (ABI 10)    */
+                                rs_batch_autotune_report tells what was measured.  0 = the rule table alone.  Every trial's final
+                                state is compared with the rule table's build: a variant that disagrees is never kept.  (ABI 10) */
+  int32_t selfcheck;         /* 1 (with jit = 1, up to 512 threads per cell): before the batch's first unlogged launch (or in
+                                rs_batch_prepare_launch) its next min(n_ttis, 256) TTIs run on the kernels built into the library and
+                                on its run-time compiled ones (general and lean build), each from the same snapshot of the whole cell
+                                state, which is put back; the final states must agree bit for bit.  The built-in kernels are one
+                                binary -- the one the GPU parity suite checks against the oracle --, a run-time build is a fresh
+                                compilation for this shape.  A build that disagrees is dropped: the batch runs on the built-in kernels
+                                and rs_batch_jit_status returns -2 with the reason.  (ABI 10)                              */
 } rs_batch_config;
 
 rs_batch* rs_batch_create(const rs_batch_config* cfg);
@@ -399,9 +407,10 @@ int rs_batch_write_state(rs_batch* b, const double* avg_rate, const double* slic
 /* the simulated clock of every cell (ref: src/core/eventScheduler/simulator.cc:117-126): t [n_cells] = time stamp of the next
  * TTI, last_update [n_cells] = RadioBearer::m_lastUpdate; either may be NULL */
 int rs_batch_read_clock(rs_batch* b, double* t, double* last_update);
-/* 1: the shape-specialised (hiprtc) kernel is in use (msg is empty, or says that the untuned variant had to be built);
- * 0: it was not asked for; -1: it was asked for and could not be built -- the built-in kernels run instead and msg
- * receives the reason */
+/* 1: the shape-specialised (hiprtc) kernel is in use (msg is empty, says that the untuned variant had to be built, or reports a
+ * passed rs_batch_config.selfcheck); 0: it was not asked for; -1: it was asked for and could not be built -- the built-in kernels
+ * run instead and msg receives the reason; -2: it was built and rs_batch_config.selfcheck found its results different from the
+ * built-in kernels': dropped, the built-in kernels run */
 int rs_batch_jit_status(rs_batch* b, char* msg, size_t msglen);
 /* what rs_batch_config.autotune measured: one line "variant: ms" per candidate and the one kept; empty before the tuning ran or
  * when it does not apply.  Returns the number of candidates timed (0: none). */

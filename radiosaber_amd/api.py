@@ -49,7 +49,7 @@ class _BatchConfig(C.Structure):
     _fields_ = [("cell", _Config), ("n_cells", C.c_int32), ("first_tti", C.c_int32),
                 ("cqi_refresh", C.c_int32), ("phy_error_draws", C.c_int32),
                 ("threads_per_cell", C.c_int32), ("jit", C.c_int32),
-                ("cqi_epoch_wrap", C.c_int32), ("queue_state_lds", C.c_int32), ("autotune", C.c_int32)]
+                ("cqi_epoch_wrap", C.c_int32), ("queue_state_lds", C.c_int32), ("autotune", C.c_int32), ("selfcheck", C.c_int32)]
 
 
 RS_ABI_VERSION = 10  # the include/radiosaber_hip.h these ctypes structs mirror; passed to the *_checked create functions
@@ -532,14 +532,14 @@ class BatchScheduler:
                  sched: int = RS_SCHED_MAXCELL, device: int = 0, first_tti: int = 100, cqi_refresh: int = 40,
                  phy_error_draws: bool = False, threads_per_cell: int = 0, stream: Optional[int] = None,
                  jit: bool = False, synthetic_exp: bool = False, cqi_epoch_wrap: bool = False, queue_state_lds: int = 0,
-                 autotune: bool = False):
+                 autotune: bool = False, selfcheck: bool = False):
         """synthetic_exp: the reference built with FIRST/SECOND_SYNTHETIC_EXP (transport blocks PRB by PRB; rs_config.synthetic_exp).
         cqi_epoch_wrap: the uploaded / synthesized epochs cycle instead of ending the run.  queue_state_lds: 0 auto, 1 LDS, -1 HBM."""
         self.slices, self.R, self.rbg_size, self.sched, self.n_cells = slices, n_rbgs, rbg_size, sched, n_cells
         self.S, self.U = slices.n_slices, slices.n_users
         self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream, synthetic_exp)
         bc = _BatchConfig(self._cfg.c, n_cells, first_tti, cqi_refresh, int(phy_error_draws), threads_per_cell,
-                          int(jit), int(bool(cqi_epoch_wrap)), int(queue_state_lds), int(bool(autotune)))
+                          int(jit), int(bool(cqi_epoch_wrap)), int(queue_state_lds), int(bool(autotune)), int(bool(selfcheck)))
         self._h = lib().rs_batch_create_checked(C.byref(bc), RS_ABI_VERSION, C.sizeof(_BatchConfig))
         if not self._h:
             raise RadioSaberError(-1, lib().rs_last_error().decode())

@@ -264,6 +264,9 @@ struct rs_batch {
   RsJitKernel* jit_lean = nullptr; /* its lean build, compiled at the first launch that can use it (launch()) */
   bool jit_lean_tried = false;
   bool autotuned = false;       /* rs_batch_config.autotune: the candidates were timed (or the tuning does not apply) */
+  bool selfchecked = false;     /* rs_batch_config.selfcheck: done (or it does not apply) */
+  bool jit_rejected = false;    /* ... and a run-time build disagreed with the built-in kernels: dropped */
+  char selfcheck_msg[160] = "";
   int autotune_n = 0;
   char autotune_msg[768] = "";
   void* d_snapshot = nullptr;   /* autotune: the whole cell state, put back after every trial */
@@ -505,6 +508,7 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   }
   if ((cfg->cqi_epoch_wrap | 1) != 1) { fail(RS_ERR_INVALID, "cqi_epoch_wrap %d is not 0 or 1", cfg->cqi_epoch_wrap); return nullptr; }
   if ((cfg->autotune | 1) != 1) { fail(RS_ERR_INVALID, "autotune %d is not 0 or 1", cfg->autotune); return nullptr; }
+  if ((cfg->selfcheck | 1) != 1) { fail(RS_ERR_INVALID, "selfcheck %d is not 0 or 1", cfg->selfcheck); return nullptr; }
   if (cfg->queue_state_lds < -1 || cfg->queue_state_lds > 1) { fail(RS_ERR_INVALID, "queue_state_lds %d outside -1..1", cfg->queue_state_lds); return nullptr; }
   if (cfg->cell.sched == RS_SCHED_UPPERBOUND) {
     /* the per-slice sorts use the register form of the sort emulation: at most four array positions per thread */
@@ -597,10 +601,64 @@ RsJitKernel* lean_kernel(rs_batch* b, int n_ttis, bool logged) {
 int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d_target, int32_t* d_tbs, int32_t* d_uinfo,
            uint32_t* d_keys = nullptr);
 
+/* ---- a device-side snapshot of the WHOLE cell state (PF averages, pending grants, cumulative counters, slice state, clock / rand()
+ * ring / CQI-report state): what rs_batch_config.autotune and .selfcheck put back after their trial launches ---- */
+struct StateParts {
+  struct Part { void* p; size_t n; };
+  Part parts[6];
+  size_t total = 0;
+  explicit StateParts(rs_batch* b) {
+    const size_t cells = b->n_cells, U = b->U, S = b->S;
+    const Part q[6] = {{b->d_avg, 8 * cells * U}, {b->d_tx, 4 * cells * U}, {b->d_cumb, 8 * cells * U}, {b->d_cumr, 8 * cells * U},
+                       {b->d_sstate, 8 * cells * S}, {b->d_scal, sizeof(RsCellScalars) * cells}};
+    for (int i = 0; i < 6; i++) { parts[i] = q[i]; total += (q[i].n + 255) & ~(size_t)255; }
+  }
+  hipError_t copy(rs_batch* b, void* snapshot, bool save) const {
+    size_t off = 0;
+    for (const Part& q : parts) {
+      void* snap = (char*)snapshot + off;
+      const hipError_t e = hipMemcpyAsync(save ? snap : q.p, save ? q.p : snap, q.n, hipMemcpyDeviceToDevice, b->stream);
+      if (e != hipSuccess) return e;
+      off += (q.n + 255) & ~(size_t)255;
+    }
+    return hipSuccess;
+  }
+};
+
+/* What a run leaves behind, in the form every kernel of a batch must agree on bit for bit: PF averages, cumulative bytes / RBs, slice
+ * state, the bytes of the pending grants (the shape-specialised kernels pack more into that word), clock, rand() ring and CQI-report
+ * state.  FNV-1a over the host copy (a few MB, once per trial). */
+int state_digest(rs_batch* b, unsigned long long* out) {
+  const size_t cells = b->n_cells, U = b->U, S = b->S;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  std::vector<unsigned char> h(8 * cells * U);
+  unsigned long long d = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t n) { const unsigned char* c = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { d ^= c[i]; d *= 1099511628211ull; } };
+  for (void* dev : {(void*)b->d_avg, (void*)b->d_cumb, (void*)b->d_cumr}) {
+    HIP_TRY(hipMemcpy(h.data(), dev, 8 * cells * U, hipMemcpyDeviceToHost));
+    mix(h.data(), 8 * cells * U);
+  }
+  HIP_TRY(hipMemcpy(h.data(), b->d_sstate, 8 * cells * S, hipMemcpyDeviceToHost));
+  mix(h.data(), 8 * cells * S);
+  std::vector<int32_t> tx(cells * U);
+  HIP_TRY(hipMemcpy(tx.data(), b->d_tx, 4 * cells * U, hipMemcpyDeviceToHost));
+  for (int32_t& v : tx) v &= RS_TX_BYTES_MASK;
+  mix(tx.data(), 4 * cells * U);
+  std::vector<RsCellScalars> sc(cells);
+  HIP_TRY(hipMemcpy(sc.data(), b->d_scal, sizeof(RsCellScalars) * cells, hipMemcpyDeviceToHost));
+  for (const RsCellScalars& c : sc) {
+    mix(&c.t, 8); mix(&c.last_update, 8); mix(&c.last_sent, 8); mix(&c.reported, 4); mix(&c.served_prev, 4); mix(&c.n_done, 8);
+    /* the ring in age order: the kernels may leave it rotated differently (f, b) with the same future */
+    for (int i = 0; i < 31; i++) { const uint32_t w = c.rng_r[(c.rng_f + i) % 31]; mix(&w, 4); }
+  }
+  *out = d;
+  return RS_OK;
+}
+
 /* rs_batch_config.autotune: time the lean kernel in the variants the rule table of rs_jit.cpp chooses between, on this batch's own
- * next TTIs, and keep the fastest.  Every trial starts from the same snapshot of the whole cell state (PF averages, pending
- * grants, counters, slice state, clock / rand() ring / CQI report state) and the snapshot is put back at the end, so the tuning
- * leaves no trace in the run; all variants compute the same results anyway (the parity tests run them against the oracle). */
+ * next TTIs, and keep the fastest.  Every trial starts from the same snapshot and the snapshot is put back at the end, so the tuning
+ * leaves no trace in the run.  All variants compute the same results (the parity tests run them against the oracle) -- and every
+ * trial's final state is compared with the rule table's: a variant that disagrees is never kept (and says so in the report). */
 int autotune(rs_batch* b, int n_ttis) {
   if (b->autotuned || !b->cfg.autotune) return RS_OK;
   if (!lean_kernel(b, n_ttis, false)) return RS_OK; /* this launch does not qualify for the lean build: try again at a later one */
@@ -613,33 +671,19 @@ int autotune(rs_batch* b, int n_ttis) {
   cand.push_back(ilp_by_rule ? "ss=default" : "ss=iterative-ilp");
   cand.push_back(b->R > 32 ? "-DRS_NO_SPEC" : "-DRS_NO_HOLD");
   if (sched == 9) cand.push_back("-DRS_P3_BLOCK=8");
-  const size_t cells = b->n_cells, U = b->U, S = b->S;
-  struct Part { void* p; size_t n; };
-  const Part parts[] = {{b->d_avg, 8 * cells * U}, {b->d_tx, 4 * cells * U}, {b->d_cumb, 8 * cells * U}, {b->d_cumr, 8 * cells * U},
-                        {b->d_sstate, 8 * cells * S}, {b->d_scal, sizeof(RsCellScalars) * cells}};
-  size_t total = 0;
-  for (const Part& q : parts) total += (q.n + 255) & ~(size_t)255;
-  HIP_TRY(hipMalloc(&b->d_snapshot, total));
-  auto copy_state = [&](bool save) -> hipError_t {
-    size_t off = 0;
-    for (const Part& q : parts) {
-      void* snap = (char*)b->d_snapshot + off;
-      const hipError_t e = hipMemcpyAsync(save ? snap : q.p, save ? q.p : snap, q.n, hipMemcpyDeviceToDevice, b->stream);
-      if (e != hipSuccess) return e;
-      off += (q.n + 255) & ~(size_t)255;
-    }
-    return hipSuccess;
-  };
+  const StateParts sp(b);
+  HIP_TRY(hipMalloc(&b->d_snapshot, sp.total));
   const int64_t done0 = b->ttis_done;
   const int trial = n_ttis < 512 ? n_ttis : 512;
   RsJitKernel* const k_default = b->jit_lean;
   RsJitKernel* best = k_default;
   float best_ms = 0, default_ms = 0;
+  unsigned long long default_digest = 0;
   int rc = RS_OK;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(copy_state(true));
+  HIP_TRY(sp.copy(b, b->d_snapshot, true));
   std::string report;
   for (size_t i = 0; i < cand.size() && rc == RS_OK; i++) {
     char msg[512] = "";
@@ -650,7 +694,7 @@ int autotune(rs_batch* b, int n_ttis) {
     b->jit_lean = k;
     float ms = 0;
     for (int rep = 0; rep < 3 && rc == RS_OK; rep++) { /* one warm launch, then the faster of two */
-      if (copy_state(false) != hipSuccess || hipEventRecord(e0, b->stream) != hipSuccess) { rc = fail(RS_ERR_HIP, "autotune: state restore failed"); break; }
+      if (sp.copy(b, b->d_snapshot, false) != hipSuccess || hipEventRecord(e0, b->stream) != hipSuccess) { rc = fail(RS_ERR_HIP, "autotune: state restore failed"); break; }
       rc = launch(b, trial, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
       if (rc) break;
       float t = 0;
@@ -661,7 +705,17 @@ int autotune(rs_batch* b, int n_ttis) {
       if (rep == 1 || (rep == 2 && t < ms)) ms = t;
     }
     if (rc) break;
-    char line[160];
+    unsigned long long digest = 0;
+    rc = state_digest(b, &digest);
+    if (rc) break;
+    if (i == 0) default_digest = digest;
+    char line[200];
+    if (digest != default_digest) {
+      /* never seen; if it ever is, the variant is a miscompiled kernel (profiles/r05_onelane.md) and must not serve the batch */
+      snprintf(line, sizeof line, "%s: %.3f ms, REJECTED: its state after the trial differs from the rule table's build; ", cand[i].c_str(), ms);
+      report += line;
+      continue;
+    }
     snprintf(line, sizeof line, "%s: %.3f ms; ", i == 0 ? "rule table" : cand[i].c_str(), ms);
     report += line;
     b->autotune_n++;
@@ -672,7 +726,7 @@ int autotune(rs_batch* b, int n_ttis) {
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   /* the run continues from where it was, whatever happened above */
-  const hipError_t back = copy_state(false);
+  const hipError_t back = sp.copy(b, b->d_snapshot, false);
   const hipError_t sync = hipStreamSynchronize(b->stream);
   b->ttis_done = done0;
   (void)hipFree(b->d_snapshot);
@@ -684,6 +738,62 @@ int autotune(rs_batch* b, int n_ttis) {
   if (rc) return rc;
   snprintf(b->autotune_msg, sizeof b->autotune_msg, "autotune over %d TTIs: %skept %s", trial, report.c_str(),
            best == k_default ? "the rule table's build" : "the fastest");
+  return RS_OK;
+}
+
+/* rs_batch_config.selfcheck: the batch's next min(n, 256) TTIs on the kernels built into the library and on its run-time compiled
+ * ones (general build, lean build), each from the same snapshot; the three final states must agree bit for bit (state_digest).  The
+ * built-in kernels are ONE binary, the one the GPU parity suite runs against the oracle; a run-time build is a fresh compilation for
+ * this shape, and round 4 met one that the compiler got wrong (profiles/r05_onelane.md).  A build that disagrees is dropped: the
+ * batch runs on the built-in kernels and rs_batch_jit_status returns -2 with the reason.  The snapshot is put back: no trace. */
+int selfcheck(rs_batch* b, int n_ttis) {
+  if (b->selfchecked || !b->cfg.selfcheck) return RS_OK;
+  b->selfchecked = true;
+  if (!b->jit || b->direct || b->threads > 512) return RS_OK; /* nothing run-time compiled, or no built-in kernel of this workgroup size */
+  const StateParts sp(b);
+  void* snap = nullptr;
+  HIP_TRY(hipMalloc(&snap, sp.total));
+  const int64_t done0 = b->ttis_done;
+  const int trial = n_ttis < 256 ? n_ttis : 256;
+  RsJitKernel* const k_gen = b->jit;
+  RsJitKernel* const k_lean = lean_kernel(b, n_ttis, false);
+  int rc = RS_OK;
+  unsigned long long want = 0, got = 0;
+  const char* bad = nullptr;
+  HIP_TRY(sp.copy(b, snap, true));
+  for (int v = 0; v < 3 && rc == RS_OK && !bad; v++) {
+    if (v == 2 && !k_lean) break;
+    /* v = 0: built-in (no run-time kernel visible to launch()), 1: the general build alone, 2: the lean build */
+    b->jit = v == 0 ? nullptr : k_gen;
+    RsJitKernel* const keep_lean = b->jit_lean;
+    const bool keep_tried = b->jit_lean_tried;
+    if (v < 2) { b->jit_lean = nullptr; b->jit_lean_tried = true; }
+    if (sp.copy(b, snap, false) != hipSuccess) rc = fail(RS_ERR_HIP, "selfcheck: state restore failed");
+    if (!rc) rc = launch(b, trial, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    b->jit_lean = keep_lean;
+    b->jit_lean_tried = keep_tried;
+    if (!rc) rc = state_digest(b, v == 0 ? &want : &got);
+    if (!rc && v > 0 && got != want) bad = v == 1 ? "general" : "lean";
+  }
+  b->jit = k_gen;
+  const hipError_t back = sp.copy(b, snap, false);
+  const hipError_t sync = hipStreamSynchronize(b->stream);
+  b->ttis_done = done0;
+  (void)hipFree(snap);
+  if (back != hipSuccess || sync != hipSuccess) return fail(RS_ERR_HIP, "selfcheck: the cell state could not be put back");
+  if (rc) return rc;
+  rc = check_device_err(b);
+  if (rc) return rc;
+  if (bad) {
+    b->jit = nullptr;
+    b->jit_lean = nullptr;
+    b->jit_lean_tried = true;
+    b->jit_rejected = true;
+    snprintf(b->jit_msg, sizeof b->jit_msg, "selfcheck: after %d TTIs the %s build of the shape-specialised kernel left a state that differs from the "
+             "built-in kernels': the batch runs on the built-in kernels (lint the code object: tools/lint_exec_restore.py)", trial, bad);
+  } else {
+    snprintf(b->selfcheck_msg, sizeof b->selfcheck_msg, "selfcheck over %d TTIs: built-in, general%s builds agree", trial, k_lean ? " and lean" : "");
+  }
   return RS_OK;
 }
 
@@ -726,8 +836,12 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
     L.q_flags = b->d_qflags; L.q_hol = b->d_qhol;
   }
   const bool logged = d_map || d_quota || d_target || d_tbs || d_uinfo || d_keys;
+  if (b->cfg.selfcheck && !b->selfchecked && !logged) {
+    const int rc = selfcheck(b, n_ttis); /* (its trials come back through here with `selfchecked` set) */
+    if (rc) return rc;
+  }
   if (b->cfg.autotune && !b->autotuned && !logged) {
-    const int rc = autotune(b, n_ttis); /* (its trials come back through here with `autotuned` set) */
+    const int rc = autotune(b, n_ttis);
     if (rc) return rc;
   }
   RsJitKernel* k = lean_kernel(b, n_ttis, logged);
@@ -1238,6 +1352,10 @@ int rs_batch_prepare_launch(rs_batch* b, int32_t n_ttis) {
   if (b->cqi_mode == RS_CQI_NONE) return fail(RS_ERR_STATE, "no CQI source set");
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   (void)lean_kernel(b, n_ttis > RS_MAX_TTIS_PER_LAUNCH ? RS_MAX_TTIS_PER_LAUNCH : n_ttis, false);
+  if (b->cfg.selfcheck && !b->selfchecked) {
+    const int rc = selfcheck(b, n_ttis > RS_MAX_TTIS_PER_LAUNCH ? RS_MAX_TTIS_PER_LAUNCH : n_ttis);
+    if (rc) return rc;
+  }
   if (b->cfg.autotune && !b->autotuned) {
     const int rc = autotune(b, n_ttis > RS_MAX_TTIS_PER_LAUNCH ? RS_MAX_TTIS_PER_LAUNCH : n_ttis);
     if (rc) return rc;
@@ -1248,6 +1366,8 @@ int rs_batch_prepare_launch(rs_batch* b, int32_t n_ttis) {
 int rs_batch_jit_status(rs_batch* b, char* msg, size_t msglen) {
   if (!b) return fail(RS_ERR_INVALID, "null batch");
   if (msg && msglen) snprintf(msg, msglen, "%s", b->jit_msg);
+  if (b->jit_rejected) return -2;
+  if (msg && msglen && b->jit && !b->jit_msg[0] && b->selfcheck_msg[0]) snprintf(msg, msglen, "%s", b->selfcheck_msg);
   return b->jit ? 1 : (b->jit_wanted ? -1 : 0);
 }
 

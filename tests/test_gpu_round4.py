@@ -64,7 +64,7 @@ def test_checked_create_refuses_another_abi_or_struct_size(rs):
     hdr = (ROOT / "include" / "radiosaber_hip.h").read_text()
     assert f"#define RS_ABI_VERSION {api.RS_ABI_VERSION} " in hdr
     assert hdr.index("int32_t cqi_epoch_wrap;") < hdr.index("int32_t queue_state_lds;") < hdr.index("} rs_batch_config;")
-    assert [f[0] for f in api._BatchConfig._fields_][-3:] == ["cqi_epoch_wrap", "queue_state_lds", "autotune"]
+    assert [f[0] for f in api._BatchConfig._fields_][-4:] == ["cqi_epoch_wrap", "queue_state_lds", "autotune", "selfcheck"]
 
 
 def test_jit_builds_without_the_llvm_tuning_options_and_for_640_threads(rs):

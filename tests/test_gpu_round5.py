@@ -120,3 +120,90 @@ def test_drop_in_completion_word(rs, oracle, monkeypatch, poll, jit):
         np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits, err_msg=f"call {it}")
         np.testing.assert_array_equal(res.quota_rbgs, out.quota_rbgs, err_msg=f"call {it}")
     ts.close()
+
+
+def _selfcheck_batch(rs, sched, ues, R, G, **kw):
+    sc = rs.SliceConfig(ues)
+    b = rs.BatchScheduler(sc, R, G, 3, sched=sched, jit=True, selfcheck=True, **kw)
+    b.seed(np.arange(3, dtype=np.uint32) + 5)
+    b.synthesize_cqi(11, 24)
+    return b
+
+
+@pytest.mark.parametrize("sched,ues,R,G", [(9, [25] * 20, 25, 4), (9, [5] * 20, 64, 8), (8, [10] * 20, 64, 8), (7, [25] * 20, 25, 4),
+                                           (1, [30] * 20, 25, 4), (103, [5] * 20, 25, 4), (101, [5] * 20, 25, 4), (10, [5] * 20, 25, 4),
+                                           (11, [5] * 20, 25, 4)])
+def test_selfcheck_passes_and_leaves_no_trace(rs, oracle, sched, ues, R, G):
+    """rs_batch_config.selfcheck: built-in, general and lean build agree on the batch's own next TTIs; the run afterwards is the
+    oracle's, as if nothing had happened."""
+    b = _selfcheck_batch(rs, sched, ues, R, G)
+    grids = [b.download_cqi_epochs(c) for c in range(3)]
+    b.run(30)
+    b.prepare_launch(400)
+    code, msg = b.jit_status()
+    assert code == 1 and "selfcheck over 256 TTIs" in msg and "agree" in msg, (code, msg)
+    assert b.ttis_done == 30
+    b.run(400)
+    st = b.state()
+    b.close()
+    for c in range(3):
+        cell = oracle.Cell(ues, R, G, sched)
+        cell.run_synth(grids[c], 5 + c, 430, log=False)
+        ost = cell.state()
+        np.testing.assert_array_equal(st["cum_bytes"][c], ost["cum_bytes"])
+        assert st["avg_rate"][c].tobytes() == ost["avg_rate"].tobytes()
+        assert st["slice_state"][c].tobytes() == ost["slice_state"].tobytes()
+
+
+def test_selfcheck_drops_a_wrong_run_time_build(rs, oracle, monkeypatch):
+    """A deliberately wrong shape-specialised build (one byte more per grant, -DRS_FAULT_INJECT_JIT): the self-check notices, the batch
+    falls back to the built-in kernels, says so (-2), and its results are the oracle's."""
+    monkeypatch.setenv("RS_JIT_EXTRA", "-DRS_FAULT_INJECT_JIT")
+    ues, R, G = [25] * 20, 25, 4
+    b = _selfcheck_batch(rs, 9, ues, R, G)
+    grids = [b.download_cqi_epochs(c) for c in range(3)]
+    assert b.kernel_name == "rs_cell_kernel_jit"
+    b.prepare_launch(300)
+    code, msg = b.jit_status()
+    assert code == -2 and "differs from the built-in" in msg, (code, msg)
+    assert b.kernel_name != "rs_cell_kernel_jit"
+    b.run(300)
+    st = b.state()
+    b.close()
+    for c in range(3):
+        cell = oracle.Cell(ues, R, G, 9)
+        cell.run_synth(grids[c], 5 + c, 300, log=False)
+        np.testing.assert_array_equal(st["cum_bytes"][c], cell.state()["cum_bytes"])
+    # without the self-check the wrong build would have served the batch -- the fault injection really bites
+    sc = rs.SliceConfig(ues)
+    b = rs.BatchScheduler(sc, R, G, 1, sched=9, jit=True)
+    b.seed(np.array([5], np.uint32))
+    b.synthesize_cqi(11, 24)
+    b.run(300)
+    cell = oracle.Cell(ues, R, G, 9)
+    cell.run_synth(grids[0], 5, 300, log=False)
+    assert (b.state()["cum_bytes"][0] != cell.state()["cum_bytes"]).any()
+    b.close()
+
+
+def test_autotune_never_keeps_a_variant_whose_state_differs(rs, oracle, monkeypatch):
+    """-DRS_FAULT_INJECT_P3B8 breaks exactly one autotune candidate of MaximizeCell (the 8-users-per-block build): the report says
+    REJECTED and the batch's results stay the oracle's."""
+    monkeypatch.setenv("RS_JIT_EXTRA", "-DRS_FAULT_INJECT_P3B8")
+    ues, R, G = [25] * 20, 25, 4
+    sc = rs.SliceConfig(ues)
+    b = rs.BatchScheduler(sc, R, G, 2, sched=9, jit=True, autotune=True)
+    b.seed(np.array([5, 6], np.uint32))
+    b.synthesize_cqi(11, 24)
+    grids = [b.download_cqi_epochs(c) for c in range(2)]
+    b.prepare_launch(600)
+    n, text = b.autotune_report()
+    assert "-DRS_P3_BLOCK=8" in text and "REJECTED" in text, text
+    b.run(600)
+    st = b.state()
+    b.close()
+    for c in range(2):
+        cell = oracle.Cell(ues, R, G, 9)
+        cell.run_synth(grids[c], 5 + c, 600, log=False)
+        np.testing.assert_array_equal(st["cum_bytes"][c], cell.state()["cum_bytes"])
+        assert st["avg_rate"][c].tobytes() == cell.state()["avg_rate"].tobytes()
