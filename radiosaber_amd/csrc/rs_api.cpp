@@ -265,6 +265,7 @@ struct rs_batch {
   bool jit_lean_tried = false;
   bool autotuned = false;       /* rs_batch_config.autotune: the candidates were timed (or the tuning does not apply) */
   bool selfchecked = false;     /* rs_batch_config.selfcheck: done (or it does not apply) */
+  bool selfchecked_general = false, selfchecked_lean = false;
   bool jit_rejected = false;    /* ... and a run-time build disagreed with the built-in kernels: dropped */
   char selfcheck_msg[160] = "";
   int autotune_n = 0;
@@ -628,30 +629,54 @@ struct StateParts {
 /* What a run leaves behind, in the form every kernel of a batch must agree on bit for bit: PF averages, cumulative bytes / RBs, slice
  * state, the bytes of the pending grants (the shape-specialised kernels pack more into that word), clock, rand() ring and CQI-report
  * state.  FNV-1a over the host copy (a few MB, once per trial). */
-int state_digest(rs_batch* b, unsigned long long* out) {
+struct StateDigest {
+  unsigned long long part[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; /* PF averages, cumulative bytes, cumulative RBs, slice state, pending grants' bytes, scalars */
+  bool operator==(const StateDigest& o) const { return memcmp(part, o.part, sizeof part) == 0; }
+  bool operator!=(const StateDigest& o) const { return !(*this == o); }
+  std::string diff(const StateDigest& o) const {
+    static const char* const names[10] = {"PF averages", "cumulative bytes", "cumulative RBs", "slice state", "pending grants", "simulated time",
+                                          "last EWMA update", "TTIs done", "users served in the last TTI", "rand() ring / CQI-report state"};
+    std::string d;
+    for (int i = 0; i < 10; i++)
+      if (part[i] != o.part[i]) d += std::string(d.empty() ? "" : ", ") + names[i];
+    return d;
+  }
+};
+int state_digest(rs_batch* b, StateDigest* out) {
   const size_t cells = b->n_cells, U = b->U, S = b->S;
   HIP_TRY(hipStreamSynchronize(b->stream));
   std::vector<unsigned char> h(8 * cells * U);
-  unsigned long long d = 1469598103934665603ull;
-  auto mix = [&](const void* p, size_t n) { const unsigned char* c = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { d ^= c[i]; d *= 1099511628211ull; } };
+  auto fnv = [](const void* p, size_t n, unsigned long long d = 1469598103934665603ull) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < n; i++) { d ^= c[i]; d *= 1099511628211ull; }
+    return d;
+  };
+  int k = 0;
   for (void* dev : {(void*)b->d_avg, (void*)b->d_cumb, (void*)b->d_cumr}) {
     HIP_TRY(hipMemcpy(h.data(), dev, 8 * cells * U, hipMemcpyDeviceToHost));
-    mix(h.data(), 8 * cells * U);
+    out->part[k++] = fnv(h.data(), 8 * cells * U);
   }
   HIP_TRY(hipMemcpy(h.data(), b->d_sstate, 8 * cells * S, hipMemcpyDeviceToHost));
-  mix(h.data(), 8 * cells * S);
+  out->part[3] = fnv(h.data(), 8 * cells * S);
   std::vector<int32_t> tx(cells * U);
   HIP_TRY(hipMemcpy(tx.data(), b->d_tx, 4 * cells * U, hipMemcpyDeviceToHost));
   for (int32_t& v : tx) v &= RS_TX_BYTES_MASK;
-  mix(tx.data(), 4 * cells * U);
+  out->part[4] = fnv(tx.data(), 4 * cells * U);
   std::vector<RsCellScalars> sc(cells);
   HIP_TRY(hipMemcpy(sc.data(), b->d_scal, sizeof(RsCellScalars) * cells, hipMemcpyDeviceToHost));
+  for (int i = 5; i < 10; i++) out->part[i] = 1469598103934665603ull;
   for (const RsCellScalars& c : sc) {
-    mix(&c.t, 8); mix(&c.last_update, 8); mix(&c.last_sent, 8); mix(&c.reported, 4); mix(&c.served_prev, 4); mix(&c.n_done, 8);
+    out->part[5] = fnv(&c.t, 8, out->part[5]);
+    out->part[6] = fnv(&c.last_update, 8, out->part[6]);
+    out->part[7] = fnv(&c.n_done, 8, out->part[7]);
+    /* (read by the error model's draws only: a lean build, which serves batches without them, does not keep it) */
+    if (b->cfg.phy_error_draws) out->part[8] = fnv(&c.served_prev, 4, out->part[8]);
+    unsigned long long d = out->part[9];
+    if (b->cqi_mode == RS_CQI_TRACE) { d = fnv(&c.last_sent, 8, d); d = fnv(&c.reported, 4, d); d = fnv(&c.cqi_row, 4, d); }
     /* the ring in age order: the kernels may leave it rotated differently (f, b) with the same future */
-    for (int i = 0; i < 31; i++) { const uint32_t w = c.rng_r[(c.rng_f + i) % 31]; mix(&w, 4); }
+    for (int i = 0; i < 31; i++) { const uint32_t w = c.rng_r[(c.rng_f + i) % 31]; d = fnv(&w, 4, d); }
+    out->part[9] = d;
   }
-  *out = d;
   return RS_OK;
 }
 
@@ -678,7 +703,7 @@ int autotune(rs_batch* b, int n_ttis) {
   RsJitKernel* const k_default = b->jit_lean;
   RsJitKernel* best = k_default;
   float best_ms = 0, default_ms = 0;
-  unsigned long long default_digest = 0;
+  StateDigest default_digest;
   int rc = RS_OK;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   HIP_TRY(hipEventCreate(&e0));
@@ -705,14 +730,15 @@ int autotune(rs_batch* b, int n_ttis) {
       if (rep == 1 || (rep == 2 && t < ms)) ms = t;
     }
     if (rc) break;
-    unsigned long long digest = 0;
+    StateDigest digest;
     rc = state_digest(b, &digest);
     if (rc) break;
     if (i == 0) default_digest = digest;
-    char line[200];
+    char line[320];
     if (digest != default_digest) {
       /* never seen; if it ever is, the variant is a miscompiled kernel (profiles/r05_onelane.md) and must not serve the batch */
-      snprintf(line, sizeof line, "%s: %.3f ms, REJECTED: its state after the trial differs from the rule table's build; ", cand[i].c_str(), ms);
+      snprintf(line, sizeof line, "%s: %.3f ms, REJECTED: its state after the trial differs from the rule table's build (%s); ", cand[i].c_str(), ms,
+               digest.diff(default_digest).c_str());
       report += line;
       continue;
     }
@@ -747,28 +773,39 @@ int autotune(rs_batch* b, int n_ttis) {
  * this shape, and round 4 met one that the compiler got wrong (profiles/r05_onelane.md).  A build that disagrees is dropped: the
  * batch runs on the built-in kernels and rs_batch_jit_status returns -2 with the reason.  The snapshot is put back: no trace. */
 int selfcheck(rs_batch* b, int n_ttis) {
-  if (b->selfchecked || !b->cfg.selfcheck) return RS_OK;
-  b->selfchecked = true;
-  if (!b->jit || b->direct || b->threads > 512) return RS_OK; /* nothing run-time compiled, or no built-in kernel of this workgroup size */
+  if (!b->cfg.selfcheck || b->selfchecked) return RS_OK;
+  if (!b->jit || b->direct || b->threads > 512) { b->selfchecked = true; return RS_OK; } /* nothing run-time compiled, or no built-in kernel of this workgroup size */
+  /* the general build at the first unlogged launch; the lean build at the first launch that qualifies for it (RS_JIT_LEAN_MIN_TTIS) */
+  RsJitKernel* const k_gen = b->jit;
+  RsJitKernel* const k_lean = lean_kernel(b, n_ttis, false);
+  const bool need_gen = !b->selfchecked_general, need_lean = k_lean && !b->selfchecked_lean;
+  if (!need_gen && !need_lean) return RS_OK;
+  b->selfchecked = true; /* (the trial launches come back through launch(): not again) */
   const StateParts sp(b);
   void* snap = nullptr;
   HIP_TRY(hipMalloc(&snap, sp.total));
   const int64_t done0 = b->ttis_done;
   const int trial = n_ttis < 256 ? n_ttis : 256;
-  RsJitKernel* const k_gen = b->jit;
-  RsJitKernel* const k_lean = lean_kernel(b, n_ttis, false);
   int rc = RS_OK;
-  unsigned long long want = 0, got = 0;
+  StateDigest want, got;
   const char* bad = nullptr;
   HIP_TRY(sp.copy(b, snap, true));
   for (int v = 0; v < 3 && rc == RS_OK && !bad; v++) {
-    if (v == 2 && !k_lean) break;
     /* v = 0: built-in (no run-time kernel visible to launch()), 1: the general build alone, 2: the lean build */
+    if ((v == 1 && !need_gen) || (v == 2 && !need_lean)) continue;
     b->jit = v == 0 ? nullptr : k_gen;
     RsJitKernel* const keep_lean = b->jit_lean;
     const bool keep_tried = b->jit_lean_tried;
     if (v < 2) { b->jit_lean = nullptr; b->jit_lean_tried = true; }
     if (sp.copy(b, snap, false) != hipSuccess) rc = fail(RS_ERR_HIP, "selfcheck: state restore failed");
+    if (!rc && v == 0) {
+      /* the snapshot was left by a shape-specialised kernel, whose pending-grant word is bytes | PRBs << 20 | "counted" << 30 (RS_TX_*,
+       * the grant is in the cumulative totals already); the built-in kernels keep plain bytes there (and count at grant time) */
+      std::vector<int32_t> tx((size_t)b->n_cells * b->U);
+      if (hipStreamSynchronize(b->stream) != hipSuccess || hipMemcpy(tx.data(), b->d_tx, 4 * tx.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RS_ERR_HIP, "selfcheck: copy failed");
+      for (int32_t& w : tx) w &= RS_TX_BYTES_MASK;
+      if (!rc && hipMemcpy(b->d_tx, tx.data(), 4 * tx.size(), hipMemcpyHostToDevice) != hipSuccess) rc = fail(RS_ERR_HIP, "selfcheck: copy failed");
+    }
     if (!rc) rc = launch(b, trial, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     b->jit_lean = keep_lean;
     b->jit_lean_tried = keep_tried;
@@ -790,10 +827,16 @@ int selfcheck(rs_batch* b, int n_ttis) {
     b->jit_lean_tried = true;
     b->jit_rejected = true;
     snprintf(b->jit_msg, sizeof b->jit_msg, "selfcheck: after %d TTIs the %s build of the shape-specialised kernel left a state that differs from the "
-             "built-in kernels': the batch runs on the built-in kernels (lint the code object: tools/lint_exec_restore.py)", trial, bad);
-  } else {
-    snprintf(b->selfcheck_msg, sizeof b->selfcheck_msg, "selfcheck over %d TTIs: built-in, general%s builds agree", trial, k_lean ? " and lean" : "");
+             "built-in kernels' in: %s; the batch runs on the built-in kernels (lint the code object: tools/lint_exec_restore.py)", trial, bad,
+             got.diff(want).c_str());
+    return RS_OK; /* (selfchecked stays set) */
   }
+  b->selfchecked_general |= need_gen;
+  b->selfchecked_lean |= need_lean;
+  snprintf(b->selfcheck_msg, sizeof b->selfcheck_msg, "selfcheck over %d TTIs: the built-in kernels and the %s build%s agree", trial,
+           b->selfchecked_lean ? "general and lean" : "general", b->selfchecked_lean ? "s" : "");
+  const char* const e_on = getenv("RS_JIT_LEAN");
+  b->selfchecked = b->selfchecked_lean || (e_on && atoi(e_on) == 0); /* the lean build is still to come: look again at the next launch */
   return RS_OK;
 }
 

@@ -138,10 +138,12 @@ def test_selfcheck_passes_and_leaves_no_trace(rs, oracle, sched, ues, R, G):
     oracle's, as if nothing had happened."""
     b = _selfcheck_batch(rs, sched, ues, R, G)
     grids = [b.download_cqi_epochs(c) for c in range(3)]
-    b.run(30)
-    b.prepare_launch(400)
+    b.run(30)                       # the general build is checked here (30 TTIs; too short a launch for the lean build)
     code, msg = b.jit_status()
-    assert code == 1 and "selfcheck over 256 TTIs" in msg and "agree" in msg, (code, msg)
+    assert code == 1 and "selfcheck over 30 TTIs" in msg and "general build agree" in msg, (code, msg)
+    b.prepare_launch(400)           # ... the lean build here
+    code, msg = b.jit_status()
+    assert code == 1 and "selfcheck over 256 TTIs" in msg and "general and lean builds agree" in msg, (code, msg)
     assert b.ttis_done == 30
     b.run(400)
     st = b.state()
