@@ -6,10 +6,10 @@
 #                                                     rs_trace_*, rs_internet_flow_arrivals, rs_link_tables, config validation, the
 #                                                     checked create functions, the hiprtc option handling
 #   3. tests/csrc/{sort_emul_check,umap_emul_check}.cpp   the host+device sort / unordered_map emulation against the real containers
-# then `pytest -m "not gpu"` with both libraries selected and libasan preloaded into python.  Output: profiles/r04_sanitizers.log
+# then `pytest -m "not gpu"` with both libraries selected and libasan preloaded into python.  Output: profiles/r05_sanitizers.log
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd); cd "$R"
-LOG=${1:-$R/profiles/r04_sanitizers.log}
+LOG=${1:-$R/profiles/r05_sanitizers.log}
 SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer"
 ASAN_LIB=$(g++ -print-file-name=libasan.so)
 STDCXX_LIB=$(g++ -print-file-name=libstdc++.so)  # preloaded too: ASan resolves __cxa_throw when it starts, and python itself does not link libstdc++
