@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define RS_ABI_VERSION 10 /* 10: rs_batch_debug_heap_sorts / rs_ctx_debug_heap_sorts (the sort emulation's heap-sort fallback counted per device site),
-                               rs_jit_cache_stats / _file / _warm (code objects cached on disk), rs_batch_config.autotune + rs_batch_autotune_report, rs_batch_config.selfcheck, rs_batch_debug_clocks;
+                               rs_jit_cache_stats / _file / _warm (code objects cached on disk), rs_batch_config.autotune + rs_batch_autotune_report, rs_batch_config.selfcheck, rs_batch_debug_clocks, rs_batch_checkpoint_bytes / _save / _load;
                             9: rs_create_checked / rs_batch_create_checked (RS_CREATE / RS_BATCH_CREATE: the caller's ABI version and struct size are
                             checked), rs_batch_config.cqi_epoch_wrap / queue_state_lds, threads_per_cell up to 1024 with jit, rs_jit_selfcheck_untuned, rs_batch_write_state, rs_ctx_specialize, rs_jit_selfcheck_dropin;
                             8: rs_jit_selfcheck_queue, rs_config.synthetic_exp, any integer algo_epsilon / algo_psi in drop-in contexts; 7: rs_device_source_hash; rs_schedule_tti accepts any double as avg_rate / hol_delay (exact scan outside the FP32 filter's range);
@@ -404,6 +404,17 @@ int rs_batch_read_state(rs_batch* b, double* avg_rate, int64_t* cum_bytes, int64
  * launch (or on a batch whose last grant was zero); after a launch the pending grant is applied on top of the new averages.  Not
  * with the queue model (one average per bearer there).  (ABI 9) */
 int rs_batch_write_state(rs_batch* b, const double* avg_rate, const double* slice_state);
+/* Checkpoint / resume (ABI 10).  A checkpoint is everything a batch carries from one launch to the next -- PF averages, the grants
+ * the next EWMA update consumes, cumulative counters, slice state, every cell's clock, rand() ring and CQI-report state, the number of
+ * TTIs done, and with the queue model the bearers' queues, averages and counters -- as one host block of rs_batch_checkpoint_bytes
+ * bytes.  rs_batch_checkpoint_load puts it into a batch of the same shape (slices, UEs, RBGs, PRBs per RBG, scheduler, cells, queue
+ * model or not; jit, threads_per_cell, device and process may differ), which then continues bit for bit like the batch that saved
+ * it: run 300 TTIs, save, run 300 more == load into a new batch, run 300.  The CQI source (epoch grids, trace tables, arrival bursts) is
+ * configuration, not state: set it on the resuming batch as on the first one (rs_batch_seed need not be called: the ring is in the
+ * block).  Between launches only.  rs_batch_read_state / rs_batch_write_state remain the partial accessors they were. */
+int64_t rs_batch_checkpoint_bytes(rs_batch* b);
+int rs_batch_checkpoint_save(rs_batch* b, void* buf, size_t buflen);
+int rs_batch_checkpoint_load(rs_batch* b, const void* buf, size_t buflen);
 /* the simulated clock of every cell (ref: src/core/eventScheduler/simulator.cc:117-126): t [n_cells] = time stamp of the next
  * TTI, last_update [n_cells] = RadioBearer::m_lastUpdate; either may be NULL */
 int rs_batch_read_clock(rs_batch* b, double* t, double* last_update);

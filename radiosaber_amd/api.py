@@ -97,6 +97,7 @@ ABI_SYMBOLS = [
     "rs_ctx_specialize", "rs_jit_selfcheck_dropin",
     "rs_batch_debug_heap_sorts", "rs_ctx_debug_heap_sorts",
     "rs_jit_cache_stats", "rs_jit_cache_file", "rs_jit_cache_warm", "rs_batch_autotune_report", "rs_batch_debug_clocks",
+    "rs_batch_checkpoint_bytes", "rs_batch_checkpoint_save", "rs_batch_checkpoint_load",
 ]
 
 _lib = None
@@ -173,6 +174,10 @@ def lib():
     L.rs_jit_cache_warm.argtypes = [C.c_int] * 7 + [C.c_char_p, C.c_size_t]
     L.rs_batch_autotune_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.rs_batch_debug_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rs_batch_checkpoint_bytes.restype = C.c_int64
+    L.rs_batch_checkpoint_bytes.argtypes = [C.c_void_p]
+    L.rs_batch_checkpoint_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.rs_batch_checkpoint_load.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.rs_batch_ttis_done.restype = C.c_int64
     L.rs_batch_ttis_done.argtypes = [C.c_void_p]
     L.rs_batch_stream.restype = C.c_void_p
@@ -692,6 +697,17 @@ class BatchScheduler:
     def prepare_launch(self, n_ttis):
         """Build now the kernel an unlogged run(n_ttis) would build at its first launch (the lean build): keeps hiprtc out of timed runs."""
         _check(lib().rs_batch_prepare_launch(self._h, int(n_ttis)))
+
+    def checkpoint(self):
+        """Everything the batch carries from one launch to the next, as bytes (rs_batch_checkpoint_save)."""
+        n = _count(lib().rs_batch_checkpoint_bytes(self._h))
+        buf = C.create_string_buffer(n)
+        _check(lib().rs_batch_checkpoint_save(self._h, buf, n))
+        return buf.raw
+
+    def restore(self, blob):
+        """Continue from a checkpoint of a batch of the same shape (rs_batch_checkpoint_load); set the CQI source first."""
+        _check(lib().rs_batch_checkpoint_load(self._h, blob, len(blob)))
 
     def debug_clocks(self):
         """(shader MHz [n_cells], ms [n_cells]) of the last launch, from the kernel's own two clocks (rs_batch_debug_clocks)."""

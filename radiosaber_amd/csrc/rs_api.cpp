@@ -1370,6 +1370,98 @@ int rs_batch_debug_heap_sorts(rs_batch* b, int64_t* out) {
   return RS_OK;
 }
 
+/* ---- checkpoint / resume (ABI 10): everything a batch carries from one launch to the next, as one host block ----
+ * header: magic "RSCK1", the shape it belongs to (S, U, R, G, sched, cells, queue model, threads are NOT part of it: any workgroup
+ * size continues a run), the number of scheduled TTIs so far, the kernel family that wrote the pending-grant words; then the device
+ * arrays verbatim.  The CQI source (epoch grids / trace tables / arrival bursts) is configuration, not state: the caller sets it
+ * again on the batch that resumes. */
+namespace {
+struct CkptHeader {
+  char magic[8];
+  int32_t S, U, R, G, sched, n_cells, queues, packed_tx; /* packed_tx: the pending-grant words were left by a shape-specialised kernel */
+  int64_t ttis_done;
+  uint64_t bytes; /* of the whole block */
+};
+struct CkptPart { void* p; size_t n; };
+std::vector<CkptPart> ckpt_parts(rs_batch* b) {
+  const size_t cells = b->n_cells, U = b->U, S = b->S, n2 = cells * 2 * U;
+  std::vector<CkptPart> v = {{b->d_avg, 8 * cells * U}, {b->d_tx, 4 * cells * U}, {b->d_cumb, 8 * cells * U}, {b->d_cumr, 8 * cells * U},
+                             {b->d_sstate, 8 * cells * S}, {b->d_scal, sizeof(RsCellScalars) * cells}};
+  if (b->queues) {
+    v.push_back({b->d_qi, 4 * 7 * n2});
+    v.push_back({b->d_bavg, 8 * n2});
+    v.push_back({b->d_bcum, 8 * 2 * n2});
+    v.push_back({b->d_qflags, cells * U});
+    v.push_back({b->d_qhol, 8 * cells * U});
+  }
+  return v;
+}
+}  // namespace
+
+int64_t rs_batch_checkpoint_bytes(rs_batch* b) {
+  if (!b) return fail(RS_ERR_INVALID, "null batch");
+  if (b->direct) return fail(RS_ERR_INVALID, "drop-in contexts carry slice_rbs_offset_ only: rs_get_slice_offset / rs_set_slice_offset");
+  size_t n = sizeof(CkptHeader);
+  for (const CkptPart& q : ckpt_parts(b)) n += q.n;
+  return (int64_t)n;
+}
+
+int rs_batch_checkpoint_save(rs_batch* b, void* buf, size_t buflen) {
+  const int64_t need = rs_batch_checkpoint_bytes(b);
+  if (need < 0) return (int)need;
+  if (!buf || buflen < (size_t)need) return fail(RS_ERR_INVALID, "checkpoint buffer of %zu bytes, %lld needed", buflen, (long long)need);
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  CkptHeader h{};
+  memcpy(h.magic, "RSCK1\0\0", 8);
+  h.S = b->S; h.U = b->U; h.R = b->R; h.G = b->G; h.sched = b->sched; h.n_cells = b->n_cells; h.queues = b->queues ? 1 : 0;
+  h.packed_tx = (b->jit && !b->queues) ? 1 : 0;
+  h.ttis_done = b->ttis_done;
+  h.bytes = (uint64_t)need;
+  memcpy(buf, &h, sizeof h);
+  char* out = (char*)buf + sizeof h;
+  for (const CkptPart& q : ckpt_parts(b)) {
+    HIP_TRY(hipMemcpy(out, q.p, q.n, hipMemcpyDeviceToHost));
+    out += q.n;
+  }
+  return RS_OK;
+}
+
+int rs_batch_checkpoint_load(rs_batch* b, const void* buf, size_t buflen) {
+  const int64_t need = rs_batch_checkpoint_bytes(b);
+  if (need < 0) return (int)need;
+  if (!buf || buflen < sizeof(CkptHeader)) return fail(RS_ERR_INVALID, "no checkpoint");
+  CkptHeader h;
+  memcpy(&h, buf, sizeof h);
+  if (memcmp(h.magic, "RSCK1\0\0", 8) != 0) return fail(RS_ERR_INVALID, "not a checkpoint (magic)");
+  if (h.S != b->S || h.U != b->U || h.R != b->R || h.G != b->G || h.sched != b->sched || h.n_cells != b->n_cells || h.queues != (b->queues ? 1 : 0))
+    return fail(RS_ERR_INVALID, "checkpoint of another batch: %d slices x %d UEs x %d RBGs x %d PRBs, sched %d, %d cells, queue model %d", h.S, h.U, h.R,
+                h.G, h.sched, h.n_cells, h.queues);
+  if (h.bytes != (uint64_t)need || buflen < (size_t)need) return fail(RS_ERR_INVALID, "checkpoint of %llu bytes, this batch's are %lld", (unsigned long long)h.bytes, (long long)need);
+  HIP_TRY(hipSetDevice(b->cfg.cell.device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const char* in = (const char*)buf + sizeof h;
+  for (const CkptPart& q : ckpt_parts(b)) {
+    if (q.p == (void*)b->d_tx && !b->queues) {
+      /* the pending-grant words follow the kernel family that will consume them: a shape-specialised kernel wants bytes | PRBs << 20 with
+       * "counted" set (the grant is in the cumulative totals already, whoever wrote it), the built-in kernels want plain bytes */
+      std::vector<int32_t> tx(q.n / 4);
+      memcpy(tx.data(), in, q.n);
+      const bool want_packed = b->jit != nullptr;
+      for (int32_t& w : tx) {
+        if (want_packed && !h.packed_tx) w = w ? (w | RS_TX_COUNTED) : 0; /* (no PRB count: it is in the totals, nothing reads it again) */
+        else if (!want_packed && h.packed_tx) w &= RS_TX_BYTES_MASK;
+      }
+      HIP_TRY(hipMemcpy(q.p, tx.data(), q.n, hipMemcpyHostToDevice));
+    } else {
+      HIP_TRY(hipMemcpy(q.p, in, q.n, hipMemcpyHostToDevice));
+    }
+    in += q.n;
+  }
+  b->ttis_done = h.ttis_done;
+  return RS_OK;
+}
+
 int rs_batch_debug_clocks(rs_batch* b, double* shader_mhz, double* kernel_ms) {
   if (!b) return fail(RS_ERR_INVALID, "null batch");
   HIP_TRY(hipSetDevice(b->cfg.cell.device));

@@ -209,3 +209,107 @@ def test_autotune_never_keeps_a_variant_whose_state_differs(rs, oracle, monkeypa
         cell.run_synth(grids[c], 5 + c, 600, log=False)
         np.testing.assert_array_equal(st["cum_bytes"][c], cell.state()["cum_bytes"])
         assert st["avg_rate"][c].tobytes() == cell.state()["avg_rate"].tobytes()
+
+
+def _fresh(rs, sched, ues, R, G, n_cells, grids, seeds, jit, threads=0, phy=False):
+    sc = rs.SliceConfig(ues)
+    b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=jit, threads_per_cell=threads, phy_error_draws=phy)
+    b.seed(seeds)
+    b.upload_cqi_epochs(grids)
+    return b
+
+
+@pytest.mark.parametrize("sched,ues,R,G,phy", [(9, [25] * 20, 25, 4, False), (9, [5] * 20, 64, 8, True), (8, [10] * 20, 25, 4, False),
+                                               (7, [25] * 20, 25, 4, True), (1, [30] * 20, 25, 4, False), (11, [5] * 20, 25, 4, False)])
+def test_checkpoint_resume_is_exact(rs, oracle, sched, ues, R, G, phy):
+    """run, save, run == load into a new batch, run -- bit for bit, across kernel families (the pending-grant words are converted) and
+    workgroup sizes, and the whole run is the oracle's."""
+    n_cells, n1, n2 = 2, 137, 263
+    U = sum(ues)
+    grids = synth_cqi(31, (n_cells, (n1 + n2 + 39) // 40, U, R), HIST)
+    seeds = np.arange(n_cells, dtype=np.uint32) + 77
+    ref = []
+    for c in range(n_cells):
+        cell = oracle.Cell(ues, R, G, sched)
+        cell.run_synth(grids[c], int(seeds[c]), n1 + n2, phy_error_draws=int(phy), log=False)
+        ref.append(cell.state())
+    for jit_a, jit_b, thr_b in ((True, True, 0), (True, False, 0), (False, True, 0), (True, True, 256), (False, False, 128)):
+        a = _fresh(rs, sched, ues, R, G, n_cells, grids, seeds, jit_a, phy=phy)
+        a.run(n1)
+        blob = a.checkpoint()
+        a.run(n2)
+        st_a = a.state()
+        a.close()
+        b = _fresh(rs, sched, ues, R, G, n_cells, grids, np.zeros(n_cells, np.uint32), jit_b, threads=thr_b, phy=phy)  # (another seed: the ring comes from the block)
+        b.restore(blob)
+        assert b.ttis_done == n1
+        b.run(n2)
+        st_b = b.state()
+        t_b = b.clock()
+        b.close()
+        for k in ("cum_bytes", "cum_rbs"):
+            np.testing.assert_array_equal(st_a[k], st_b[k], err_msg=f"{k} {jit_a}->{jit_b}")
+        assert st_a["avg_rate"].tobytes() == st_b["avg_rate"].tobytes() and st_a["slice_state"].tobytes() == st_b["slice_state"].tobytes()
+        for c in range(n_cells):
+            np.testing.assert_array_equal(st_b["cum_bytes"][c], ref[c]["cum_bytes"])
+            np.testing.assert_array_equal(st_b["cum_rbs"][c], ref[c]["cum_rbs"])
+            assert st_b["avg_rate"][c].tobytes() == ref[c]["avg_rate"].tobytes()
+
+
+def test_checkpoint_refuses_what_does_not_fit(rs):
+    sc = rs.SliceConfig([5] * 4)
+    a = rs.BatchScheduler(sc, 12, 2, 2, sched=9)
+    a.seed(np.array([1, 2], np.uint32))
+    a.synthesize_cqi(1, 4)
+    a.run(50)
+    blob = a.checkpoint()
+    for other in (rs.BatchScheduler(sc, 12, 2, 3, sched=9), rs.BatchScheduler(sc, 12, 2, 2, sched=8), rs.BatchScheduler(rs.SliceConfig([5] * 3 + [6]), 12, 2, 2, sched=9)):
+        with pytest.raises(rs.RadioSaberError) as e:
+            other.restore(blob)
+        assert "another batch" in str(e.value)
+        other.close()
+    with pytest.raises(rs.RadioSaberError):
+        a.restore(blob[:100])
+    with pytest.raises(rs.RadioSaberError):
+        a.restore(b"x" * len(blob))
+    a.restore(blob)  # its own checkpoint: back to TTI 50
+    assert a.ttis_done == 50
+    a.close()
+
+
+def test_checkpoint_resume_with_the_queue_model(rs, oracle):
+    """The queue model's checkpoint carries the bearers' queues, averages and counters too."""
+    from test_gpu_queues import _random_bursts
+    ues, R, G, n_cells, n1, n2 = [4, 4, 4], 25, 4, 2, 90, 150
+    sc = rs.SliceConfig(ues, algo_alpha=[1, 0, 0], algo_beta=[1, 0, 0])
+    U = sc.n_users
+    kinds = np.zeros((U, 2), np.uint8)
+    kinds[:, 0] = rs.BEARER_QUEUE
+    kinds[4:, 0] = rs.BEARER_BACKLOG
+    kinds[:4, 1] = rs.BEARER_QUEUE
+    rng = np.random.default_rng(5)
+    bursts = {(c, u, k): _random_bursts(rng, n1 + n2, 5, 2500) for c in range(n_cells) for u in range(U) for k in range(2) if kinds[u, k] == rs.BEARER_QUEUE}
+    grids = synth_cqi(41, (n_cells, (n1 + n2 + 39) // 40, U, R), HIST)
+    seeds = np.array([3, 4], np.uint32)
+
+    def make(jit):
+        b = rs.BatchScheduler(sc, R, G, n_cells, sched=9, jit=jit)
+        b.seed(seeds)
+        b.upload_cqi_epochs(grids)
+        b.set_bearers(kinds)
+        b.set_arrivals(bursts)
+        return b
+    for jit in (False, True):
+        a = make(jit)
+        a.run(n1)
+        blob = a.checkpoint()
+        a.run(n2)
+        sa = a.bearer_state()
+        a.close()
+        b = make(jit)
+        b.restore(blob)
+        b.run(n2)
+        sb = b.bearer_state()
+        b.close()
+        for k in sa:
+            assert sa[k].tobytes() == sb[k].tobytes(), (k, jit)
