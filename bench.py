@@ -466,7 +466,8 @@ def main():
             "kernel_ms_mean_per_rank": rank_kernel_ms,
             # the shader clock the last timed launch ran at (mean over the cells; the kernel reads both of its clocks at its first and
             # last instruction) and the longest single cell's own run time: a lease whose GPU clocks lower shows here, not as a mystery
-            "shader_mhz": float(np.mean(clk_mhz)), "cell_ms_max": float(np.max(cell_ms)),
+            "shader_mhz": float(np.mean(clk_mhz)), "cell_ms_max": float(np.max(cell_ms)), "cell_ms_mean": float(np.mean(cell_ms)),
+            "cell_ms_min": float(np.min(cell_ms)), "compute_units": int(torch.cuda.get_device_properties(local_rank).multi_processor_count),
             "total_slice_bytes": total_bytes,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
