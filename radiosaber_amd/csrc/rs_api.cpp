@@ -271,6 +271,7 @@ struct rs_batch {
   int autotune_n = 0;
   char autotune_msg[768] = "";
   void* d_snapshot = nullptr;   /* autotune: the whole cell state, put back after every trial */
+  unsigned long long* d_prio_sum = nullptr; /* TTIs done by all cells of the running launch (the cells' issue-priority feedback) */
   bool jit_wanted = false;
   char jit_msg[512] = ""; /* why the shape-specialised kernel is not in use (empty: it is, or it was not asked for) */
   int64_t ttis_done = 0;
@@ -477,6 +478,22 @@ int batch_alloc(rs_batch* b) {
   L.slice_state = b->d_sstate; L.scal = b->d_scal; L.err = b->d_err; L.stamps = b->d_stamps;
   carve_lds(b, &L);
   if (L.lds_bytes > 160 * 1024) return fail(RS_ERR_INVALID, "cell needs %d B of LDS (> 160 KiB)", L.lds_bytes);
+  {
+    /* co-resident cells take turns at the issue priority (RS_SETPRIO, rs_kernels.hip) when the batch has more cells than the device has
+     * compute units -- the second dispatch round shares its CUs with the first, which would win every tie by age.  RS_PRIO_BALANCE=0 / 1
+     * overrides. */
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, b->cfg.cell.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    int mode = (!b->direct && b->n_cells > cus) ? 2 : 0; /* 2: feedback through a progress sum (rs_kernels.hip), 1: time windows, 0: off */
+    if (const char* e = getenv("RS_PRIO_BALANCE")) mode = b->direct ? 0 : atoi(e);
+    L.prio_round_cells = mode == 1 ? cus : 0;
+    if (mode == 2) {
+      HIP_TRY(hipMalloc(&b->d_prio_sum, 8));
+      HIP_TRY(hipMemset(b->d_prio_sum, 0, 8));
+      L.prio_sum = b->d_prio_sum;
+    }
+  }
   HIP_TRY(rs_prepare_kernels(160 * 1024));
   return RS_OK;
 }
@@ -887,6 +904,7 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
     const int rc = autotune(b, n_ttis);
     if (rc) return rc;
   }
+  if (L.prio_sum) HIP_TRY(hipMemsetAsync(L.prio_sum, 0, 8, b->stream)); /* (every launch counts from zero) */
   RsJitKernel* k = lean_kernel(b, n_ttis, logged);
   if (!k) k = b->jit;
   if (k) HIP_TRY(rs_jit_launch(k, &L, b->stream));
@@ -918,7 +936,7 @@ void rs_batch_destroy(rs_batch* b) {
   void* ptrs[] = {b->d_tab, b->d_weight, b->d_eps, b->d_psi, b->d_alpha, b->d_beta, b->d_user_slice, b->d_tbs_eff, b->d_avg, b->d_tx, b->d_cumb, b->d_cumr,
                   b->d_sstate, b->d_scal, b->d_epochs, b->d_trace, b->d_user_trace, b->d_err, b->d_slice_bytes, b->d_stamps,
                   b->d_bearer_kind, b->d_arr_off, b->d_arr_time, b->d_arr_nfull, b->d_arr_last, b->d_qi, b->d_bavg, b->d_bcum,
-                  b->d_qflags, b->d_qhol, b->d_epochs_prb, b->d_trace_prb, b->d_gen_num};
+                  b->d_qflags, b->d_qhol, b->d_epochs_prb, b->d_trace_prb, b->d_gen_num, b->d_prio_sum};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);

@@ -59,6 +59,8 @@ struct RsMisc {
   RsSpecFlags spec[2];           /* by TTI parity */
   int32_t grid_free;             /* TTIs of this launch whose serial wave is done reading the CQI grid (the next grid may be written over it) */
   int32_t heap_sorts[3];         /* diagnostics: std::__partial_sort fallbacks of this launch, per device site (rs_sort_device.h) */
+  int32_t prio_boost;            /* this cell is behind the batch's average progress: its waves ask for one issue-priority level more (RS_SETPRIO) */
+  int32_t pad3[3];
 };
 
 /* LDS carve of one cell (byte offsets from the dynamic LDS base), a pure function of the cell shape so
@@ -290,6 +292,13 @@ struct RsLaunch {
    * scope, after every thread's outputs): rs_schedule_tti polls it instead of waiting for the stream's completion signal */
   uint32_t* done_flag;
   uint32_t done_seq;
+  /* batches: cells per dispatch round = the device's compute units, when the batch puts exactly two cells on every CU (0: no
+   * priority balancing between co-resident cells, RS_SETPRIO in rs_kernels.hip) */
+  int32_t prio_round_cells;
+  /* ... or, preferred: feedback.  *prio_sum = TTIs done by all cells of this launch together (every cell adds RS_PRIO_PERIOD each
+   * RS_PRIO_PERIOD TTIs); a cell whose own count times n_cells is below it is behind the average and runs boosted until the next
+   * look.  nullptr: off.  Zeroed by the host before every launch. */
+  unsigned long long* prio_sum;
 };
 
 #endif /* RS_DEVICE_H_ */

@@ -73,6 +73,20 @@ __device__ __forceinline__ double rs_div_1000(double x) {
   const double r = __builtin_fma(-q, 1000.0, x);
   return __builtin_fma(r, 0.001, q);
 }
+/* Issue priorities with the co-resident cell in mind (round 5).  Two cells share a CU; at equal s_setprio the SIMDs' arbiters prefer
+ * the OLDER wave, so the cell that was dispatched first wins every tie for the whole launch: of the headline batch's 512 cells the
+ * first 256 finish an 8 000-TTI launch after 105.5 ms, the second 256 after 114.7 -- alone on their CUs for the last 9 ms
+ * (tools/cell_spread.py).  RS_SETPRIO(x) raises the level by one during the cell's own windows of the chip-wide 100 MHz clock
+ * (s_memrealtime, bit RS_PRIO_WINDOW_LOG2): even windows for cells of even dispatch round (blockIdx.x / compute units), odd windows
+ * for the others, so that each of two co-resident cells is preferred half of the time whatever their ages. */
+#ifndef RS_PRIO_WINDOW_LOG2
+#define RS_PRIO_WINDOW_LOG2 15 /* 2^15 ticks of 10 ns = 0.33 ms, about twenty TTIs */
+#endif
+#define RS_SETPRIO(x)                                                        \
+  do {                                                                       \
+    if (prio_boost) __builtin_amdgcn_s_setprio((x) < 3 ? (x) + 1 : 3);       \
+    else __builtin_amdgcn_s_setprio(x);                                      \
+  } while (0)
 #define RS_SPEC_NAP 2    /* s_sleep argument (x 64 cycles) while the scanning waves wait for the allocation */
 #define RS_SERIAL_PRIO 3 /* issue priority of the wave that runs the serial end of the TTI (inter-slice policy, link adaptation) */
 #define RS_SPEC_PRIO 0   /* issue priority of the scanning waves during the serial phase */
@@ -518,7 +532,22 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   constexpr bool kGridAhead = FIXED && RS_JIT_STREAMED && !DIRECT && (SCHED == 1 || SCHED == 7 || SCHED == 8 || SCHED == 101 || SCHED == 103);
 #endif
   bool grid_ahead = false; /* this TTI's grid was written during the previous TTI's serial phase */
+  /* (batches only; a launch argument says how many cells one dispatch round holds: 0 = no balancing) */
+  const int prio_class = (!DIRECT && p.prio_round_cells > 0) ? ((int)blockIdx.x / p.prio_round_cells) & 1 : 0;
+  const bool prio_windows = !DIRECT && p.prio_round_cells > 0 && p.prio_sum == nullptr;
+  const bool prio_feedback = !DIRECT && p.prio_sum != nullptr;
+  if (prio_feedback && tid == 0) m->prio_boost = 0; /* (the barriers of the first TTI lie between this and its first reader) */
+#ifndef RS_PRIO_PERIOD
+#define RS_PRIO_PERIOD 16 /* TTIs between two looks at the batch's progress */
+#endif
   for (int tti = 0; tti < p.n_ttis; ++tti) {
+    bool prio_boost = prio_windows && ((((int)(__builtin_amdgcn_s_memrealtime() >> RS_PRIO_WINDOW_LOG2)) ^ prio_class) & 1) != 0;
+    if (prio_feedback) {
+      /* Feedback (the default): every RS_PRIO_PERIOD TTIs thread 0 adds its cell's TTIs to the launch's sum and reads it back; behind
+       * the average = the sum exceeds my own count times the number of cells (the cells dispatched second, which lose every tie to
+       * the older cells on their CUs).  The flag is a word in LDS that every wave reads at the top of the TTI. */
+      prio_boost = rs_lds_load(&m->prio_boost) != 0;
+    }
     RS_STAMP(11);
     auto prb_ptr = [&](int user, int r2) -> const uint8_t* { /* the G PRBs of RBG r2 as `user` reported them */
       if (DIRECT) return p.prb_cqi + ((size_t)user * R + r2) * G;
@@ -588,7 +617,12 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
 #include "rs_phase_p5.inc"
     }
 #include "rs_phase_next.inc"
-    __builtin_amdgcn_s_setprio(0);
+    if (prio_feedback && tid == (nt > 64 ? 64 : 0) && ((tti + 1) & (RS_PRIO_PERIOD - 1)) == 0) {
+      /* (the first thread of wave 1, which is idle or early at the end of the TTI: the atomic's round trip is not on wave 0's path) */
+      const unsigned long long sum = atomicAdd(p.prio_sum, (unsigned long long)RS_PRIO_PERIOD) + RS_PRIO_PERIOD;
+      m->prio_boost = (unsigned long long)(tti + 1) * (unsigned long long)p.n_cells < sum ? 1 : 0;
+    }
+    RS_SETPRIO(0);
     RS_STAMP(7);
     __syncthreads();
     RS_STAMP(8);
