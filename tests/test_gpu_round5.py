@@ -313,3 +313,50 @@ def test_checkpoint_resume_with_the_queue_model(rs, oracle):
         b.close()
         for k in sa:
             assert sa[k].tobytes() == sb[k].tobytes(), (k, jit)
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_issue_priority_sharing_changes_no_result(rs, oracle, monkeypatch, mode):
+    """RS_PRIO_BALANCE (off / time windows / progress feedback) is scheduling only: more cells than compute units, every mode, bit-exact."""
+    monkeypatch.setenv("RS_PRIO_BALANCE", mode)
+    ues, R, G, n_cells, n_ttis = [3] * 6, 12, 2, 600, 70
+    sc = rs.SliceConfig(ues)
+    grids = synth_cqi(5, (n_cells, 2, sc.n_users, R), HIST)
+    seeds = np.arange(n_cells, dtype=np.uint32) + 1
+    for sched, jit in ((9, True), (9, False), (7, True), (8, True)):
+        b = rs.BatchScheduler(sc, R, G, n_cells, sched=sched, jit=jit)
+        b.seed(seeds)
+        b.upload_cqi_epochs(grids)
+        b.run(n_ttis)
+        st = b.state()
+        b.close()
+        for c in (0, 1, 255, 256, 511, 599):
+            cell = oracle.Cell(ues, R, G, sched)
+            cell.run_synth(grids[c], int(seeds[c]), n_ttis, log=False)
+            ost = cell.state()
+            np.testing.assert_array_equal(st["cum_bytes"][c], ost["cum_bytes"])
+            assert st["avg_rate"][c].tobytes() == ost["avg_rate"].tobytes()
+
+
+def test_co_resident_cells_finish_together(rs, monkeypatch):
+    """The headline batch (512 cells on 256 CUs): without the feedback the cells dispatched second finish ~8 % after the first ones
+    (they lose every issue tie by age); with it all cells finish within a fraction of that (each cell's own run time: rs_batch_debug_clocks)."""
+    spread = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("RS_PRIO_BALANCE", mode)
+        sc = rs.SliceConfig([25] * 20)
+        b = rs.BatchScheduler(sc, 25, 4, 512, sched=9, jit=True, cqi_epoch_wrap=True)
+        b.seed(np.arange(512, dtype=np.uint32) + 9)
+        b.synthesize_cqi(3, 64)
+        b.prepare_launch(2000)
+        b.run(2000)
+        b.run(2000)
+        _, ms = b.debug_clocks()
+        b.close()
+        spread[mode] = (float(ms[:256].mean()), float(ms[256:].mean()), float(ms.max() - ms.min()))
+    first0, second0, sp0 = spread["0"]
+    first2, second2, sp2 = spread["2"]
+    if rs.lib().rs_device_count() and second0 < 1.03 * first0:
+        pytest.skip(f"this device does not show the age effect ({first0:.2f} / {second0:.2f} ms)")
+    assert sp2 < 0.6 * sp0, spread
+    assert abs(second2 - first2) < 0.5 * (second0 - first0), spread
