@@ -76,16 +76,23 @@ constexpr int rs_upad_of(int U) {
   int k = (U + 7) / 8;
   return 8 * ((k & 1) ? k : k + 1);
 }
-/* sched 11 (NVS non-greedy sampler) scratch, at off_sortx: val f64[U][4] | hm f64[32][R] | draws u8[8192] |
- * ha u16[32][R] | pad | high u8[U] */
+/* sched 11 (NVS non-greedy sampler) scratch, at off_sortx: val f64[U][4] (a slice of up to 64 users: its 4 n metrics, then the
+ * u16 key table) | draws u8[draw bytes] | winner u16[batch][R] (metric index i * 4 + draw, 0x8000 = the metric is 0.0) | pad |
+ * high u8[U].  Round 5: a sample's RBG metrics are no longer stored as doubles (f64[batch][R], 16 ... 32 KB at 64 RBGs) -- the
+ * lane that adds them up reads them through the winner's metric index; with a 4 KB draw buffer that is two 500-UE x 64-RBG cells
+ * per CU instead of one. */
 #ifndef RS_UMAP_SCRATCH_BYTES
 #define RS_UMAP_SCRATCH_BYTES 272 /* sched 101 (SubOpt), at off_sortx: rs_umap_order's nxt u8[68] | bkt u8[128] | ord u8[64] */
 #endif
 #define RS_NVS_SAMPLES 300      /* num_sample, downlink-nvs-scheduler.cpp:430 */
-#define RS_NVS_DRAW_BYTES 8192  /* draws of one batch of samples */
+#define RS_NVS_DRAW_BYTES 8192  /* draws of two batches of samples (one being drawn while the other is scanned); 4096 where that keeps two cells per CU */
 #define RS_NVS_BATCH 64         /* samples per batch at most (one lane of wave 0 per sample adds up its RBGs); rs_carve picks 64 or 32 */
-constexpr int rs_nvs_scratch_bytes(int U, int R, int batch) {
-  return 32 * U + 8 * batch * R + RS_NVS_DRAW_BYTES + 2 * batch * R + 128 + (U + 15) / 16 * 16;
+/* RsCarve::nvs_seg of scheduler 11 carries both choices: samples per batch | draw-buffer KB << 8 */
+constexpr int rs_nvs_pack(int batch, int draw_bytes) { return batch | ((draw_bytes >> 10) << 8); }
+constexpr int rs_nvs_batch_of(int seg) { return seg & 0xff; }
+constexpr int rs_nvs_draw_of(int seg) { return (seg >> 8) << 10; }
+constexpr int rs_nvs_scratch_bytes(int U, int R, int seg) {
+  return 32 * U + rs_nvs_draw_of(seg) + 2 * rs_nvs_batch_of(seg) * R + 128 + (U + 15) / 16 * 16;
 }
 /* sched 7: the served slice is scanned in 8-aligned runs of nvs_seg users, one work item per (run, RBG); the run winners
  * (user u16 + metric f64 per RBG) are reduced per RBG in ascending order afterwards.  With slices of more than 32 users on
@@ -122,7 +129,7 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
   c.off_tx = off; off += rs_round_up(4 * U, 16);
   c.off_misc = off; off += rs_round_up((int)sizeof(RsMisc), 16);
   c.off_tbs = off; off += rs_round_up(4 * 16 * (R + 1), 16); /* TBS bits of n RBGs at a final CQI */
-  c.off_elems = off; off += rs_round_up(pf_like ? 8 * c.n_items : 4 * R * S, 16);
+  c.off_elems = off; off += sched == 11 ? 0 : rs_round_up(pf_like ? 8 * c.n_items : 4 * R * S, 16); /* (the sampler keeps no records) */
   /* (the sorted / alternate record array: the transport schedulers only -- 1, 7 and 11 keep winner tables; without it a 600-UE x 64-RBG
    * cell of the per-flow PF scheduler is 77 824 B instead of 82 944: two cells per CU, round 5) */
   c.off_sorted = off; off += (sched == 1 || sched == 7 || sched == 11) ? 0 : rs_round_up(4 * R * S, 16);
@@ -165,13 +172,15 @@ constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads, int queu
   }
   if (nvs_long) return rs_carve_with(S, U, R, sched, threads, 32);
   if (sched == 11) {
-    /* the sampler's batch (carried in nvs_seg, which scheduler 7 alone reads as a run length): 64 samples -- half the barriers,
-     * fuller scan rounds: 15.3 against 13.0 M TTIs/s at 500 UEs x 25 RBGs -- unless that is what takes the cell over 80 KB (two
-     * cells per CU: 100 UEs x 64 RBGs 12.1 M with 32 against 7.7 M with 64) */
-    const RsCarve c64 = rs_carve_with(S, U, R, sched, threads, 64);
-    if (c64.lds_bytes <= 80 * 1024) return c64;
-    const RsCarve c32 = rs_carve_with(S, U, R, sched, threads, 32);
-    return c32.lds_bytes <= 80 * 1024 ? c32 : c64;
+    /* the sampler's batch and draw buffer (carried in nvs_seg, which scheduler 7 alone reads as a run length): 64 samples -- half
+     * the barriers, fuller scan rounds: 15.3 against 13.0 M TTIs/s at 500 UEs x 25 RBGs -- and 8 KB of draws, unless a smaller choice
+     * is what keeps the cell within 80 KB (two cells per CU: 100 UEs x 64 RBGs 12.1 M with 32 against 7.7 M with 64) */
+    const RsCarve c0 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(64, RS_NVS_DRAW_BYTES));
+    if (c0.lds_bytes <= 80 * 1024) return c0;
+    const RsCarve c1 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(64, RS_NVS_DRAW_BYTES / 2));
+    if (c1.lds_bytes <= 80 * 1024) return c1;
+    const RsCarve c2 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(32, RS_NVS_DRAW_BYTES / 2));
+    return c2.lds_bytes <= 80 * 1024 ? c2 : c0;
   }
   return rs_carve_with(S, U, R, sched, threads, 0); /* sched 7 with small slices: one work item per RBG scans the whole slice */
 }

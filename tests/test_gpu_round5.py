@@ -360,3 +360,46 @@ def test_co_resident_cells_finish_together(rs, monkeypatch):
         pytest.skip(f"this device does not show the age effect ({first0:.2f} / {second0:.2f} ms)")
     assert sp2 < 0.6 * sp0, spread
     assert abs(second2 - first2) < 0.5 * (second0 - first0), spread
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ues,R,G,threads,jit", [
+    ([25] * 20, 64, 8, 0, True),        # the 64-RBG sweep shape: one sample per wave, lanes on the RBGs
+    ([25] * 20, 64, 8, 0, False),
+    # (the key table lives behind the slice's metrics in an array sized for U users: slices of up to ~U / 17.5 users at 64 RBGs)
+    ([8, 16, 32, 5] + [60] * 9, 64, 8, 0, True),   # slice sizes whose [R][n][4] rows sat 16- to 32-way on one LDS bank; 60: on doubles
+    ([13, 40, 1, 250, 240], 50, 4, 0, True),       # 50 RBGs: rows of 25 dwords need no padding; a 1-user slice; 250: 27 samples per batch
+    ([6, 0, 11, 3, 100], 34, 3, 64, False),        # one wave per cell: the generator wave scans too
+    ([29, 28, 31, 200, 210], 64, 8, 256, True),    # 28 users x 66 keys just fit (15 680 of 15 936 B), 29 and 31 scan on doubles
+    ([40, 10, 210, 200], 40, 3, 128, True),        # 42-key rows; the 40-user slice fills the array exactly
+])
+def test_sampler_wide_grids(rs, oracle, ues, R, G, threads, jit):
+    """ORACLE UNPINNED (sched 11).  Round 5: on grids of 33 ... 64 RBGs the sampler's scan takes one sample per wave (draws through
+    v_readlane, keys u16[n][4][Rk] with the RBG in the lanes) and a sample's row of RBG metrics is stored rotated by the sample
+    index (rs_phase_nvs_sampler.inc); device == oracle bit for bit on every form, error-model draws included."""
+    _check_batch(rs, oracle, 11, ues, R, G, n_cells=2, n_ttis=50, threads=threads, jit=jit, seed=31)
+    _check_batch(rs, oracle, 11, ues, R, G, n_cells=1, n_ttis=42, threads=threads, jit=jit, seed=32, phy=1)
+
+
+@pytest.mark.gpu
+def test_sampler_wide_grid_drop_in(rs, oracle):
+    """ORACLE UNPINNED (sched 11): the 64-RBG drop-in call (the caller's rand() values), built-in and shape-specialised."""
+    ues, R, G = [9] * 4, 64, 8
+    sc = rs.SliceConfig(ues)
+    for jit in (False, True):
+        ts = rs.TtiScheduler(sc, R, G, sched=11, jit=jit)
+        cell = oracle.Cell(ues, R, G, 11)
+        rng = np.random.default_rng(77)
+        for it in range(6):
+            cqi = synth_cqi(900 + it, (sc.n_users, R), HIST)
+            avg = rng.uniform(1e3, 5e6, sc.n_users)
+            sl = it % 4
+            ids = np.arange(sl * 9, sl * 9 + 9)
+            draws = rng.integers(0, 2**31 - 1, 300 * len(ids)).astype(np.int32)
+            cell.set_cqi(cqi)
+            out = cell.new_out()
+            assert cell.allocate_nongreedy(avg, sl, draws, out) == 0
+            res = ts.schedule_tti(cqi[ids], avg[ids], user_id=ids, rand_draws=draws)
+            np.testing.assert_array_equal(res.rbg_to_user, out.rbg_to_user)
+            np.testing.assert_array_equal(res.user_tbs_bits, out.user_tbs_bits[ids])
+        ts.close()
