@@ -77,7 +77,7 @@ constexpr int rs_upad_of(int U) {
   return 8 * ((k & 1) ? k : k + 1);
 }
 /* sched 11 (NVS non-greedy sampler) scratch, at off_sortx: val f64[U][4] (a slice of up to 64 users: its 4 n metrics, then the
- * u16 key table) | draws u8[draw bytes] | winner u16[batch][R] (metric index i * 4 + draw, 0x8000 = the metric is 0.0) | pad |
+ * u16 key table; rs_nvs_val_bytes) | draws u8[draw bytes] | winner u16[batch][R] (metric index i * 4 + draw, 0x8000 = the metric is 0.0) | pad |
  * high u8[U].  Round 5: a sample's RBG metrics are no longer stored as doubles (f64[batch][R], 16 ... 32 KB at 64 RBGs) -- the
  * lane that adds them up reads them through the winner's metric index; with a 4 KB draw buffer that is two 500-UE x 64-RBG cells
  * per CU instead of one. */
@@ -87,12 +87,26 @@ constexpr int rs_upad_of(int U) {
 #define RS_NVS_SAMPLES 300      /* num_sample, downlink-nvs-scheduler.cpp:430 */
 #define RS_NVS_DRAW_BYTES 8192  /* draws of two batches of samples (one being drawn while the other is scanned); 4096 where that keeps two cells per CU */
 #define RS_NVS_BATCH 64         /* samples per batch at most (one lane of wave 0 per sample adds up its RBGs); rs_carve picks 64 or 32 */
-/* RsCarve::nvs_seg of scheduler 11 carries both choices: samples per batch | draw-buffer KB << 8 */
-constexpr int rs_nvs_pack(int batch, int draw_bytes) { return batch | ((draw_bytes >> 10) << 8); }
+/* RsCarve::nvs_seg of scheduler 11 carries the three choices: samples per batch | draw-buffer KB << 8 | metric / key array in 16 B << 16 */
+constexpr int rs_nvs_pack(int batch, int draw_bytes, int val_bytes) { return batch | ((draw_bytes >> 10) << 8) | ((val_bytes >> 4) << 16); }
 constexpr int rs_nvs_batch_of(int seg) { return seg & 0xff; }
-constexpr int rs_nvs_draw_of(int seg) { return (seg >> 8) << 10; }
+constexpr int rs_nvs_draw_of(int seg) { return ((seg >> 8) & 0xff) << 10; }
+constexpr int rs_nvs_val_of(int seg) { return (seg >> 16) << 4; }
+/* key row of the wide grids (33 ... 64 RBGs): R rounded up to an odd number of dwords */
+constexpr int rs_nvs_rk(int R) { return (((R + 1) >> 1) & 1) ? ((R + 1) & ~1) : ((R + 1) & ~1) + 2; }
+/* a slice's 4 n metrics + its key table: u16[n][4][Rk] on the wide grids, u16[R][4 n + 2] otherwise (rows of an odd number of dwords:
+ * the lanes of a wave read one row each) */
+constexpr int rs_nvs_key_bytes(int n, int R) { return (R > 32 && R <= 64) ? n * (32 + 8 * rs_nvs_rk(R)) : 32 * n + 2 * R * (4 * n + 2); }
+/* the metric array: f64[4] per user of the served slice (any slice: 32 U), and behind the metrics of a slice of up to 64 users its key
+ * table -- room for the batch's longest slice when that is known (win: its 8-aligned window) and has at most 64 users, so that a
+ * cell of few slices scans on keys too (round 5; before, 32 U bounded the table: slices of up to ~U / 17 users at 64 RBGs) */
+constexpr int rs_nvs_val_bytes(int U, int R, int win, bool roomy) {
+  const int w = win > 0 && win < U ? win : U;
+  const int keyed = (roomy && w <= 64) ? rs_nvs_key_bytes(w, R) : 0;
+  return rs_round_up(keyed > 32 * U ? keyed : 32 * U, 16);
+}
 constexpr int rs_nvs_scratch_bytes(int U, int R, int seg) {
-  return 32 * U + rs_nvs_draw_of(seg) + 2 * rs_nvs_batch_of(seg) * R + 128 + (U + 15) / 16 * 16;
+  return rs_nvs_val_of(seg) + rs_nvs_draw_of(seg) + 2 * rs_nvs_batch_of(seg) * R + 128 + (U + 15) / 16 * 16;
 }
 /* sched 7: the served slice is scanned in 8-aligned runs of nvs_seg users, one work item per (run, RBG); the run winners
  * (user u16 + metric f64 per RBG) are reduced per RBG in ascending order afterwards.  With slices of more than 32 users on
@@ -175,12 +189,16 @@ constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads, int queu
     /* the sampler's batch and draw buffer (carried in nvs_seg, which scheduler 7 alone reads as a run length): 64 samples -- half
      * the barriers, fuller scan rounds: 15.3 against 13.0 M TTIs/s at 500 UEs x 25 RBGs -- and 8 KB of draws, unless a smaller choice
      * is what keeps the cell within 80 KB (two cells per CU: 100 UEs x 64 RBGs 12.1 M with 32 against 7.7 M with 64) */
-    const RsCarve c0 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(64, RS_NVS_DRAW_BYTES));
-    if (c0.lds_bytes <= 80 * 1024) return c0;
-    const RsCarve c1 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(64, RS_NVS_DRAW_BYTES / 2));
-    if (c1.lds_bytes <= 80 * 1024) return c1;
-    const RsCarve c2 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(32, RS_NVS_DRAW_BYTES / 2));
-    return c2.lds_bytes <= 80 * 1024 ? c2 : c0;
+    for (int roomy = 1; roomy >= 0; --roomy) { /* (room for the longest slice's keys only where it does not cost the second cell on the CU) */
+      const int val = rs_nvs_val_bytes(U, R, win, roomy != 0);
+      const RsCarve c0 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(64, RS_NVS_DRAW_BYTES, val));
+      if (c0.lds_bytes <= 80 * 1024) return c0;
+      const RsCarve c1 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(64, RS_NVS_DRAW_BYTES / 2, val));
+      if (c1.lds_bytes <= 80 * 1024) return c1;
+      const RsCarve c2 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(32, RS_NVS_DRAW_BYTES / 2, val));
+      if (c2.lds_bytes <= 80 * 1024) return c2;
+      if (roomy == 0) return c0;
+    }
   }
   return rs_carve_with(S, U, R, sched, threads, 0); /* sched 7 with small slices: one work item per RBG scans the whole slice */
 }

@@ -366,12 +366,15 @@ def test_co_resident_cells_finish_together(rs, monkeypatch):
 @pytest.mark.parametrize("ues,R,G,threads,jit", [
     ([25] * 20, 64, 8, 0, True),        # the 64-RBG sweep shape: one sample per wave, lanes on the RBGs
     ([25] * 20, 64, 8, 0, False),
-    # (the key table lives behind the slice's metrics in an array sized for U users: slices of up to ~U / 17.5 users at 64 RBGs)
+    # (the key table lives behind the slice's metrics, in an array sized for U users on doubles or for the batch's longest slice of <= 64 users with its keys)
     ([8, 16, 32, 5] + [60] * 9, 64, 8, 0, True),   # slice sizes whose [R][n][4] rows sat 16- to 32-way on one LDS bank; 60: on doubles
     ([13, 40, 1, 250, 240], 50, 4, 0, True),       # 50 RBGs: rows of 25 dwords need no padding; a 1-user slice; 250: 27 samples per batch
     ([6, 0, 11, 3, 100], 34, 3, 64, False),        # one wave per cell: the generator wave scans too
-    ([29, 28, 31, 200, 210], 64, 8, 256, True),    # 28 users x 66 keys just fit (15 680 of 15 936 B), 29 and 31 scan on doubles
+    ([29, 28, 31, 200, 210], 64, 8, 256, True),    # 210 > 64: the array is 32 U = 15 936 B; 28 users x 66 keys just fit (15 680), 29 and 31 scan on doubles
     ([40, 10, 210, 200], 40, 3, 128, True),        # 42-key rows; the 40-user slice fills the array exactly
+    ([10, 20, 30], 64, 8, 0, True),                # few slices: the key table is sized for the longest slice, not for 32 U bytes
+    ([10, 20, 30], 64, 8, 0, False),
+    ([64, 3], 25, 4, 0, True),
 ])
 def test_sampler_wide_grids(rs, oracle, ues, R, G, threads, jit):
     """ORACLE UNPINNED (sched 11).  Round 5: on grids of 33 ... 64 RBGs the sampler's scan takes one sample per wave (draws through
