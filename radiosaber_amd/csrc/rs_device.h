@@ -77,7 +77,7 @@ constexpr int rs_upad_of(int U) {
   return 8 * ((k & 1) ? k : k + 1);
 }
 /* sched 11 (NVS non-greedy sampler) scratch, at off_sortx: val f64[U][4] (a slice of up to 64 users: its 4 n metrics, then the
- * u16 key table; rs_nvs_val_bytes) | draws u8[draw bytes] | winner u16[batch][R] (metric index i * 4 + draw, 0x8000 = the metric is 0.0) | pad |
+ * u16 key table; rs_nvs_val_bytes) | draws u8[draw bytes] | winner u16[batch][R rounded up to 4] (metric index i * 4 + draw, 0x8000 = the metric is 0.0) | pad |
  * high u8[U].  Round 5: a sample's RBG metrics are no longer stored as doubles (f64[batch][R], 16 ... 32 KB at 64 RBGs) -- the
  * lane that adds them up reads them through the winner's metric index; with a 4 KB draw buffer that is two 500-UE x 64-RBG cells
  * per CU instead of one. */
@@ -92,11 +92,8 @@ constexpr int rs_nvs_pack(int batch, int draw_bytes, int val_bytes) { return bat
 constexpr int rs_nvs_batch_of(int seg) { return seg & 0xff; }
 constexpr int rs_nvs_draw_of(int seg) { return ((seg >> 8) & 0xff) << 10; }
 constexpr int rs_nvs_val_of(int seg) { return (seg >> 16) << 4; }
-/* key row of the wide grids (33 ... 64 RBGs): R rounded up to an odd number of dwords */
-constexpr int rs_nvs_rk(int R) { return (((R + 1) >> 1) & 1) ? ((R + 1) & ~1) : ((R + 1) & ~1) + 2; }
-/* a slice's 4 n metrics + its key table: u16[n][4][Rk] on the wide grids, u16[R][4 n + 2] otherwise (rows of an odd number of dwords:
- * the lanes of a wave read one row each) */
-constexpr int rs_nvs_key_bytes(int n, int R) { return (R > 32 && R <= 64) ? n * (32 + 8 * rs_nvs_rk(R)) : 32 * n + 2 * R * (4 * n + 2); }
+/* a slice's 4 n metrics + its key table u16[n][4][Q][4]: a row per (UE, draw), the RBGs in Q = ceil(R / 4) units of four */
+constexpr int rs_nvs_key_bytes(int n, int R) { return 32 * n + 32 * n * ((R + 3) / 4); }
 /* the metric array: f64[4] per user of the served slice (any slice: 32 U), and behind the metrics of a slice of up to 64 users its key
  * table -- room for the batch's longest slice when that is known (win: its 8-aligned window) and has at most 64 users, so that a
  * cell of few slices scans on keys too (round 5; before, 32 U bounded the table: slices of up to ~U / 17 users at 64 RBGs) */
@@ -106,7 +103,7 @@ constexpr int rs_nvs_val_bytes(int U, int R, int win, bool roomy) {
   return rs_round_up(keyed > 32 * U ? keyed : 32 * U, 16);
 }
 constexpr int rs_nvs_scratch_bytes(int U, int R, int seg) {
-  return rs_nvs_val_of(seg) + rs_nvs_draw_of(seg) + 2 * rs_nvs_batch_of(seg) * R + 128 + (U + 15) / 16 * 16;
+  return rs_nvs_val_of(seg) + rs_nvs_draw_of(seg) + 2 * rs_nvs_batch_of(seg) * ((R + 3) / 4 * 4) + 128 + (U + 15) / 16 * 16;
 }
 /* sched 7: the served slice is scanned in 8-aligned runs of nvs_seg users, one work item per (run, RBG); the run winners
  * (user u16 + metric f64 per RBG) are reduced per RBG in ascending order afterwards.  With slices of more than 32 users on
