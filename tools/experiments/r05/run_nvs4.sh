@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 5: the sampler (sched 11) on the reference's own exp-nongreedy shapes (20 slices x 10 / 20 / 30 UEs, 64 RBGs) and the sweep shapes,
-# this tree against the tree before the sampler work (scratch_nvs/ = git archive of that commit, built in the container), same lease
+# this tree against the tree before the sampler work, same lease.  scratch_nvs/ (git-ignored, travels with gpurun) is recreated HERE by:
+#   mkdir scratch_nvs && git archive 0583421 radiosaber_amd bench.py oracle include tests/golden tests/conftest.py | tar -x -C scratch_nvs && (cd scratch_nvs && python -m radiosaber_amd.build --force)
 cd $GRAFT_REPO_ROOT; O=$GRAFT_REPO_ROOT/gpurun_out/nvs_exp5; mkdir -p $O
 ab() { local dir=$1 tag=$2; shift 2
   (cd $dir && timeout 300 python bench.py --no-cpu-baseline --no-r64 --no-streamed --steps 3 --warmup 1 "$@" > $O/ab_$tag.log 2>&1)
