@@ -7,7 +7,7 @@ ab() { local tag=$1 extra=$2; shift 2
 import sys,json
 d=json.loads(sys.stdin.read()); print('%-14s %-28s %.2f M TTIs/s  %.3f us' % (sys.argv[1], sys.argv[2], d['value']/1e6, d['us_per_tti_per_cell']))" "$tag" "[$extra]" || tail -3 $O/ab_$tag.log
 }
-for x in "" "-DRS_NVS_SUM_AHEAD=1"; do
+for x in "" "-DRS_NVS_SUM_AHEAD=0"; do
   t=$(echo "$x" | tr -d ' -=' )
   ab r64_$t "$x" --sched 11 --ttis 1000 --rbgs 64 --rbg-size 8
   ab ng20_$t "$x" --sched 11 --ttis 1000 --ues-per-slice 20 --rbgs 64 --rbg-size 8
