@@ -137,6 +137,18 @@ def test_headline_shapes_keep_four_cells_per_cu(rs):
         rs.lds_bytes_per_cell(65, 500, 25)
 
 
+def test_sampler_cells_keep_two_per_cu(rs):
+    """Round 5: the NVS non-greedy sampler (sched 11) keeps 16-bit winner indices instead of metric doubles and no record array; a cell
+    of 20 slices x 25 UEs x 64 RBGs is exactly 81 920 B (two per CU; 128 000 B before: one), the reference's exp-nongreedy shapes
+    of 10 / 20 UEs per slice fit too (30 per slice: the 38 KB CQI grid keeps it at one).  The drop-in query knows no slice window
+    (the metric array is sized for U users)."""
+    assert rs.lds_bytes_per_cell(20, 500, 64, 11, 512) == 81920
+    for users in (200, 400):
+        assert rs.lds_bytes_per_cell(20, users, 64, 11, 512) <= 81920
+    assert rs.lds_bytes_per_cell(20, 600, 64, 11, 512) > 81920
+    assert rs.lds_bytes_per_cell(20, 500, 25, 11, 512) <= 81920
+
+
 def test_division_by_1000_in_three_operations_is_correctly_rounded():
     """The kernel replaces `averageRate /= 1000.0` by q = x * 0.001; r = fma(-q, 1000, x); fma(r, 0.001, q) (rs_div_1000, Markstein's
     theorem).  Checked here in exact rational arithmetic -- float(Fraction) rounds to nearest even, so an fma is one exact
