@@ -96,12 +96,14 @@ constexpr int rs_nvs_val_of(int seg) { return (seg >> 16) << 4; }
 constexpr int rs_nvs_key_bytes(int n, int R) { return 32 * n + 32 * n * ((R + 3) / 4); }
 /* the metric array: f64[4] per user of the served slice, and behind the metrics of a slice of up to 64 users its key table.  Sized for
  * the batch's longest slice (win: its 8-aligned window; U when that is not known) with its keys -- a cell of few slices scans on keys
- * too, a cell of many does not pay for U users (round 5) -- or, where only that keeps two cells on a CU, 32 U as before (the window
- * overstates the slice by up to 14 users: 500 UEs x 64 RBGs in slices of 25) */
-constexpr int rs_nvs_val_bytes(int U, int R, int win, bool longest) {
+ * too -- and for U users on doubles (32 U: what a ragged batch's shorter slices may use for their keys when the longest has more than
+ * 64 users), whichever is larger; where that costs the second cell on the CU, the smaller of the two that still serves the longest
+ * slice, then 32 U (the window overstates the slice by up to 14 users: 500 UEs x 64 RBGs in slices of 25) (round 5) */
+constexpr int rs_nvs_val_bytes(int U, int R, int win, int choice) { /* 0: the larger of the two, 1: the longest slice with its keys, 2: 32 U */
   const int w = win > 0 && win < U ? win : U;
   const int keyed = w <= 64 ? rs_nvs_key_bytes(w, R) : 0;
-  return rs_round_up(longest ? (keyed > 32 * w ? keyed : 32 * w) : 32 * U, 16);
+  const int longest = keyed > 32 * w ? keyed : 32 * w;
+  return rs_round_up(choice == 1 ? longest : (choice == 2 ? 32 * U : (longest > 32 * U ? longest : 32 * U)), 16);
 }
 constexpr int rs_nvs_scratch_bytes(int U, int R, int seg) {
   return rs_nvs_val_of(seg) + rs_nvs_draw_of(seg) + 2 * rs_nvs_batch_of(seg) * ((R + 3) / 4 * 4) + 128 + (U + 15) / 16 * 16;
@@ -187,8 +189,8 @@ constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads, int queu
     /* the sampler's batch and draw buffer (carried in nvs_seg, which scheduler 7 alone reads as a run length): 64 samples -- half
      * the barriers, fuller scan rounds: 15.3 against 13.0 M TTIs/s at 500 UEs x 25 RBGs -- and 8 KB of draws, unless a smaller choice
      * is what keeps the cell within 80 KB (two cells per CU: 100 UEs x 64 RBGs 12.1 M with 32 against 7.7 M with 64) */
-    for (int longest = 1; longest >= 0; --longest) {
-      const int val = rs_nvs_val_bytes(U, R, win, longest != 0);
+    for (int choice = 0; choice <= 2; ++choice) { /* the roomiest metric / key array that keeps two cells on a CU */
+      const int val = rs_nvs_val_bytes(U, R, win, choice);
       const RsCarve c0 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(64, RS_NVS_DRAW_BYTES, val));
       if (c0.lds_bytes <= 80 * 1024) return c0;
       const RsCarve c1 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(64, RS_NVS_DRAW_BYTES / 2, val));
@@ -196,7 +198,7 @@ constexpr RsCarve rs_carve(int S, int U, int R, int sched, int threads, int queu
       const RsCarve c2 = rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(32, RS_NVS_DRAW_BYTES / 2, val));
       if (c2.lds_bytes <= 80 * 1024) return c2;
     }
-    return rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(64, RS_NVS_DRAW_BYTES, rs_nvs_val_bytes(U, R, win, true)));
+    return rs_carve_with(S, U, R, sched, threads, rs_nvs_pack(64, RS_NVS_DRAW_BYTES, rs_nvs_val_bytes(U, R, win, 0)));
   }
   return rs_carve_with(S, U, R, sched, threads, 0); /* sched 7 with small slices: one work item per RBG scans the whole slice */
 }

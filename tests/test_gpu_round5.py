@@ -364,22 +364,24 @@ def test_co_resident_cells_finish_together(rs, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ues,R,G,threads,jit", [
-    ([25] * 20, 64, 8, 0, True),        # the 64-RBG sweep shape: one sample per wave, lanes on the RBGs
+    ([25] * 20, 64, 8, 0, True),        # the 64-RBG sweep shape: 16 lanes per sample, four samples per wave and pass
     ([25] * 20, 64, 8, 0, False),
-    # (the key table lives behind the slice's metrics, in an array sized for U users on doubles or for the batch's longest slice of <= 64 users with its keys)
-    ([8, 16, 32, 5] + [60] * 9, 64, 8, 0, True),   # slice sizes whose [R][n][4] rows sat 16- to 32-way on one LDS bank; 60: on doubles
-    ([13, 40, 1, 250, 240], 50, 4, 0, True),       # 50 RBGs: rows of 25 dwords need no padding; a 1-user slice; 250: 27 samples per batch
-    ([6, 0, 11, 3, 100], 34, 3, 64, False),        # one wave per cell: the generator wave scans too
-    ([29, 28, 31, 200, 210], 64, 8, 256, True),    # 210 > 64: the array is 32 U = 15 936 B; 28 users x 66 keys just fit (15 680), 29 and 31 scan on doubles
-    ([40, 10, 210, 200], 40, 3, 128, True),        # 42-key rows; the 40-user slice fills the array exactly
+    # (the key table u16[n][4][ceil(R / 4)][4] lives behind the slice's metrics: the array is sized for U users on doubles and for the
+    #  batch's longest slice of <= 64 users with its keys, rs_nvs_val_bytes)
+    ([8, 16, 32, 5] + [60] * 9, 64, 8, 0, True),   # slice sizes whose u16[R][n][4] rows of round 4 sat 16- to 32-way on one LDS bank
+    ([13, 40, 1, 250, 240], 50, 4, 0, True),       # 50 RBGs: 13 units, the last one half padding; a 1-user slice; 250: on doubles, few samples per step
+    ([6, 0, 11, 3, 100], 34, 3, 64, False),        # one wave per cell: it draws, scans and adds up in turn
+    ([29, 28, 31, 200, 210], 64, 8, 256, True),    # 210 > 64: the array is 32 U = 15 936 B; 29 users x 544 B just fit (15 776), 31 scan on doubles
+    ([40, 10, 210, 200], 40, 3, 128, True),        # 10 units per row; the 40-user slice's keys (14 080 B) under 32 U = 14 720
     ([10, 20, 30], 64, 8, 0, True),                # few slices: the key table is sized for the longest slice, not for 32 U bytes
     ([10, 20, 30], 64, 8, 0, False),
-    ([64, 3], 25, 4, 0, True),
+    ([64, 3], 25, 4, 0, True),                     # 64 users exactly; 7 units of four RBGs, the last with three of padding
 ])
 def test_sampler_wide_grids(rs, oracle, ues, R, G, threads, jit):
-    """ORACLE UNPINNED (sched 11).  Round 5: on grids of 33 ... 64 RBGs the sampler's scan takes one sample per wave (draws through
-    v_readlane, keys u16[n][4][Rk] with the RBG in the lanes) and a sample's row of RBG metrics is stored rotated by the sample
-    index (rs_phase_nvs_sampler.inc); device == oracle bit for bit on every form, error-model draws included."""
+    """ORACLE UNPINNED (sched 11).  Round 5: the sampler's packed scan (a lane owns four RBGs of one sample: one draw byte, one 8-byte
+    unit of keys, two packed 16-bit maxima per user), 16-bit winner indices in rows rotated by the sample index instead of metric
+    doubles, draws and winner rows in one pool split per served slice, the key table built beside the first step's draws
+    (rs_phase_nvs_sampler.inc); device == oracle bit for bit on every form, error-model draws included."""
     _check_batch(rs, oracle, 11, ues, R, G, n_cells=2, n_ttis=50, threads=threads, jit=jit, seed=31)
     _check_batch(rs, oracle, 11, ues, R, G, n_cells=1, n_ttis=42, threads=threads, jit=jit, seed=32, phy=1)
 
