@@ -64,28 +64,38 @@ def stdout_lines(rbg_to_user, final_cqi, target, quota, cqi_of, first_ts: int = 
     return out
 
 
+def _parse_counter_lines(lines: Iterable[str]):
+    """The numeric columns of every counter line, looked up by their labels: a line is "<ts> app: <A> cumu_bytes: <B> cumu_rbs: <K>
+    hol_delay: <H> user: <U> slice: <S>"; anything that does not start with a TTI stamp or lacks a label is not a counter line."""
+    want = ("app:", "cumu_bytes:", "cumu_rbs:", "slice:")
+    rows = []
+    for line in lines:
+        tok = line.split()
+        if not tok or not tok[0].isdigit():
+            continue
+        try:
+            rows.append([int(tok[0])] + [int(tok[tok.index(k) + 1]) for k in want])
+        except (ValueError, IndexError):
+            continue
+    return np.asarray(rows, np.int64).reshape(-1, 1 + len(want))
+
+
 def slice_throughput_from_log(lines: Iterable[str], n_users: int, n_slices: int, begin_ts: int = 0,
                               end_ts: int = 10000):
-    """plot_throughput.py:26-56 (get_cumubytes + the Mbps conversion): last cumu_bytes of every flow with
-    begin_ts < ts <= end_ts, divided by the window in seconds, summed per slice, x 8 / 1e6."""
-    cumu_bytes = [0.0] * n_users
-    cumu_rbs = [0.0] * n_users
-    flow_to_slice = [-1] * n_users
-    for line in lines:
-        words = line.split(" ")
-        if not words[0].isdigit():
-            continue
-        if int(words[0]) > end_ts:
-            break
-        if int(words[0]) > begin_ts:
-            flow = int(words[2])
-            flow_to_slice[flow] = int(words[12])
-            cumu_rbs[flow] = int(words[6]) / (end_ts / 1000)
-            cumu_bytes[flow] = int(words[4]) / (end_ts / 1000)
-    sb = [0.0] * n_slices
-    sr = [0.0] * n_slices
-    for f in range(n_users):
-        if flow_to_slice[f] >= 0:
-            sb[flow_to_slice[f]] += cumu_bytes[f]
-            sr[flow_to_slice[f]] += cumu_rbs[f]
-    return [x * 8 / (1000 * 1000) for x in sb], sr
+    """Per-slice throughput of one run's stderr, as the reference's evaluation defines it (what plot_throughput.py:26-56 computes):
+    for every flow the LAST cumu_bytes / cumu_rbs it printed at a stamp in (begin_ts, end_ts], over end_ts milliseconds in seconds,
+    summed over the flows of a slice; bytes as Mbit/s (x 8 / 1e6).  A flow that printed nothing in the window counts for nothing.
+    Returns (mbps[n_slices], rbs_per_s[n_slices]).  The stamps of a log ascend, so "the last line" is the row with the largest index."""
+    tab = _parse_counter_lines(lines)
+    mbps, rbs = np.zeros(n_slices), np.zeros(n_slices)
+    if tab.size:
+        ts, flow = tab[:, 0], tab[:, 1]
+        tab = tab[(ts > begin_ts) & (ts <= end_ts) & (flow >= 0) & (flow < n_users)]
+    if tab.size:
+        # the last row of each flow: first occurrence in the reversed table
+        flows, first_rev = np.unique(tab[::-1, 1], return_index=True)
+        last = tab[len(tab) - 1 - first_rev]
+        seconds = end_ts / 1000
+        np.add.at(mbps, last[:, 4], last[:, 2] / seconds)
+        np.add.at(rbs, last[:, 4], last[:, 3] / seconds)
+    return list(mbps * 8 / 1e6), list(rbs)

@@ -23,7 +23,8 @@ print(json.dumps({"size": n, "seconds": time.time() - t, "stats": rs.jit_cache_s
 
 
 def _child(cache_dir, lean=False, env_extra=None):
-    env = dict(os.environ, RS_JIT_CACHE_DIR=str(cache_dir))
+    # (comgr keeps a cache of its own under ~/.cache/comgr since ROCm 7: off here, so that a miss of OUR cache is a real hiprtc run)
+    env = dict(os.environ, RS_JIT_CACHE_DIR=str(cache_dir), AMD_COMGR_CACHE="0")
     env.pop("RS_JIT_CACHE", None)
     env.update(env_extra or {})
     r = subprocess.run([sys.executable, "-c", CHILD % (str(ROOT), SHAPE, lean, lean)], capture_output=True, text=True, env=env, timeout=600)
