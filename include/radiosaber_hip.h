@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
-#define RS_ABI_VERSION 10 /* 10: rs_batch_debug_heap_sorts / rs_ctx_debug_heap_sorts (the sort emulation's heap-sort fallback counted per device site),
+#define RS_ABI_VERSION 11 /* 11: rs_config.link_tables (RS_LINK_*) + rs_link_tables_pinned / rs_link_tables_compare, rs_tti_in.cqi_epoch (the context keeps the
+                               CQI image of an unchanged report set on the device), rs_ctx_jit_status (a specialised context checks its run-time build against the
+                               built-in kernel during its first calls), rs_batch_config.selfcheck -1 / 0 / 1 with run-time builds verified by default and the
+                               self-check mark in the cache file, rs_jit_compiler_identity (the compiler's full identity in the cache key);
+                            10: rs_batch_debug_heap_sorts / rs_ctx_debug_heap_sorts (the sort emulation's heap-sort fallback counted per device site),
                                rs_jit_cache_stats / _file / _warm (code objects cached on disk), rs_batch_config.autotune + rs_batch_autotune_report, rs_batch_config.selfcheck, rs_batch_debug_clocks, rs_batch_checkpoint_bytes / _save / _load;
                             9: rs_create_checked / rs_batch_create_checked (RS_CREATE / RS_BATCH_CREATE: the caller's ABI version and struct size are
                             checked), rs_batch_config.cqi_epoch_wrap / queue_state_lds, threads_per_cell up to 1024 with jit, rs_jit_selfcheck_untuned, rs_batch_write_state, rs_ctx_specialize, rs_jit_selfcheck_dropin;
@@ -102,7 +106,20 @@ typedef struct rs_config {
                                  * PRB, each with the MCS of its own CQI (downlink-transport-scheduler.cpp:653-659,
                                  * downlink-nvs-scheduler.cpp:336-342; the PDCCH record keeps the EESM MCS); schedulers 1 and 11 have
                                  * no such branch and ignore it.  (ABI 8)                                                      */
+  int32_t link_tables;          /* RS_LINK_*: where the EESM constants E[c] / X[k] come from (see rs_link_tables).  (ABI 11)    */
 } rs_config;
+
+/* The EESM constants are transcendental: the reference evaluates exp / pow / log / log10 with the libm of the machine it was built on
+ * (src/utility/eesm-effective-sinr.h:33-46, src/protocolStack/mac/AMCModule.cpp:253-261), and a final CQI can differ by one between two
+ * libms that round one of them differently.
+ *   RS_LINK_PINNED_GLIBC_2_35  the values glibc 2.35 (x86-64) gives -- the libm behind every fixture of this repository (SURVEY.md
+ *                              Appendix A, tests/golden/appendix_a.json) -- compiled into the library as data: results do not depend
+ *                              on the machine that runs the GPU
+ *   RS_LINK_HOST_LIBM          this host's libm, evaluated at create time exactly as the reference evaluates them: what a drop-in needs
+ *                              beside a reference built on the same machine
+ *   RS_LINK_DEFAULT (0)        batches: pinned; drop-in contexts (rs_create): host libm -- and when the two sets differ on this host,
+ *                              rs_create still succeeds and rs_last_error() carries one line that says where (empty otherwise) */
+enum { RS_LINK_DEFAULT = 0, RS_LINK_HOST_LIBM = 1, RS_LINK_PINNED_GLIBC_2_35 = 2 };
 
 const char* rs_last_error(void);   /* thread-local message of the last failing call */
 /* The structs of this header grow at their ends from one ABI version to the next, and the plain create functions below read them
@@ -122,6 +139,11 @@ int rs_device_count(void);         /* number of HIP devices (0 when none)       
  * final CQI of an allocation = 1 + #{k : x <= X[k]}, x = (sum of E over its PRBs) / nPRB; x == 0 -> 15.
  * Needs no GPU.  Returns RS_ERR_INVALID if the host libm is not monotone around a threshold. */
 int rs_link_tables(double eff[16], double kbps[16], double eesm_e[16], double eesm_x[16]);
+/* the same with E[c] / X[k] from the pinned glibc-2.35 set (eff / kbps are IEEE divisions of table integers: the same on any host) */
+int rs_link_tables_pinned(double eff[16], double kbps[16], double eesm_e[16], double eesm_x[16]);
+/* this host's libm against the pinned set: the number of E / X entries that differ (0: they agree), msg receives "E[c] host ... pinned
+ * ..." for each; RS_ERR_INVALID when the host's libm is not monotone around a threshold.  Needs no GPU. */
+int rs_link_tables_compare(char* msg, size_t msglen);
 
 /* replaces get_rbg_size() (ref: src/utility/eesm-effective-sinr.h:82-103): PRBs per RBG of a cell with nb_rbs PRBs
  * (<= 10: 1, <= 26: 2, <= 63: 3, <= 110: 4, <= 512: 8).  Above 512 the reference throws std::runtime_error: RS_ERR_INVALID. */
@@ -172,6 +194,13 @@ typedef struct rs_tti_in {
   const int32_t* data_to_transmit; /* RS_SCHED_PF, [n] bytes: FlowToSchedule::GetDataToTransmit(); a flow leaves the TTI's
                                       competition once the transport block of its PRBs so far carries data * 8 bits
                                       (downlink-packet-scheduler.cpp:253-265)                                               */
+  uint64_t cqi_epoch;       /* 0: no promise -- the CQI block is validated, copied and read on every call.  Non-zero: the caller's
+                               version number of `cqi` (or `cqi_prb`): it changes the number whenever ANY report changed.  The reference
+                               refreshes a UE's CQI every 40 TTIs (src/protocolStack/mac/enb-mac-entity.cc:38 CQI_INTERVAL,
+                               src/device/CqiManager/cqi-manager.cpp:115), so 39 calls of 40 see the grid of the call before.  A call
+                               whose cqi_epoch, n_users and user_id list equal the previous call's does not touch the caller's block:
+                               the kernel reads the image the context kept on the device (the grid in the layout of its LDS, HBM-resident)
+                               instead of n * R bytes over the host link, and the host skips the range check and the copy.  (ABI 11) */
 } rs_tti_in;
 
 /* What RBsAllocation() leaves behind (ref: :589-620 allocation lists + slice_rbs_offset_,
@@ -202,6 +231,16 @@ int rs_schedule_tti(rs_ctx* ctx, const rs_tti_in* in, rs_tti_out* out);
  * FP32 number -- with those per-call options as constants (RS_JIT_LEAN=0: the general one only).  RS_OK, or RS_ERR_HIP with the
  * context left on the kernels built into the library.  The C++ adapter calls it from its constructor.  (ABI 9) */
 int rs_ctx_specialize(rs_ctx* ctx);
+/* A specialised context does not trust its run-time build blindly (round 6): unless the code object came from the disk cache with the
+ * self-check mark of an earlier process, the first RS_DROPIN_SELFCHECK_CALLS (default 8) calls each of its two builds serves run on the
+ * kernel built into the library AS WELL, from the same slice state, and every field of rs_tti_out plus the slice state left behind is
+ * compared.  Agreement for all of them leaves the mark in the cache file; one difference drops the build for good -- that call and all
+ * later ones are served by the built-in kernel, the call still returns RS_OK with the built-in kernel's (correct) results, and
+ * rs_last_error() / rs_ctx_jit_status say which field of which user differed.  RS_JIT_SELFCHECK=0 switches the check off, =2 checks
+ * marked builds too.
+ * rs_ctx_jit_status: 1 = the specialised kernels serve the calls (msg: empty, or how many checked calls agreed), 0 = rs_ctx_specialize
+ * was not called, -1 = it failed to build, -2 = a build was dropped by the check (msg says what differed). */
+int rs_ctx_jit_status(rs_ctx* ctx, char* msg, size_t msglen);
 /* build check without a GPU: does that kernel compile for a context of this shape? (code size or a negative value) */
 int rs_jit_selfcheck_dropin(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, char* err, size_t errlen);
 /* slice_rbs_offset_ accessors (ref: downlink-transport-scheduler.h:38) */
@@ -255,13 +294,18 @@ typedef struct rs_batch_config {
                                 ~2 s of hiprtc per variant once per shape and machine (the code objects are cached on disk).
                                 rs_batch_autotune_report tells what was measured.  0 = the rule table alone.  Every trial's final
                                 state is compared with the rule table's build: a variant that disagrees is never kept.  (ABI 10) */
-  int32_t selfcheck;         /* 1 (with jit = 1, up to 512 threads per cell): before the batch's first unlogged launch (or in
-                                rs_batch_prepare_launch) its next min(n_ttis, 256) TTIs run on the kernels built into the library and
-                                on its run-time compiled ones (general and lean build), each from the same snapshot of the whole cell
-                                state, which is put back; the final states must agree bit for bit.  The built-in kernels are one
-                                binary -- the one the GPU parity suite checks against the oracle --, a run-time build is a fresh
-                                compilation for this shape.  A build that disagrees is dropped: the batch runs on the built-in kernels
-                                and rs_batch_jit_status returns -2 with the reason.  (ABI 10)                              */
+  int32_t selfcheck;         /* The self-check of a batch's run-time builds (jit = 1, up to 512 threads per cell): before the batch's first
+                                launch (or in rs_batch_prepare_launch) its next min(n_ttis, 256) TTIs run on the kernels built into the
+                                library and on its run-time compiled ones (general build; the lean build before the first launch that
+                                uses it), each from the same snapshot of the whole cell state -- bearers' queues included --, which is put
+                                back; the final states must agree bit for bit.  The built-in kernels are one binary -- the one the GPU
+                                parity suite checks against the oracle --, a run-time build is a fresh compilation for this shape.  A
+                                general build that disagrees is dropped: the batch runs on the built-in kernels and rs_batch_jit_status
+                                returns -2 with the reason; a lean build that disagrees alone is dropped alone.
+                                0 (default, ABI 11): every build that does not carry the self-check mark -- compiled by this process, or
+                                loaded from a cache file no process has checked yet; a build that passes gets the mark in its cache file,
+                                so only the first process of a campaign pays (RS_JIT_SELFCHECK=0 switches this default off).
+                                1: every build, marked or not.  -1: never.  (ABI 10; default on and -1 since ABI 11)            */
 } rs_batch_config;
 
 rs_batch* rs_batch_create(const rs_batch_config* cfg);
@@ -448,15 +492,22 @@ int rs_jit_selfcheck_queue(int n_slices, int n_users, int n_rbgs, int rbg_size, 
                            size_t errlen);
 /* ---- the run-time compiled kernels' cache on disk (ABI 10) ----
  * Every code object hiprtc produces (rs_batch_create with jit = 1, the lean / streamed variants, rs_ctx_specialize) is kept in
- * $RS_JIT_CACHE_DIR (default $XDG_CACHE_HOME/radiosaber_amd, else ~/.cache/radiosaber_amd), one file per (device source hash, full
- * hiprtc option list, hiprtc version); a later process loads it instead of compiling (~2 s per variant -> a few ms).  Files are
- * written under a temporary name and renamed; a file that does not check out (magic, key text, length, checksum) is compiled again
- * and replaced.  RS_JIT_CACHE=0 switches the cache off.
+ * $RS_JIT_CACHE_DIR (default $XDG_CACHE_HOME/radiosaber_amd, else ~/.cache/radiosaber_amd; created with mode 0700), one file per (device
+ * source hash, compiler identity -- see rs_jit_compiler_identity --, full hiprtc option list); a later process loads it instead of
+ * compiling (~2 s per variant -> a few ms).  Files are written under a temporary name and renamed; a file that does not check out
+ * (magic, key text, length, checksum), is not a regular file of the caller's own, or is writable by anybody else is compiled again and
+ * replaced (RS_JIT_CACHE_SHARED=1 accepts another account's read-only cache).  Its last 8 bytes say whether the object has passed a
+ * self-check against the built-in kernels ("VERIFIED"); a build that a self-check rejects is unlinked.  RS_JIT_CACHE=0 switches the
+ * cache off.
  * rs_jit_cache_stats: this process's hits, misses (= hiprtc runs), files written, files rejected.
  * rs_jit_cache_file: the file the batch kernel of a shape lives in (flags: 2 = streamed-CQI variant, 4 = lean build); returns its
  *   length, 0 when no cache directory can be named.
  * rs_jit_cache_warm: that kernel THROUGH the cache (compiles and stores on a miss); needs no GPU; code size or -1 with the log. */
 void rs_jit_cache_stats(long long out[4]);
+/* the compiler identity that is part of every cache key (ABI 11): hiprtc and HIP runtime versions down to the patch level, the clang
+ * version string of the compiler inside hiprtc with its LLVM commit (read from a two-line probe compilation), comgr's version.
+ * RS_JIT_COMPILER_ID replaces it (deployments that pin the toolchain themselves).  Needs no GPU. */
+const char* rs_jit_compiler_identity(void);
 int rs_jit_cache_file(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, int flags, char* out, size_t outlen);
 int rs_jit_cache_warm(int n_slices, int n_users, int n_rbgs, int rbg_size, int threads, int sched, int flags, char* err, size_t errlen);
 /* 16 hex digits: FNV-1a hash of the device sources this library was built from (and compiles at run time); measurement

@@ -106,10 +106,12 @@ class GpuDownlinkScheduler {
 
   /* ENodeB::UserEquipmentRecord::SetCQI at RBG granularity (enb-mac-entity.cc:189-191) */
   void SetCQI(int user_id, const uint8_t* cqi_per_rbg) {
+    ++cqi_epoch_; /* rs_tti_in.cqi_epoch: the reports changed (the reference: every CQI_INTERVAL = 40 TTIs, enb-mac-entity.cc:38) */
     for (int r = 0; r < nb_rbgs_; ++r) cqi_[(size_t)user_id * nb_rbgs_ + r] = cqi_per_rbg[r];
   }
   /* the full per-PRB vector, as UserEquipmentRecord::GetCQI() holds it (CQIs may differ inside an RBG) */
   void SetCQIPerPrb(int user_id, const int* cqi_per_prb) {
+    ++cqi_epoch_;
     if (cqi_prb_.empty()) cqi_prb_.assign(user_to_slice_.size() * (size_t)nb_rbs_, 10);
     for (int k = 0; k < nb_rbs_; ++k) cqi_prb_[(size_t)user_id * nb_rbs_ + k] = (uint8_t)cqi_per_prb[k];
     for (int r = 0; r < nb_rbgs_; ++r) cqi_[(size_t)user_id * nb_rbgs_ + r] = (uint8_t)cqi_per_prb[r * rbg_size_];
@@ -236,6 +238,8 @@ class GpuDownlinkScheduler {
     in.cqi = in_cqi_.data();
     in.avg_rate = in_avg_.data();
     in.cqi_prb = cqi_prb_.empty() ? nullptr : in_prb_.data();
+    /* between two SetCQI calls the library serves the grid from the image it kept on the device (it compares the user list itself) */
+    in.cqi_epoch = cqi_epoch_;
     in_hol_.resize(n);
     in_prio_.resize(n);
     for (int i = 0; i < n; ++i) {
@@ -361,6 +365,7 @@ class GpuDownlinkScheduler {
   std::vector<double> slice_ewma_time_;
   std::vector<BearerState> bearers_; /* [user][priority] */
   std::vector<uint8_t> cqi_, in_cqi_, cqi_prb_, in_prb_;
+  uint64_t cqi_epoch_ = 1; /* version number of cqi_ / cqi_prb_ (never 0: 0 means "no promise") */
   std::vector<double> in_avg_, in_hol_;
   std::vector<uint8_t> in_prio_;
   std::vector<int> in_draws_, upper_rbg_, upper_user_;

@@ -11,7 +11,7 @@
 #include "../mac-entity.h"
 
 DL_GPU_PF_PacketScheduler::DL_GPU_PF_PacketScheduler(std::string config_fname, int max_flows, int hip_device)
-    : DL_PF_PacketScheduler(config_fname), ctx_(NULL), hip_device_(hip_device), max_flows_(max_flows), nb_rbs_(0) {}
+    : DL_PF_PacketScheduler(config_fname), ctx_(NULL), hip_device_(hip_device), max_flows_(max_flows), nb_rbs_(0), cqi_epoch_(0) {}
 
 DL_GPU_PF_PacketScheduler::~DL_GPU_PF_PacketScheduler() { rs_destroy(ctx_); }
 
@@ -45,6 +45,7 @@ void DL_GPU_PF_PacketScheduler::RBsAllocation() {
     cfg.user_to_slice = u2s.data();
     cfg.stream = NULL;
     cfg.synthetic_exp = 0; /* DownlinkPacketScheduler::RBsAllocation has no synthetic-experiment branch */
+    cfg.link_tables = RS_LINK_HOST_LIBM; /* this machine's libm, like the CPU schedulers in the same binary */
     ctx_ = RS_CREATE(&cfg);
     if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
     (void)rs_ctx_specialize(ctx_); /* this shape's own build of the one-TTI kernel (~2 s at start-up; on failure the built-in kernels stay) */
@@ -53,7 +54,11 @@ void DL_GPU_PF_PacketScheduler::RBsAllocation() {
   if (nb_rbs != nb_rbs_) throw std::runtime_error("DL_GPU_PF_PacketScheduler: the PRB grid changed after the first TTI");
 
   /* the "users" of the C ABI are this scheduler's flows, ids = positions in the flow list (user_id NULL) */
-  std::vector<uint8_t> cqi_prb((size_t)n * nb_rbs);
+  /* (rs_tti_in.cqi_epoch: a flow's reports change every 40 TTIs; with the same flows and the same reports as the call before, the
+   * library schedules from the image it kept on the device) */
+  bool cqi_changed = cqi_prb_.size() != (size_t)n * nb_rbs;
+  cqi_prb_.resize((size_t)n * nb_rbs);
+  std::vector<uint8_t>& cqi_prb = cqi_prb_;
   std::vector<double> avg(n);
   std::vector<int> data(n);
   for (int i = 0; i < n; i++) {
@@ -61,7 +66,12 @@ void DL_GPU_PF_PacketScheduler::RBsAllocation() {
     /* the break at :253-265 (transport block >= dataToTransmit * 8): rs_tti_in.data_to_transmit carries every flow's queue */
     data[i] = f->GetDataToTransmit();
     const std::vector<int> fb = f->GetCqiFeedbacks();
-    for (int k = 0; k < nb_rbs; k++) cqi_prb[(size_t)i * nb_rbs + k] = (uint8_t)fb.at(k);
+    for (int k = 0; k < nb_rbs; k++) {
+      const uint8_t v = (uint8_t)fb.at(k);
+      uint8_t& slot = cqi_prb[(size_t)i * nb_rbs + k];
+      cqi_changed |= slot != v;
+      slot = v;
+    }
     avg[i] = f->GetBearer()->GetAverageTransmissionRate(); /* metric (se * 180000.) / avg, dl-pf-packet-scheduler.cpp:128-140 */
   }
   rs_tti_in in;
@@ -76,6 +86,8 @@ void DL_GPU_PF_PacketScheduler::RBsAllocation() {
   in.rand_draws = NULL;
   in.required_rbs = NULL;
   in.data_to_transmit = data.data();
+  if (cqi_changed) ++cqi_epoch_;
+  in.cqi_epoch = cqi_epoch_;
   int target = 0, quota = 0;
   std::vector<int> map(R), nprb(n), fcqi(n), mcs(n), tbs(n);
   rs_tti_out out;

@@ -22,6 +22,8 @@ class DL_GPU_PF_PacketScheduler : public DL_PF_PacketScheduler {
  private:
   rs_ctx* ctx_;
   int hip_device_, max_flows_, nb_rbs_;
+  std::vector<uint8_t> cqi_prb_;    /* the previous call's per-PRB reports (rs_tti_in.cqi_epoch) */
+  unsigned long long cqi_epoch_;    /* bumped when any report changed */
 };
 
 #endif /* DLGPUPFPACKETSCHEDULER_H_ */

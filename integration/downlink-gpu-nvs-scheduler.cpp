@@ -17,7 +17,7 @@
 
 DownlinkGpuNVSScheduler::DownlinkGpuNVSScheduler(std::string config_fname, bool is_nongreedy, int hip_device)
     : DownlinkNVSScheduler(config_fname, is_nongreedy), ctx_(NULL), hip_device_(hip_device), nongreedy_(is_nongreedy),
-      num_slices_(0), nb_rbs_(0) {
+      num_slices_(0), nb_rbs_(0), cqi_epoch_(0) {
   /* the keys the parent's constructor reads (downlink-nvs-scheduler.cpp:44-86); its members are private */
   std::ifstream ifs(config_fname);
   if (!ifs.is_open()) throw std::runtime_error("Fail to open configuration file.");
@@ -77,6 +77,7 @@ void DownlinkGpuNVSScheduler::RBsAllocation() {
 #if defined(FIRST_SYNTHETIC_EXP) || defined(SECOND_SYNTHETIC_EXP)
     cfg.synthetic_exp = 1; /* downlink-nvs-scheduler.cpp:336-342 (the sampler of :405-528 has no such branch: ignored there) */
 #endif
+    cfg.link_tables = RS_LINK_HOST_LIBM; /* this machine's libm, like the CPU schedulers in the same binary */
     ctx_ = RS_CREATE(&cfg);
     if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
     (void)rs_ctx_specialize(ctx_); /* this shape's own build of the one-TTI kernel (~2 s at start-up; on failure the built-in kernels stay) */
@@ -91,7 +92,12 @@ void DownlinkGpuNVSScheduler::RBsAllocation() {
     for (int b = 0; b < MAX_BEARERS; b++)
       if (users->at(i)->m_bearers[b] && b > slice_priority) slice_priority = b;
   std::vector<int> ids(n);
-  std::vector<uint8_t> cqi_prb((size_t)n * nb_rbs), prio_has_data(n, 1);
+  /* (rs_tti_in.cqi_epoch: the reports of the previous call stay in a member; a slice served twice in a row with unchanged reports
+   * is scheduled from the context's device-resident image -- the library compares the user list itself) */
+  bool cqi_changed = cqi_prb_.size() != (size_t)n * nb_rbs;
+  cqi_prb_.resize((size_t)n * nb_rbs);
+  std::vector<uint8_t>& cqi_prb = cqi_prb_;
+  std::vector<uint8_t> prio_has_data(n, 1);
   std::vector<double> avg(n), hol(n, 0.0);
   std::vector<int> required(n);
   for (int i = 0; i < n; i++) {
@@ -101,7 +107,12 @@ void DownlinkGpuNVSScheduler::RBsAllocation() {
     /* the gate at :299-300 (allocated PRBs < m_requiredRBs): rs_tti_in.required_rbs */
     required[i] = u->m_requiredRBs;
     const std::vector<int>& fb = u->GetCqiFeedbacks();
-    for (int k = 0; k < nb_rbs; k++) cqi_prb[(size_t)i * nb_rbs + k] = (uint8_t)fb.at(k);
+    for (int k = 0; k < nb_rbs; k++) {
+      const uint8_t v = (uint8_t)fb.at(k);
+      uint8_t& slot = cqi_prb[(size_t)i * nb_rbs + k];
+      cqi_changed |= slot != v;
+      slot = v;
+    }
     double k1 = 1, only = 0; /* :364-369: averageRate = 1; += every bearer's average */
     int nb = 0;
     for (int b = 0; b < MAX_BEARERS; b++)
@@ -134,6 +145,8 @@ void DownlinkGpuNVSScheduler::RBsAllocation() {
   in.rand_draws = nongreedy_ ? draws.data() : NULL;
   in.required_rbs = nongreedy_ ? NULL : required.data(); /* RBsAllocationNonGreedyPF has no such gate */
   in.data_to_transmit = NULL;
+  if (cqi_changed) ++cqi_epoch_;
+  in.cqi_epoch = cqi_epoch_;
   std::vector<int> target(num_slices_), quota(num_slices_), map(R), nprb(n), fcqi(n), mcs(n), tbs(n);
   rs_tti_out out;
   out.target_rbs = target.data();

@@ -31,7 +31,7 @@ int SchedOfInterSliceAlgo(int algo) {
 DownlinkGpuScheduler::DownlinkGpuScheduler(std::string config_fname, int interslice_algo, int hip_device)
     : DownlinkTransportScheduler(config_fname, interslice_algo),
       ctx_(NULL), hip_device_(hip_device), sched_(SchedOfInterSliceAlgo(interslice_algo)), num_slices_(0),
-      nb_rbs_(0), rbg_size_(0), any_alpha_(false) {
+      nb_rbs_(0), rbg_size_(0), any_alpha_(false), cqi_epoch_(0) {
   /* the same keys the parent's constructor reads (downlink-transport-scheduler.cpp:55-88) */
   std::ifstream ifs(config_fname);
   if (!ifs.is_open()) throw std::runtime_error("Fail to open configuration file.");
@@ -77,6 +77,7 @@ void DownlinkGpuScheduler::LazyCreate(int nb_rbs, int rbg_size) {
 #if defined(FIRST_SYNTHETIC_EXP) || defined(SECOND_SYNTHETIC_EXP)
   cfg.synthetic_exp = 1; /* the parent's transport block, :653-659 */
 #endif
+  cfg.link_tables = RS_LINK_HOST_LIBM; /* the EESM constants of THIS machine's libm, like the CPU schedulers linked into the same binary */
   ctx_ = RS_CREATE(&cfg);
   if (!ctx_) throw std::runtime_error(std::string("rs_create: ") + rs_last_error());
   (void)rs_ctx_specialize(ctx_); /* this shape's own build of the one-TTI kernel (~2 s at start-up; on failure the built-in kernels stay) */
@@ -96,7 +97,12 @@ void DownlinkGpuScheduler::RBsAllocation() {
 
   const int n = (int)users->size();
   std::vector<int> ids(n);
-  std::vector<uint8_t> cqi_prb((size_t)n * nb_rbs);
+  /* the per-PRB reports live in a member: a UE's CQI changes every CQI_INTERVAL = 40 TTIs (enb-mac-entity.cc:38, cqi-manager.cpp:115), so
+   * the gather below notices for free whether ANY byte differs from the previous TTI's and bumps rs_tti_in.cqi_epoch only then -- the
+   * library then serves 39 calls of 40 from the image it kept on the device (it checks the user list itself) */
+  bool cqi_changed = cqi_prb_.size() != (size_t)n * nb_rbs;
+  cqi_prb_.resize((size_t)n * nb_rbs);
+  std::vector<uint8_t>& cqi_prb = cqi_prb_;
   std::vector<double> avg(n), hol(n, 0.0);
   std::vector<uint8_t> prio_has_data(n, 1);
   /* slice_priority_ is private in the parent: highest priority among the bearers that have packets, per slice
@@ -114,7 +120,12 @@ void DownlinkGpuScheduler::RBsAllocation() {
     if (i && ids[i] <= ids[i - 1]) throw std::runtime_error("DownlinkGpuScheduler: users are not in ascending id order");
     /* the full per-PRB report: the metric reads PRB rbg*rbg_size (:536), link adaptation every allocated PRB (:643-646) */
     const std::vector<int>& fb = u->GetCqiFeedbacks();
-    for (int k = 0; k < nb_rbs; k++) cqi_prb[(size_t)i * nb_rbs + k] = (uint8_t)fb.at(k);
+    for (int k = 0; k < nb_rbs; k++) {
+      const uint8_t v = (uint8_t)fb.at(k);
+      uint8_t& slot = cqi_prb[(size_t)i * nb_rbs + k];
+      cqi_changed |= slot != v;
+      slot = v;
+    }
     /* ComputeSchedulingMetric :681-686: averageRate = 1; += every bearer's average.  The device forms 1 + avg[i];
      * ((1 + a0) + a1) - 1 is exact for averages >= 1, so two bearers keep the reference's summation order bit for bit */
     double k1 = 1, only = 0;
@@ -147,6 +158,8 @@ void DownlinkGpuScheduler::RBsAllocation() {
   in.rand_draws = NULL;
   in.required_rbs = NULL; /* DownlinkTransportScheduler::RBsAllocation has no per-user gate */
   in.data_to_transmit = NULL;
+  if (cqi_changed) ++cqi_epoch_;
+  in.cqi_epoch = cqi_epoch_; /* (never 0: starts at 1) */
 
   std::vector<int> target(num_slices_), quota(num_slices_), map(R), nprb(n), fcqi(n), mcs(n), tbs(n);
   std::vector<int> upper_rbg, upper_user;

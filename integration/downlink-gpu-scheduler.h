@@ -36,6 +36,8 @@ class DownlinkGpuScheduler : public DownlinkTransportScheduler {
   std::vector<int> user_to_slice_;
   std::vector<double> slice_weights_;
   std::vector<int> alpha_, beta_, epsilon_, psi_;
+  std::vector<uint8_t> cqi_prb_;    /* the previous TTI's per-PRB reports (rs_tti_in.cqi_epoch) */
+  unsigned long long cqi_epoch_;    /* bumped when any report changed */
 };
 
 #endif /* DOWNLINKGPUSCHEDULER_H_ */

@@ -42,7 +42,7 @@ class _Config(C.Structure):
                 ("slice_weight", C.POINTER(C.c_double)), ("algo_alpha", C.POINTER(C.c_int32)),
                 ("algo_beta", C.POINTER(C.c_int32)), ("algo_epsilon", C.POINTER(C.c_int32)),
                 ("algo_psi", C.POINTER(C.c_int32)), ("user_to_slice", C.POINTER(C.c_int32)),
-                ("stream", C.c_void_p), ("synthetic_exp", C.c_int32)]
+                ("stream", C.c_void_p), ("synthetic_exp", C.c_int32), ("link_tables", C.c_int32)]
 
 
 class _BatchConfig(C.Structure):
@@ -52,7 +52,9 @@ class _BatchConfig(C.Structure):
                 ("cqi_epoch_wrap", C.c_int32), ("queue_state_lds", C.c_int32), ("autotune", C.c_int32), ("selfcheck", C.c_int32)]
 
 
-RS_ABI_VERSION = 10  # the include/radiosaber_hip.h these ctypes structs mirror; passed to the *_checked create functions
+RS_LINK_DEFAULT, RS_LINK_HOST_LIBM, RS_LINK_PINNED_GLIBC_2_35 = 0, 1, 2  # rs_config.link_tables
+
+RS_ABI_VERSION = 11  # the include/radiosaber_hip.h these ctypes structs mirror; passed to the *_checked create functions
 
 
 class _TtiIn(C.Structure):
@@ -61,7 +63,7 @@ class _TtiIn(C.Structure):
                 ("rand0", C.c_int32), ("rand1", C.c_int32), ("cqi_prb", C.POINTER(C.c_uint8)),
                 ("hol_delay", C.POINTER(C.c_double)), ("prio_has_data", C.POINTER(C.c_uint8)),
                 ("rand_draws", C.POINTER(C.c_int32)),
-                ("required_rbs", C.POINTER(C.c_int32)), ("data_to_transmit", C.POINTER(C.c_int32))]
+                ("required_rbs", C.POINTER(C.c_int32)), ("data_to_transmit", C.POINTER(C.c_int32)), ("cqi_epoch", C.c_uint64)]
 
 
 class _TtiOut(C.Structure):
@@ -98,6 +100,7 @@ ABI_SYMBOLS = [
     "rs_batch_debug_heap_sorts", "rs_ctx_debug_heap_sorts",
     "rs_jit_cache_stats", "rs_jit_cache_file", "rs_jit_cache_warm", "rs_batch_autotune_report", "rs_batch_debug_clocks",
     "rs_batch_checkpoint_bytes", "rs_batch_checkpoint_save", "rs_batch_checkpoint_load",
+    "rs_link_tables_pinned", "rs_link_tables_compare", "rs_ctx_jit_status", "rs_jit_compiler_identity",
 ]
 
 _lib = None
@@ -114,6 +117,11 @@ def lib():
     L = C.CDLL(str(_LIB_PATH))
     L.rs_last_error.restype = C.c_char_p
     L.rs_link_tables.argtypes = [C.POINTER(C.c_double)] * 4
+    L.rs_link_tables_pinned.argtypes = [C.POINTER(C.c_double)] * 4
+    L.rs_link_tables_compare.argtypes = [C.c_char_p, C.c_size_t]
+    L.rs_ctx_jit_status.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.rs_jit_compiler_identity.restype = C.c_char_p
+    L.rs_jit_compiler_identity.argtypes = []
     L.rs_create.restype = C.c_void_p
     L.rs_create.argtypes = [C.POINTER(_Config)]
     L.rs_destroy.argtypes = [C.c_void_p]
@@ -303,11 +311,23 @@ def hbm_copy_probe(device=0, nbytes=1 << 30, iters=10):
     return g.value
 
 
-def link_tables():
-    """Host-libm link adaptation tables (no GPU needed): dict of eff/kbps/E/X, each float64[16]."""
+def link_tables(pinned=False):
+    """Link adaptation tables (no GPU needed): dict of eff/kbps/E/X, each float64[16] -- as this host's libm evaluates them, or
+    (pinned=True) the glibc-2.35 set compiled into the library (rs_config.link_tables)."""
     out = [np.zeros(16, np.float64) for _ in range(4)]
-    _check(lib().rs_link_tables(*[_p(a, C.c_double) for a in out]))
+    _check((lib().rs_link_tables_pinned if pinned else lib().rs_link_tables)(*[_p(a, C.c_double) for a in out]))
     return dict(zip(("eff", "kbps", "eesm_e", "eesm_x"), out))
+
+
+def link_tables_compare():
+    """(n, text): how many EESM constants of this host's libm differ from the pinned glibc-2.35 set, and which."""
+    buf = C.create_string_buffer(4096)
+    return _count(lib().rs_link_tables_compare(buf, 4096)), buf.value.decode(errors="replace")
+
+
+def jit_compiler_identity():
+    """The compiler identity inside every cache key of the run-time builds (hiprtc / HIP runtime / clang with its LLVM commit / comgr)."""
+    return lib().rs_jit_compiler_identity().decode()
 
 
 def read_trace_mapping(path, max_entries=4096):
@@ -417,7 +437,7 @@ class SliceConfig:
 class _CfgHolder:
     """Keeps the numpy arrays a C rs_config points at alive."""
 
-    def __init__(self, slices: SliceConfig, n_rbgs, rbg_size, sched, device, stream, synthetic_exp=False):
+    def __init__(self, slices: SliceConfig, n_rbgs, rbg_size, sched, device, stream, synthetic_exp=False, link_tables=0):
         self.w = np.ascontiguousarray(slices.weight, np.float64)
         self.a = np.ascontiguousarray(slices.algo_alpha, np.int32)
         self.b = np.ascontiguousarray(slices.algo_beta, np.int32)
@@ -427,7 +447,7 @@ class _CfgHolder:
         self.c = _Config(slices.n_slices, slices.n_users, n_rbgs, rbg_size, sched, device,
                          _p(self.w, C.c_double), _p(self.a, C.c_int32), _p(self.b, C.c_int32),
                          _p(self.e, C.c_int32), _p(self.p, C.c_int32), _p(self.u2s, C.c_int32),
-                         C.c_void_p(stream or 0), int(bool(synthetic_exp)))
+                         C.c_void_p(stream or 0), int(bool(synthetic_exp)), int(link_tables))
 
 
 @dataclass
@@ -447,15 +467,25 @@ class TtiScheduler:
     """Drop-in mode: RBsAllocation() of one TTI on the GPU (rs_create / rs_schedule_tti)."""
 
     def __init__(self, slices: SliceConfig, n_rbgs: int, rbg_size: int, sched: int = RS_SCHED_MAXCELL,
-                 device: int = 0, stream: Optional[int] = None, synthetic_exp: bool = False, jit: bool = False):
-        """jit: rs_ctx_specialize -- this context's own hiprtc build of the one-TTI kernel (identical results, shorter calls)."""
+                 device: int = 0, stream: Optional[int] = None, synthetic_exp: bool = False, jit: bool = False,
+                 link_tables: int = RS_LINK_DEFAULT):
+        """jit: rs_ctx_specialize -- this context's own hiprtc build of the one-TTI kernel (identical results, shorter calls; its first
+        calls run beside the built-in kernel unless the build carries the self-check mark: jit_status()).
+        link_tables: RS_LINK_* (default for a drop-in context: this host's libm; create_warning says when it is not the fixtures')."""
         self.slices, self.R, self.rbg_size, self.sched = slices, n_rbgs, rbg_size, sched
-        self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream, synthetic_exp)
+        self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream, synthetic_exp, link_tables)
         self._h = lib().rs_create_checked(C.byref(self._cfg.c), RS_ABI_VERSION, C.sizeof(_Config))
         if not self._h:
             raise RadioSaberError(-1, lib().rs_last_error().decode())
+        self.create_warning = lib().rs_last_error().decode()
         if jit:
             _check(lib().rs_ctx_specialize(self._h))
+
+    def jit_status(self):
+        """(code, message) of rs_ctx_jit_status: 1 specialised kernels serve, 0 not asked for, -1 build failed, -2 dropped by the self-check."""
+        buf = C.create_string_buffer(512)
+        rc = lib().rs_ctx_jit_status(self._h, buf, 512)
+        return rc, buf.value.decode(errors="replace")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -466,9 +496,11 @@ class TtiScheduler:
 
     def schedule_tti(self, cqi, avg_rate, rand0=0, rand1=0, user_id: Optional[Sequence[int]] = None,
                      cqi_prb=None, hol_delay=None, prio_has_data=None, rand_draws=None, required_rbs=None,
-                     data_to_transmit=None) -> TtiResult:
+                     data_to_transmit=None, cqi_epoch: int = 0) -> TtiResult:
         """cqi [n][R] per-RBG CQI, or cqi_prb [n][R*rbg_size] per-PRB CQI (then cqi may be None).
-        rand_draws (RS_SCHED_NVS_NONGREEDY): the 300 * n rand() values of RBsAllocationNonGreedyPF, in draw order."""
+        rand_draws (RS_SCHED_NVS_NONGREEDY): the 300 * n rand() values of RBsAllocationNonGreedyPF, in draw order.
+        cqi_epoch: non-zero = the caller's version number of the CQI block; a call with the number (and users) of the call before reads
+        the context's device-resident image instead of the block (rs_tti_in.cqi_epoch)."""
         prb = None
         if cqi_prb is not None:
             prb = np.ascontiguousarray(cqi_prb, np.uint8)
@@ -499,7 +531,7 @@ class TtiScheduler:
                      _p(prio, C.c_uint8) if prio is not None else None,
                      _p(draws, C.c_int32) if draws is not None else None,
                      _p(req, C.c_int32) if req is not None else None,
-                     _p(dat, C.c_int32) if dat is not None else None)
+                     _p(dat, C.c_int32) if dat is not None else None, int(cqi_epoch))
         if self.sched == RS_SCHED_UPPERBOUND:
             res.upper_rbg = np.full((S, self.R), -1, np.int32)
             res.upper_user = np.full((S, self.R), -1, np.int32)
@@ -537,14 +569,16 @@ class BatchScheduler:
                  sched: int = RS_SCHED_MAXCELL, device: int = 0, first_tti: int = 100, cqi_refresh: int = 40,
                  phy_error_draws: bool = False, threads_per_cell: int = 0, stream: Optional[int] = None,
                  jit: bool = False, synthetic_exp: bool = False, cqi_epoch_wrap: bool = False, queue_state_lds: int = 0,
-                 autotune: bool = False, selfcheck: bool = False):
-        """synthetic_exp: the reference built with FIRST/SECOND_SYNTHETIC_EXP (transport blocks PRB by PRB; rs_config.synthetic_exp).
+                 autotune: bool = False, selfcheck=0, link_tables: int = RS_LINK_DEFAULT):
+        """selfcheck: 0 / False = run-time builds without the self-check mark are checked against the built-in kernels before they serve
+        (the default since ABI 11), 1 / True = every build, -1 = never.  link_tables: RS_LINK_* (default for batches: pinned glibc 2.35).
+        synthetic_exp: the reference built with FIRST/SECOND_SYNTHETIC_EXP (transport blocks PRB by PRB; rs_config.synthetic_exp).
         cqi_epoch_wrap: the uploaded / synthesized epochs cycle instead of ending the run.  queue_state_lds: 0 auto, 1 LDS, -1 HBM."""
         self.slices, self.R, self.rbg_size, self.sched, self.n_cells = slices, n_rbgs, rbg_size, sched, n_cells
         self.S, self.U = slices.n_slices, slices.n_users
-        self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream, synthetic_exp)
+        self._cfg = _CfgHolder(slices, n_rbgs, rbg_size, sched, device, stream, synthetic_exp, link_tables)
         bc = _BatchConfig(self._cfg.c, n_cells, first_tti, cqi_refresh, int(phy_error_draws), threads_per_cell,
-                          int(jit), int(bool(cqi_epoch_wrap)), int(queue_state_lds), int(bool(autotune)), int(bool(selfcheck)))
+                          int(jit), int(bool(cqi_epoch_wrap)), int(queue_state_lds), int(bool(autotune)), int(selfcheck))
         self._h = lib().rs_batch_create_checked(C.byref(bc), RS_ABI_VERSION, C.sizeof(_BatchConfig))
         if not self._h:
             raise RadioSaberError(-1, lib().rs_last_error().decode())

@@ -24,6 +24,7 @@
 
 #include "../../include/radiosaber_hip.h"
 #include "rs_amc_tables.inc"
+#include "rs_link_pinned.inc"
 #include "rs_device.h"
 
 extern "C" hipError_t rs_launch_cells(const RsLaunch* p, int threads, hipStream_t stream);
@@ -33,6 +34,10 @@ extern "C" RsJitKernel* rs_jit_get(int device, int S, int U, int R, int G, int N
                                    int flags, /* bit 0: drop-in (one-TTI) kernel, bit 1: streamed batch (cqi_refresh <= 4), bit 2: lean build */
                                    const char* variant = nullptr); /* an autotune candidate: extra -D options and / or "ss=<LLVM scheduler strategy>" */
 extern "C" int rs_jit_is_untuned(const RsJitKernel* k);
+extern "C" int rs_jit_is_verified(const RsJitKernel* k);  /* carries the self-check mark (this process, or its cache file) */
+extern "C" int rs_jit_was_loaded(const RsJitKernel* k);   /* came from the disk cache */
+extern "C" void rs_jit_mark_verified(RsJitKernel* k);
+extern "C" void rs_jit_reject(RsJitKernel* k);
 extern "C" hipError_t rs_jit_launch(RsJitKernel* k, const RsLaunch* p, hipStream_t stream);
 extern "C" hipError_t rs_launch_synth(uint8_t* epochs, int64_t grid_stride, int n_cells, int n_epochs, int U, int R, int Upad,
                                       uint64_t seed, int64_t first_cell, const uint32_t* cdf16, hipStream_t stream);
@@ -173,6 +178,49 @@ int rs_dl_prbs_for_bandwidth(double bw_mhz) {
   return 25;
 }
 
+/* the EESM constants as glibc 2.35 (x86-64) evaluates them: E[1..15], X[1..13] (radiosaber_amd/data/link_tables_glibc_2_35.json ->
+ * rs_link_pinned.inc by build.py; the same hex values as SURVEY.md Appendix A / tests/golden/appendix_a.json) */
+static const double kPinnedE[15] = {RS_LINK_PINNED_E};
+static const double kPinnedX[13] = {RS_LINK_PINNED_X};
+
+int rs_link_tables_pinned(double eff[16], double kbps[16], double eesm_e[16], double eesm_x[16]) {
+  eff[0] = kbps[0] = eesm_e[0] = eesm_x[0] = 0;
+  for (int c = 1; c <= 15; c++) {
+    const int bits = kTbs[0][kMcsToItbs[kCqiToMcs[c - 1]]];
+    const double e = (bits / 0.001) / 180000.; /* IEEE divisions of table integers: no libm */
+    eff[c] = e;
+    kbps[c] = e * 180000 / 1000;
+    eesm_e[c] = kPinnedE[c - 1];
+  }
+  eesm_x[14] = eesm_x[15] = 0;
+  for (int k = 1; k <= 13; k++) eesm_x[k] = kPinnedX[k - 1];
+  return RS_OK;
+}
+
+int rs_link_tables_compare(char* msg, size_t msglen) {
+  double eff[16], kbps[16], e[16], x[16];
+  if (msg && msglen) msg[0] = 0;
+  const int rc = rs_link_tables(eff, kbps, e, x);
+  if (rc) return rc;
+  int diff = 0;
+  std::string text;
+  char line[160];
+  for (int c = 1; c <= 15; c++)
+    if (to_bits(e[c]) != to_bits(kPinnedE[c - 1])) {
+      diff++;
+      snprintf(line, sizeof line, "E[%d] host %a pinned %a; ", c, e[c], kPinnedE[c - 1]);
+      text += line;
+    }
+  for (int k = 1; k <= 13; k++)
+    if (to_bits(x[k]) != to_bits(kPinnedX[k - 1])) {
+      diff++;
+      snprintf(line, sizeof line, "X[%d] host %a pinned %a; ", k, x[k], kPinnedX[k - 1]);
+      text += line;
+    }
+  if (msg && msglen) snprintf(msg, msglen, "%s", text.c_str());
+  return diff;
+}
+
 int rs_link_tables(double eff[16], double kbps[16], double eesm_e[16], double eesm_x[16]) {
   eff[0] = kbps[0] = eesm_e[0] = eesm_x[0] = 0;
   for (int c = 1; c <= 15; c++) {
@@ -264,13 +312,13 @@ struct rs_batch {
   RsJitKernel* jit_lean = nullptr; /* its lean build, compiled at the first launch that can use it (launch()) */
   bool jit_lean_tried = false;
   bool autotuned = false;       /* rs_batch_config.autotune: the candidates were timed (or the tuning does not apply) */
-  bool selfchecked = false;     /* rs_batch_config.selfcheck: done (or it does not apply) */
+  bool selfchecked = false;     /* the self-check of the run-time builds: done (or it does not apply) */
   bool selfchecked_general = false, selfchecked_lean = false;
+  bool in_selfcheck = false;    /* its trial launches come back through launch(): not again */
   bool jit_rejected = false;    /* ... and a run-time build disagreed with the built-in kernels: dropped */
   char selfcheck_msg[160] = "";
   int autotune_n = 0;
   char autotune_msg[768] = "";
-  void* d_snapshot = nullptr;   /* autotune: the whole cell state, put back after every trial */
   unsigned long long* d_prio_sum = nullptr; /* TTIs done by all cells of the running launch (the cells' issue-priority feedback) */
   bool jit_wanted = false;
   char jit_msg[512] = ""; /* why the shape-specialised kernel is not in use (empty: it is, or it was not asked for) */
@@ -288,6 +336,8 @@ int validate(const rs_config* c, bool direct) {
   if (c->rbg_size < 1 || c->rbg_size > 8) return fail(RS_ERR_INVALID, "rbg_size %d outside 1..8", c->rbg_size);
   if (c->n_rbgs * c->rbg_size > 512) return fail(RS_ERR_INVALID, "more than 512 PRBs (reference get_rbg_size throws)");
   if ((c->synthetic_exp | 1) != 1) return fail(RS_ERR_INVALID, "synthetic_exp %d is not 0 or 1 (an rs_config of an older ABI? it gained the field in ABI 8)", c->synthetic_exp);
+  if (c->link_tables < RS_LINK_DEFAULT || c->link_tables > RS_LINK_PINNED_GLIBC_2_35)
+    return fail(RS_ERR_INVALID, "link_tables %d is not an RS_LINK_* value (an rs_config of an older ABI? it gained the field in ABI 11)", c->link_tables);
   if (c->sched != RS_SCHED_PF && c->sched != RS_SCHED_NVS && c->sched != RS_SCHED_SEQUENTIAL && c->sched != RS_SCHED_MAXCELL &&
       c->sched != RS_SCHED_VOGEL && c->sched != RS_SCHED_SUBOPT && c->sched != RS_SCHED_UPPERBOUND && c->sched != RS_SCHED_NVS_NONGREEDY)
     return fail(RS_ERR_INVALID, "sched %d not supported (1, 7, 8, 9, 10, 11, 101, 103)", c->sched);
@@ -380,7 +430,10 @@ int batch_alloc(rs_batch* b) {
   RsTables t;
   memset(&t, 0, sizeof t);
   double eff[16];
-  int rc = rs_link_tables(eff, t.kbps, t.eesm_e, t.eesm_x);
+  /* the EESM constants: pinned (glibc 2.35) for batches, this host's libm for a drop-in beside a locally built reference, unless the
+   * configuration says otherwise (rs_config.link_tables) */
+  const int link = b->cfg.cell.link_tables != RS_LINK_DEFAULT ? b->cfg.cell.link_tables : (b->direct ? RS_LINK_HOST_LIBM : RS_LINK_PINNED_GLIBC_2_35);
+  int rc = link == RS_LINK_PINNED_GLIBC_2_35 ? rs_link_tables_pinned(eff, t.kbps, t.eesm_e, t.eesm_x) : rs_link_tables(eff, t.kbps, t.eesm_e, t.eesm_x);
   if (rc) return rc;
   for (int c = 1; c <= 15; c++) {
     t.pfnum[c] = eff[c] * 180000.; /* dl-pf-packet-scheduler.cpp:138 */
@@ -415,7 +468,9 @@ int batch_alloc(rs_batch* b) {
   HIP_TRY(hipMalloc(&b->d_user_slice, U));
   HIP_TRY(hipMemcpy(b->d_user_slice, us.data(), U, hipMemcpyHostToDevice));
   {
-    /* TBS bits of n RBGs = n*G PRBs per itbs (AMCModule.cpp:306-317); row 0 unused */
+    /* TBS bits of n RBGs = n*G PRBs per itbs (AMCModule.cpp:306-317); row 0 unused.  The device gets them with the CQI -> MCS -> I_TBS
+     * step folded in, [R+1][16] indexed by final CQI: the kernel's LDS table is then a straight copy (round 6: the two dependent loads
+     * per entry -- itbs_of_cqi, then the row -- were ~1 us of every one-TTI launch) */
     std::vector<int32_t> te((size_t)(b->R + 1) * 27, 0);
     for (int n = 1; n <= b->R; n++)
       for (int i = 0; i < 27; i++) {
@@ -427,8 +482,11 @@ int batch_alloc(rs_batch* b) {
       }
     for (int32_t v : te)
       if (v / 8 > RS_MAX_BYTES_PER_TTI) return fail(RS_ERR_INVALID, "a transport block of %d bits does not fit the per-launch byte counters", v);
-    HIP_TRY(hipMalloc(&b->d_tbs_eff, 4 * te.size()));
-    HIP_TRY(hipMemcpy(b->d_tbs_eff, te.data(), 4 * te.size(), hipMemcpyHostToDevice));
+    std::vector<int32_t> te16((size_t)(b->R + 1) * 16, 0);
+    for (int n = 0; n <= b->R; n++)
+      for (int c = 0; c < 16; c++) te16[(size_t)n * 16 + c] = te[(size_t)n * 27 + t.itbs_of_cqi[c]];
+    HIP_TRY(hipMalloc(&b->d_tbs_eff, 4 * te16.size()));
+    HIP_TRY(hipMemcpy(b->d_tbs_eff, te16.data(), 4 * te16.size(), hipMemcpyHostToDevice));
   }
   if (b->gen_exp) {
     /* ref: downlink-transport-scheduler.cpp:688-693  pow(spectralEfficiency * 180000 / 1000, epsilon), with this host's libm --
@@ -526,7 +584,7 @@ rs_batch* batch_new(const rs_batch_config* cfg, bool direct) {
   }
   if ((cfg->cqi_epoch_wrap | 1) != 1) { fail(RS_ERR_INVALID, "cqi_epoch_wrap %d is not 0 or 1", cfg->cqi_epoch_wrap); return nullptr; }
   if ((cfg->autotune | 1) != 1) { fail(RS_ERR_INVALID, "autotune %d is not 0 or 1", cfg->autotune); return nullptr; }
-  if ((cfg->selfcheck | 1) != 1) { fail(RS_ERR_INVALID, "selfcheck %d is not 0 or 1", cfg->selfcheck); return nullptr; }
+  if (cfg->selfcheck < -1 || cfg->selfcheck > 1) { fail(RS_ERR_INVALID, "selfcheck %d outside -1..1", cfg->selfcheck); return nullptr; }
   if (cfg->queue_state_lds < -1 || cfg->queue_state_lds > 1) { fail(RS_ERR_INVALID, "queue_state_lds %d outside -1..1", cfg->queue_state_lds); return nullptr; }
   if (cfg->cell.sched == RS_SCHED_UPPERBOUND) {
     /* the per-slice sorts use the register form of the sort emulation: at most four array positions per thread */
@@ -619,21 +677,34 @@ RsJitKernel* lean_kernel(rs_batch* b, int n_ttis, bool logged) {
 int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d_target, int32_t* d_tbs, int32_t* d_uinfo,
            uint32_t* d_keys = nullptr);
 
-/* ---- a device-side snapshot of the WHOLE cell state (PF averages, pending grants, cumulative counters, slice state, clock / rand()
- * ring / CQI-report state): what rs_batch_config.autotune and .selfcheck put back after their trial launches ---- */
+/* Everything a batch carries from one launch to the next, as (device pointer, bytes): PF averages, pending grants, cumulative counters,
+ * slice state, clock / rand() ring / CQI-report state, and with the queue model the bearers' queues, averages, counters and per-user
+ * words.  One list for the checkpoint (rs_batch_checkpoint_*), the autotune's snapshot and the self-check's. */
+struct StatePart { void* p; size_t n; };
+std::vector<StatePart> state_parts(rs_batch* b) {
+  const size_t cells = b->n_cells, U = b->U, S = b->S, n2 = cells * 2 * U;
+  std::vector<StatePart> v = {{b->d_avg, 8 * cells * U}, {b->d_tx, 4 * cells * U}, {b->d_cumb, 8 * cells * U}, {b->d_cumr, 8 * cells * U},
+                              {b->d_sstate, 8 * cells * S}, {b->d_scal, sizeof(RsCellScalars) * cells}};
+  if (b->queues) {
+    v.push_back({b->d_qi, 4 * 7 * n2});
+    v.push_back({b->d_bavg, 8 * n2});
+    v.push_back({b->d_bcum, 8 * 2 * n2});
+    v.push_back({b->d_qflags, cells * U});
+    v.push_back({b->d_qhol, 8 * cells * U});
+  }
+  return v;
+}
+
+/* ---- a device-side snapshot of that state: what rs_batch_config.autotune and the self-check put back after their trial launches ---- */
 struct StateParts {
-  struct Part { void* p; size_t n; };
-  Part parts[6];
+  std::vector<StatePart> parts;
   size_t total = 0;
-  explicit StateParts(rs_batch* b) {
-    const size_t cells = b->n_cells, U = b->U, S = b->S;
-    const Part q[6] = {{b->d_avg, 8 * cells * U}, {b->d_tx, 4 * cells * U}, {b->d_cumb, 8 * cells * U}, {b->d_cumr, 8 * cells * U},
-                       {b->d_sstate, 8 * cells * S}, {b->d_scal, sizeof(RsCellScalars) * cells}};
-    for (int i = 0; i < 6; i++) { parts[i] = q[i]; total += (q[i].n + 255) & ~(size_t)255; }
+  explicit StateParts(rs_batch* b) : parts(state_parts(b)) {
+    for (const StatePart& q : parts) total += (q.n + 255) & ~(size_t)255;
   }
   hipError_t copy(rs_batch* b, void* snapshot, bool save) const {
     size_t off = 0;
-    for (const Part& q : parts) {
+    for (const StatePart& q : parts) {
       void* snap = (char*)snapshot + off;
       const hipError_t e = hipMemcpyAsync(save ? snap : q.p, save ? q.p : snap, q.n, hipMemcpyDeviceToDevice, b->stream);
       if (e != hipSuccess) return e;
@@ -647,14 +718,15 @@ struct StateParts {
  * state, the bytes of the pending grants (the shape-specialised kernels pack more into that word), clock, rand() ring and CQI-report
  * state.  FNV-1a over the host copy (a few MB, once per trial). */
 struct StateDigest {
-  unsigned long long part[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; /* PF averages, cumulative bytes, cumulative RBs, slice state, pending grants' bytes, scalars */
+  unsigned long long part[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; /* PF averages, cumulative bytes, cumulative RBs, slice state, pending grants' bytes, scalars; queue model: the bearers' queues, averages, counters */
   bool operator==(const StateDigest& o) const { return memcmp(part, o.part, sizeof part) == 0; }
   bool operator!=(const StateDigest& o) const { return !(*this == o); }
   std::string diff(const StateDigest& o) const {
-    static const char* const names[10] = {"PF averages", "cumulative bytes", "cumulative RBs", "slice state", "pending grants", "simulated time",
-                                          "last EWMA update", "TTIs done", "users served in the last TTI", "rand() ring / CQI-report state"};
+    static const char* const names[13] = {"PF averages", "cumulative bytes", "cumulative RBs", "slice state", "pending grants", "simulated time",
+                                          "last EWMA update", "TTIs done", "users served in the last TTI", "rand() ring / CQI-report state",
+                                          "bearers' queues", "bearers' PF averages", "bearers' cumulative counters"};
     std::string d;
-    for (int i = 0; i < 10; i++)
+    for (int i = 0; i < 13; i++)
       if (part[i] != o.part[i]) d += std::string(d.empty() ? "" : ", ") + names[i];
     return d;
   }
@@ -694,6 +766,17 @@ int state_digest(rs_batch* b, StateDigest* out) {
     for (int i = 0; i < 31; i++) { const uint32_t w = c.rng_r[(c.rng_f + i) % 31]; d = fnv(&w, 4, d); }
     out->part[9] = d;
   }
+  if (b->queues) {
+    /* the queue model: head, tail, pk, frag, bytes, pkts, tx of every bearer; its PF average; its cumulative bytes / RBs.  (The per-user
+     * flag and HoL words are rebuilt by every TTI's first phase before anything reads them: scratch, not compared.) */
+    const size_t n2 = cells * 2 * U;
+    const StatePart q[3] = {{b->d_qi, 4 * 7 * n2}, {b->d_bavg, 8 * n2}, {b->d_bcum, 8 * 2 * n2}};
+    for (int i = 0; i < 3; i++) {
+      std::vector<unsigned char> hq(q[i].n);
+      HIP_TRY(hipMemcpy(hq.data(), q[i].p, q[i].n, hipMemcpyDeviceToHost));
+      out->part[10 + i] = fnv(hq.data(), q[i].n);
+    }
+  }
   return RS_OK;
 }
 
@@ -714,18 +797,26 @@ int autotune(rs_batch* b, int n_ttis) {
   cand.push_back(b->R > 32 ? "-DRS_NO_SPEC" : "-DRS_NO_HOLD");
   if (sched == 9) cand.push_back("-DRS_P3_BLOCK=8");
   const StateParts sp(b);
-  HIP_TRY(hipMalloc(&b->d_snapshot, sp.total));
-  const int64_t done0 = b->ttis_done;
-  const int trial = n_ttis < 512 ? n_ttis : 512;
+  /* the snapshot and the two events live exactly as long as this call, whichever way it returns (an early HIP_TRY return used
+   * to leave them -- and the candidate kernel -- behind) */
+  ScratchBuffers scratch;
+  ScratchEvents events;
+  void* snapshot = nullptr;
   RsJitKernel* const k_default = b->jit_lean;
+  const int64_t done0 = b->ttis_done;
+  struct Restore { /* whatever happens: the rule table's build unless a better one was chosen, the TTI count as it was */
+    rs_batch* b; RsJitKernel* k; int64_t done;
+    ~Restore() { b->jit_lean = k; b->ttis_done = done; }
+  } restore{b, k_default, done0};
+  HIP_TRY(scratch.alloc(&snapshot, sp.total));
+  HIP_TRY(events.create(2));
+  const hipEvent_t e0 = events.ev[0], e1 = events.ev[1];
+  const int trial = n_ttis < 512 ? n_ttis : 512;
   RsJitKernel* best = k_default;
   float best_ms = 0, default_ms = 0;
   StateDigest default_digest;
   int rc = RS_OK;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(sp.copy(b, b->d_snapshot, true));
+  HIP_TRY(sp.copy(b, snapshot, true));
   std::string report;
   for (size_t i = 0; i < cand.size() && rc == RS_OK; i++) {
     char msg[512] = "";
@@ -736,7 +827,7 @@ int autotune(rs_batch* b, int n_ttis) {
     b->jit_lean = k;
     float ms = 0;
     for (int rep = 0; rep < 3 && rc == RS_OK; rep++) { /* one warm launch, then the faster of two */
-      if (sp.copy(b, b->d_snapshot, false) != hipSuccess || hipEventRecord(e0, b->stream) != hipSuccess) { rc = fail(RS_ERR_HIP, "autotune: state restore failed"); break; }
+      if (sp.copy(b, snapshot, false) != hipSuccess || hipEventRecord(e0, b->stream) != hipSuccess) { rc = fail(RS_ERR_HIP, "autotune: state restore failed"); break; }
       rc = launch(b, trial, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
       if (rc) break;
       float t = 0;
@@ -757,8 +848,11 @@ int autotune(rs_batch* b, int n_ttis) {
       snprintf(line, sizeof line, "%s: %.3f ms, REJECTED: its state after the trial differs from the rule table's build (%s); ", cand[i].c_str(), ms,
                digest.diff(default_digest).c_str());
       report += line;
+      rs_jit_reject(k);
       continue;
     }
+    /* a variant that agrees with a build that carries the self-check mark has passed the same check by transitivity */
+    if (i > 0 && rs_jit_is_verified(k_default)) rs_jit_mark_verified(k);
     snprintf(line, sizeof line, "%s: %.3f ms; ", i == 0 ? "rule table" : cand[i].c_str(), ms);
     report += line;
     b->autotune_n++;
@@ -766,47 +860,91 @@ int autotune(rs_batch* b, int n_ttis) {
     if (i == 0) { best = k; best_ms = default_ms = ms; }
     else if (ms < best_ms && ms < 0.99f * default_ms) { best = k; best_ms = ms; }
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   /* the run continues from where it was, whatever happened above */
-  const hipError_t back = sp.copy(b, b->d_snapshot, false);
+  const hipError_t back = sp.copy(b, snapshot, false);
   const hipError_t sync = hipStreamSynchronize(b->stream);
-  b->ttis_done = done0;
-  (void)hipFree(b->d_snapshot);
-  b->d_snapshot = nullptr;
-  b->jit_lean = rc == RS_OK ? best : k_default;
   if (back != hipSuccess || sync != hipSuccess) return fail(RS_ERR_HIP, "autotune: the cell state could not be put back");
   if (rc) return rc;
   rc = check_device_err(b);
   if (rc) return rc;
+  restore.k = best;
   snprintf(b->autotune_msg, sizeof b->autotune_msg, "autotune over %d TTIs: %skept %s", trial, report.c_str(),
            best == k_default ? "the rule table's build" : "the fastest");
   return RS_OK;
 }
 
-/* rs_batch_config.selfcheck: the batch's next min(n, 256) TTIs on the kernels built into the library and on its run-time compiled
- * ones (general build, lean build), each from the same snapshot; the three final states must agree bit for bit (state_digest).  The
- * built-in kernels are ONE binary, the one the GPU parity suite runs against the oracle; a run-time build is a fresh compilation for
- * this shape, and round 4 met one that the compiler got wrong (profiles/r05_onelane.md).  A build that disagrees is dropped: the
- * batch runs on the built-in kernels and rs_batch_jit_status returns -2 with the reason.  The snapshot is put back: no trace. */
-int selfcheck(rs_batch* b, int n_ttis) {
-  if (!b->cfg.selfcheck || b->selfchecked) return RS_OK;
-  if (!b->jit || b->direct || b->threads > 512) { b->selfchecked = true; return RS_OK; } /* nothing run-time compiled, or no built-in kernel of this workgroup size */
-  /* the general build at the first unlogged launch; the lean build at the first launch that qualifies for it (RS_JIT_LEAN_MIN_TTIS) */
+/* Which run-time builds a batch checks against the built-in kernels before it trusts them (round 6: on by default).
+ *   rs_batch_config.selfcheck  1: every build, marked or not;  -1: none;  0 (default): every build WITHOUT the self-check mark -- one
+ *   that this process compiled, or that came from the disk cache of a process that never checked it.  A build that passed leaves the mark
+ *   in its cache file (rs_jit_mark_verified), so the second process of a campaign skips the check.
+ *   RS_JIT_SELFCHECK=0 switches the default off (cfg.selfcheck = 1 still checks), RS_JIT_SELFCHECK=2 makes it "every build". */
+enum { kCheckNever = 0, kCheckUnmarked = 1, kCheckAll = 2 };
+int selfcheck_policy(const rs_batch* b) {
+  if (b->cfg.selfcheck > 0) return kCheckAll;
+  if (b->cfg.selfcheck < 0) return kCheckNever;
+  const char* e = getenv("RS_JIT_SELFCHECK");
+  if (e && e[0] == '0') return kCheckNever;
+  if (e && e[0] == '2') return kCheckAll;
+  return kCheckUnmarked;
+}
+
+/* The self-check: the batch's next min(n, 256) TTIs on the kernels built into the library and on its run-time compiled ones (general
+ * build, lean build), each from the same snapshot; the final states must agree bit for bit (state_digest).  The built-in kernels are
+ * ONE binary, the one the GPU parity suite runs against the oracle; a run-time build is a fresh compilation for this shape, and round 4
+ * met one that the compiler got wrong (profiles/r05_onelane.md).  A general build that disagrees is dropped: the batch runs on the
+ * built-in kernels and rs_batch_jit_status returns -2 with the reason; a lean build that disagrees while the general one agreed is
+ * dropped alone (status stays 1, the message says so).  The snapshot is put back: no trace.  With the queue model the snapshot and the
+ * comparison include the bearers' queues, averages and counters (they were left out and the check refused nothing but
+ * silently advanced them). */
+int selfcheck(rs_batch* b, int n_ttis, bool logged) {
+  const int policy = selfcheck_policy(b);
+  if (policy == kCheckNever || b->selfchecked || b->in_selfcheck) return RS_OK;
+  if (!b->jit || b->direct) { b->selfchecked = true; return RS_OK; } /* nothing run-time compiled */
+  if (b->threads > 512) { /* no built-in kernel of this workgroup size to compare with */
+    b->selfchecked = true;
+    snprintf(b->selfcheck_msg, sizeof b->selfcheck_msg, "not self-checked: the kernels built into the library stop at 512 threads per cell");
+    return RS_OK;
+  }
+  /* the general build at the first launch; the lean build at the first launch that qualifies for it (RS_JIT_LEAN_MIN_TTIS, unlogged) */
   RsJitKernel* const k_gen = b->jit;
-  RsJitKernel* const k_lean = lean_kernel(b, n_ttis, false);
-  const bool need_gen = !b->selfchecked_general, need_lean = k_lean && !b->selfchecked_lean;
-  if (!need_gen && !need_lean) return RS_OK;
-  b->selfchecked = true; /* (the trial launches come back through launch(): not again) */
+  RsJitKernel* const k_lean = lean_kernel(b, n_ttis, logged);
+  const bool need_gen = !b->selfchecked_general && (policy == kCheckAll || !rs_jit_is_verified(k_gen));
+  const bool need_lean = k_lean && !b->selfchecked_lean && (policy == kCheckAll || !rs_jit_is_verified(k_lean));
+  const char* const e_on = getenv("RS_JIT_LEAN");
+  const bool lean_off = e_on && atoi(e_on) == 0;
+  if (!need_gen && !need_lean) {
+    /* builds that came with the mark of an earlier process's check */
+    if (!b->selfchecked_general) {
+      b->selfchecked_general = true;
+      snprintf(b->selfcheck_msg, sizeof b->selfcheck_msg, "the run-time build carries the self-check mark of the process that compiled it (cache file)");
+    }
+    if (k_lean) b->selfchecked_lean = true;
+    b->selfchecked = b->selfchecked_lean || lean_off;
+    return RS_OK;
+  }
+  b->in_selfcheck = true;
+  struct Leave { rs_batch* b; ~Leave() { b->in_selfcheck = false; } } leave{b};
   const StateParts sp(b);
+  ScratchBuffers scratch;
   void* snap = nullptr;
-  HIP_TRY(hipMalloc(&snap, sp.total));
+  HIP_TRY(scratch.alloc(&snap, sp.total));
   const int64_t done0 = b->ttis_done;
   const int trial = n_ttis < 256 ? n_ttis : 256;
   int rc = RS_OK;
   StateDigest want, got;
   const char* bad = nullptr;
-  HIP_TRY(sp.copy(b, snap, true));
+  /* the pending-grant words of a shape-specialised kernel are bytes | PRBs << 20 | "counted" << 30 (RS_TX_*: the grant is in the
+   * cumulative totals already); the built-in kernels keep plain bytes there (and count at grant time).  The queue model's kernels, built-in
+   * and run-time, share one format (and consume every grant before the launch ends): nothing to convert there. */
+  auto plain_tx = [&]() -> int {
+    if (b->queues) return RS_OK;
+    std::vector<int32_t> tx((size_t)b->n_cells * b->U);
+    if (hipStreamSynchronize(b->stream) != hipSuccess || hipMemcpy(tx.data(), b->d_tx, 4 * tx.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(RS_ERR_HIP, "selfcheck: copy failed");
+    for (int32_t& w : tx) w &= RS_TX_BYTES_MASK;
+    if (hipMemcpy(b->d_tx, tx.data(), 4 * tx.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(RS_ERR_HIP, "selfcheck: copy failed");
+    return RS_OK;
+  };
+  if (sp.copy(b, snap, true) != hipSuccess) return fail(RS_ERR_HIP, "selfcheck: snapshot failed");
   for (int v = 0; v < 3 && rc == RS_OK && !bad; v++) {
     /* v = 0: built-in (no run-time kernel visible to launch()), 1: the general build alone, 2: the lean build */
     if ((v == 1 && !need_gen) || (v == 2 && !need_lean)) continue;
@@ -815,14 +953,7 @@ int selfcheck(rs_batch* b, int n_ttis) {
     const bool keep_tried = b->jit_lean_tried;
     if (v < 2) { b->jit_lean = nullptr; b->jit_lean_tried = true; }
     if (sp.copy(b, snap, false) != hipSuccess) rc = fail(RS_ERR_HIP, "selfcheck: state restore failed");
-    if (!rc && v == 0) {
-      /* the snapshot was left by a shape-specialised kernel, whose pending-grant word is bytes | PRBs << 20 | "counted" << 30 (RS_TX_*,
-       * the grant is in the cumulative totals already); the built-in kernels keep plain bytes there (and count at grant time) */
-      std::vector<int32_t> tx((size_t)b->n_cells * b->U);
-      if (hipStreamSynchronize(b->stream) != hipSuccess || hipMemcpy(tx.data(), b->d_tx, 4 * tx.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RS_ERR_HIP, "selfcheck: copy failed");
-      for (int32_t& w : tx) w &= RS_TX_BYTES_MASK;
-      if (!rc && hipMemcpy(b->d_tx, tx.data(), 4 * tx.size(), hipMemcpyHostToDevice) != hipSuccess) rc = fail(RS_ERR_HIP, "selfcheck: copy failed");
-    }
+    if (!rc && v == 0) rc = plain_tx();
     if (!rc) rc = launch(b, trial, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     b->jit_lean = keep_lean;
     b->jit_lean_tried = keep_tried;
@@ -833,27 +964,44 @@ int selfcheck(rs_batch* b, int n_ttis) {
   const hipError_t back = sp.copy(b, snap, false);
   const hipError_t sync = hipStreamSynchronize(b->stream);
   b->ttis_done = done0;
-  (void)hipFree(snap);
   if (back != hipSuccess || sync != hipSuccess) return fail(RS_ERR_HIP, "selfcheck: the cell state could not be put back");
   if (rc) return rc;
   rc = check_device_err(b);
   if (rc) return rc;
+  if (bad && bad[0] == 'l') {
+    /* the lean build alone is wrong (the general one agreed just now or earlier, or carries the mark): the general build keeps serving every launch */
+    rs_jit_reject(k_lean);
+    if (need_gen) { b->selfchecked_general = true; rs_jit_mark_verified(k_gen); }
+    b->jit_lean = nullptr;
+    b->jit_lean_tried = true;
+    b->selfchecked_lean = true;
+    b->selfchecked = true;
+    snprintf(b->jit_msg, sizeof b->jit_msg, "selfcheck: after %d TTIs the lean build of the shape-specialised kernel left a state that differs from the "
+             "built-in kernels' in: %s; it is dropped and the general build, which agreed, serves every launch", trial, got.diff(want).c_str());
+    return RS_OK;
+  }
   if (bad) {
+    rs_jit_reject(k_gen);
     b->jit = nullptr;
     b->jit_lean = nullptr;
     b->jit_lean_tried = true;
     b->jit_rejected = true;
+    b->selfchecked = true;
+    /* the state just put back may have been left by the shape-specialised kernel: the built-in kernels that take over read plain bytes
+     * (the first EWMA after a rejection used the packed word as a byte count) */
+    rc = plain_tx();
+    if (rc) return rc;
     snprintf(b->jit_msg, sizeof b->jit_msg, "selfcheck: after %d TTIs the %s build of the shape-specialised kernel left a state that differs from the "
              "built-in kernels' in: %s; the batch runs on the built-in kernels (lint the code object: tools/lint_exec_restore.py)", trial, bad,
              got.diff(want).c_str());
-    return RS_OK; /* (selfchecked stays set) */
+    return RS_OK;
   }
-  b->selfchecked_general |= need_gen;
-  b->selfchecked_lean |= need_lean;
+  if (need_gen) { b->selfchecked_general = true; rs_jit_mark_verified(k_gen); }
+  if (need_lean) { b->selfchecked_lean = true; rs_jit_mark_verified(k_lean); }
+  if (!need_lean && k_lean) b->selfchecked_lean = true; /* (came with the mark) */
   snprintf(b->selfcheck_msg, sizeof b->selfcheck_msg, "selfcheck over %d TTIs: the built-in kernels and the %s build%s agree", trial,
            b->selfchecked_lean ? "general and lean" : "general", b->selfchecked_lean ? "s" : "");
-  const char* const e_on = getenv("RS_JIT_LEAN");
-  b->selfchecked = b->selfchecked_lean || (e_on && atoi(e_on) == 0); /* the lean build is still to come: look again at the next launch */
+  b->selfchecked = b->selfchecked_lean || lean_off; /* the lean build is still to come: look again at the next launch */
   return RS_OK;
 }
 
@@ -896,8 +1044,8 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
     L.q_flags = b->d_qflags; L.q_hol = b->d_qhol;
   }
   const bool logged = d_map || d_quota || d_target || d_tbs || d_uinfo || d_keys;
-  if (b->cfg.selfcheck && !b->selfchecked && !logged) {
-    const int rc = selfcheck(b, n_ttis); /* (its trials come back through here with `selfchecked` set) */
+  if (!b->selfchecked && !b->in_selfcheck && b->jit && !b->direct) {
+    const int rc = selfcheck(b, n_ttis, logged); /* (its trials come back through here with `in_selfcheck` set) */
     if (rc) return rc;
   }
   if (b->cfg.autotune && !b->autotuned && !logged) {
@@ -1389,7 +1537,7 @@ int rs_batch_debug_heap_sorts(rs_batch* b, int64_t* out) {
 }
 
 /* ---- checkpoint / resume (ABI 10): everything a batch carries from one launch to the next, as one host block ----
- * header: magic "RSCK1", the shape it belongs to (S, U, R, G, sched, cells, queue model, threads are NOT part of it: any workgroup
+ * header: magic "RSCK2", the shape it belongs to (S, U, R, G, sched, cells, queue model, threads are NOT part of it: any workgroup
  * size continues a run), the number of scheduled TTIs so far, the kernel family that wrote the pending-grant words; then the device
  * arrays verbatim.  The CQI source (epoch grids / trace tables / arrival bursts) is configuration, not state: the caller sets it
  * again on the batch that resumes. */
@@ -1399,20 +1547,28 @@ struct CkptHeader {
   int32_t S, U, R, G, sched, n_cells, queues, packed_tx; /* packed_tx: the pending-grant words were left by a shape-specialised kernel */
   int64_t ttis_done;
   uint64_t bytes; /* of the whole block */
+  /* round 6: FNV-1a over everything else that decides how the run continues -- the users' slices, the slices' weights and
+   * algorithm parameters, cqi_refresh, first_tti, phy_error_draws, synthetic_exp -- and over the layout of the block itself (ABI
+   * version, sizeof(RsCellScalars)): a checkpoint of a batch whose results would differ is refused, not continued silently */
+  uint64_t config_hash;
 };
-struct CkptPart { void* p; size_t n; };
-std::vector<CkptPart> ckpt_parts(rs_batch* b) {
-  const size_t cells = b->n_cells, U = b->U, S = b->S, n2 = cells * 2 * U;
-  std::vector<CkptPart> v = {{b->d_avg, 8 * cells * U}, {b->d_tx, 4 * cells * U}, {b->d_cumb, 8 * cells * U}, {b->d_cumr, 8 * cells * U},
-                             {b->d_sstate, 8 * cells * S}, {b->d_scal, sizeof(RsCellScalars) * cells}};
-  if (b->queues) {
-    v.push_back({b->d_qi, 4 * 7 * n2});
-    v.push_back({b->d_bavg, 8 * n2});
-    v.push_back({b->d_bcum, 8 * 2 * n2});
-    v.push_back({b->d_qflags, cells * U});
-    v.push_back({b->d_qhol, 8 * cells * U});
-  }
-  return v;
+uint64_t ckpt_config_hash(const rs_batch* b) {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&h](const void* q, size_t n) {
+    const unsigned char* c = (const unsigned char*)q;
+    for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ull; }
+    h ^= 0xffu; h *= 1099511628211ull; /* field boundary */
+  };
+  const int32_t scalars[6] = {RS_ABI_VERSION, (int32_t)sizeof(RsCellScalars), b->cfg.cqi_refresh, b->cfg.first_tti, b->cfg.phy_error_draws ? 1 : 0,
+                              b->synthetic ? 1 : 0};
+  mix(scalars, sizeof scalars);
+  mix(b->u2s.data(), 4 * b->u2s.size());
+  mix(b->weight.data(), 8 * b->weight.size());
+  mix(b->alpha.data(), 4 * b->alpha.size());
+  mix(b->beta.data(), 4 * b->beta.size());
+  mix(b->eps.data(), 4 * b->eps.size());
+  mix(b->psi.data(), 4 * b->psi.size());
+  return h;
 }
 }  // namespace
 
@@ -1420,7 +1576,7 @@ int64_t rs_batch_checkpoint_bytes(rs_batch* b) {
   if (!b) return fail(RS_ERR_INVALID, "null batch");
   if (b->direct) return fail(RS_ERR_INVALID, "drop-in contexts carry slice_rbs_offset_ only: rs_get_slice_offset / rs_set_slice_offset");
   size_t n = sizeof(CkptHeader);
-  for (const CkptPart& q : ckpt_parts(b)) n += q.n;
+  for (const StatePart& q : state_parts(b)) n += q.n;
   return (int64_t)n;
 }
 
@@ -1431,14 +1587,15 @@ int rs_batch_checkpoint_save(rs_batch* b, void* buf, size_t buflen) {
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   CkptHeader h{};
-  memcpy(h.magic, "RSCK1\0\0", 8);
+  memcpy(h.magic, "RSCK2\0\0", 8);
   h.S = b->S; h.U = b->U; h.R = b->R; h.G = b->G; h.sched = b->sched; h.n_cells = b->n_cells; h.queues = b->queues ? 1 : 0;
   h.packed_tx = (b->jit && !b->queues) ? 1 : 0;
   h.ttis_done = b->ttis_done;
   h.bytes = (uint64_t)need;
+  h.config_hash = ckpt_config_hash(b);
   memcpy(buf, &h, sizeof h);
   char* out = (char*)buf + sizeof h;
-  for (const CkptPart& q : ckpt_parts(b)) {
+  for (const StatePart& q : state_parts(b)) {
     HIP_TRY(hipMemcpy(out, q.p, q.n, hipMemcpyDeviceToHost));
     out += q.n;
   }
@@ -1451,15 +1608,18 @@ int rs_batch_checkpoint_load(rs_batch* b, const void* buf, size_t buflen) {
   if (!buf || buflen < sizeof(CkptHeader)) return fail(RS_ERR_INVALID, "no checkpoint");
   CkptHeader h;
   memcpy(&h, buf, sizeof h);
-  if (memcmp(h.magic, "RSCK1\0\0", 8) != 0) return fail(RS_ERR_INVALID, "not a checkpoint (magic)");
+  if (memcmp(h.magic, "RSCK2\0\0", 8) != 0) return fail(RS_ERR_INVALID, "not a checkpoint of this library version (magic)");
   if (h.S != b->S || h.U != b->U || h.R != b->R || h.G != b->G || h.sched != b->sched || h.n_cells != b->n_cells || h.queues != (b->queues ? 1 : 0))
     return fail(RS_ERR_INVALID, "checkpoint of another batch: %d slices x %d UEs x %d RBGs x %d PRBs, sched %d, %d cells, queue model %d", h.S, h.U, h.R,
                 h.G, h.sched, h.n_cells, h.queues);
   if (h.bytes != (uint64_t)need || buflen < (size_t)need) return fail(RS_ERR_INVALID, "checkpoint of %llu bytes, this batch's are %lld", (unsigned long long)h.bytes, (long long)need);
+  if (h.config_hash != ckpt_config_hash(b))
+    return fail(RS_ERR_INVALID, "checkpoint of a batch configured differently (users per slice, slice weights / algorithm parameters, cqi_refresh, first_tti, "
+                                "phy_error_draws, synthetic_exp or the library's state layout): the run would not continue as it began");
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   const char* in = (const char*)buf + sizeof h;
-  for (const CkptPart& q : ckpt_parts(b)) {
+  for (const StatePart& q : state_parts(b)) {
     if (q.p == (void*)b->d_tx && !b->queues) {
       /* the pending-grant words follow the kernel family that will consume them: a shape-specialised kernel wants bytes | PRBs << 20 with
        * "counted" set (the grant is in the cumulative totals already, whoever wrote it), the built-in kernels want plain bytes */
@@ -1505,8 +1665,8 @@ int rs_batch_prepare_launch(rs_batch* b, int32_t n_ttis) {
   if (b->cqi_mode == RS_CQI_NONE) return fail(RS_ERR_STATE, "no CQI source set");
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   (void)lean_kernel(b, n_ttis > RS_MAX_TTIS_PER_LAUNCH ? RS_MAX_TTIS_PER_LAUNCH : n_ttis, false);
-  if (b->cfg.selfcheck && !b->selfchecked) {
-    const int rc = selfcheck(b, n_ttis > RS_MAX_TTIS_PER_LAUNCH ? RS_MAX_TTIS_PER_LAUNCH : n_ttis);
+  if (!b->selfchecked) {
+    const int rc = selfcheck(b, n_ttis > RS_MAX_TTIS_PER_LAUNCH ? RS_MAX_TTIS_PER_LAUNCH : n_ttis, false);
     if (rc) return rc;
   }
   if (b->cfg.autotune && !b->autotuned) {
@@ -1601,6 +1761,21 @@ struct rs_ctx {
   size_t flag_off = 0; /* offset of the word in h_out / z_out: behind the largest layout, on its own cache line */
   long poll_us = 2000;
   long n_polled = 0, n_fallback = 0;
+  /* rs_tti_in.cqi_epoch (round 6): the grid of the last call whose reports were new, kept on the device as the LDS image ([R][Upad]);
+   * a call with the same epoch number and the same user list reads it instead of the caller's block (RsLaunch::image_mode) */
+  uint8_t* d_img = nullptr;
+  bool img_valid = false, img_prb = false, img_has_ids = false;
+  uint64_t img_epoch = 0;
+  int img_n = 0;
+  std::vector<int32_t> img_ids;
+  long n_img_reused = 0;
+  /* the specialised builds' check against the built-in kernel (rs_ctx_specialize; index 0: general build, 1: lean build):
+   * calls still to be checked, calls that agreed so far */
+  int chk_left[2] = {0, 0}, chk_agreed[2] = {0, 0};
+  bool jit_dropped = false;
+  uint8_t *d_out2 = nullptr, *d_chk = nullptr; /* the built-in kernel's output block; slice state + scalars before / after it */
+  std::vector<uint8_t> h_out2;
+  char jit_msg[512] = "";
 };
 
 namespace {
@@ -1671,7 +1846,11 @@ rs_ctx* rs_create(const rs_config* cfg) {
   c->in_bytes = l.in_total;
   c->flag_off = round_up(l.out_total, 64);
   c->out_bytes = c->flag_off + 64;
+  const size_t img_bytes = round_up(rs_upad_of(b->U) * b->R, 16);
+  const size_t chk_bytes = round_up(8 * b->S, 256) + round_up((int)sizeof(RsCellScalars), 256);
   bool ok = hipMalloc(&c->d_in, c->in_bytes) == hipSuccess && hipMalloc(&c->d_out, c->out_bytes) == hipSuccess &&
+            hipMalloc(&c->d_img, img_bytes) == hipSuccess && hipMalloc(&c->d_out2, c->out_bytes) == hipSuccess &&
+            hipMalloc(&c->d_chk, 2 * chk_bytes) == hipSuccess &&
             hipHostMalloc((void**)&c->h_in, c->in_bytes, hipHostMallocMapped) == hipSuccess &&
             hipHostMalloc((void**)&c->h_out, c->out_bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
   const char* force_copy = getenv("RS_DROPIN_COPY");
@@ -1689,17 +1868,30 @@ rs_ctx* rs_create(const rs_config* cfg) {
   c->poll = c->z_out != nullptr && !(pl && pl[0] == '0');
   if (const char* pu = getenv("RS_DROPIN_POLL_US")) c->poll_us = atol(pu) > 0 ? atol(pu) : 2000;
   if (c->h_out) memset(c->h_out + c->flag_off, 0, 64);
+  c->h_out2.assign(c->out_bytes, 0);
+  g_err[0] = 0;
+  if (cfg->link_tables == RS_LINK_DEFAULT) {
+    /* a drop-in context follows THIS host's libm (the reference beside it does); when that is not the libm of the fixtures, say so once */
+    char where[300] = "";
+    const int diff = rs_link_tables_compare(where, sizeof where);
+    if (diff > 0)
+      snprintf(g_err, sizeof g_err, "warning: this host's libm gives %d EESM constant(s) that differ from the pinned glibc-2.35 set (%.300s): the context "
+               "follows the host (RS_LINK_HOST_LIBM); RS_LINK_PINNED_GLIBC_2_35 reproduces the fixtures", diff, where);
+  }
   return c;
 }
 
 void rs_destroy(rs_ctx* c) {
   if (!c) return;
   if (c->timing && c->n_calls)
-    fprintf(stderr, "rs_schedule_tti x %ld: prepare %.2f us, enqueue %.2f us, wait %.2f us, unpack %.2f us per call (%ld completed by the polled word, %ld fell back to the stream)\n", c->n_calls,
-            c->t_prep / c->n_calls, c->t_enq / c->n_calls, c->t_wait / c->n_calls, c->t_unpack / c->n_calls, c->n_polled, c->n_fallback);
+    fprintf(stderr, "rs_schedule_tti x %ld: prepare %.2f us, enqueue %.2f us, wait %.2f us, unpack %.2f us per call (%ld completed by the polled word, %ld fell back to the stream, %ld read the device-resident CQI image)\n", c->n_calls,
+            c->t_prep / c->n_calls, c->t_enq / c->n_calls, c->t_wait / c->n_calls, c->t_unpack / c->n_calls, c->n_polled, c->n_fallback, c->n_img_reused);
   if (c->b && c->b->stream) (void)hipStreamSynchronize(c->b->stream);
   if (c->d_in) (void)hipFree(c->d_in);
   if (c->d_out) (void)hipFree(c->d_out);
+  if (c->d_img) (void)hipFree(c->d_img);
+  if (c->d_out2) (void)hipFree(c->d_out2);
+  if (c->d_chk) (void)hipFree(c->d_chk);
   if (c->h_in) (void)hipHostFree(c->h_in);
   if (c->h_out) (void)hipHostFree(c->h_out);
   rs_batch_destroy(c->b);
@@ -1728,18 +1920,27 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   }
   const int G = b->G;
   size_t in_bytes = l.prb; /* the per-PRB block travels only when given */
+  /* rs_tti_in.cqi_epoch: the same reports for the same users as the call before?  Then the caller's block is not touched -- the kernel
+   * reads the image the context kept on the device (and, per-PRB reports, the device copy of the block) */
+  const bool same_users = c->img_valid && c->img_n == n && c->img_has_ids == (in->user_id != nullptr) &&
+                          (!in->user_id || memcmp(c->img_ids.data(), in->user_id, 4 * (size_t)n) == 0);
+  const bool reuse_grid = in->cqi_epoch != 0 && same_users && in->cqi_epoch == c->img_epoch && c->img_prb == (in->cqi_prb != nullptr);
+  const int image_mode = in->cqi_epoch == 0 ? 0 : (reuse_grid ? 2 : 1);
   if (in->cqi_prb) {
     const size_t np = (size_t)n * R * G;
-    if (const uint8_t* bad = first_bad_cqi(in->cqi_prb, np)) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", *bad);
-    memcpy(c->h_in + l.prb, in->cqi_prb, np);
-    for (int i = 0; i < n; i++)
-      for (int r = 0; r < R; r++) c->h_in[l.grid + (size_t)i * R + r] = in->cqi_prb[((size_t)i * R + r) * G];
+    if (!reuse_grid) {
+      if (const uint8_t* bad = first_bad_cqi(in->cqi_prb, np)) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", *bad);
+      memcpy(c->h_in + l.prb, in->cqi_prb, np);
+      for (int i = 0; i < n; i++)
+        for (int r = 0; r < R; r++) c->h_in[l.grid + (size_t)i * R + r] = in->cqi_prb[((size_t)i * R + r) * G];
+    }
     in_bytes = l.prb + np;
-  } else {
+  } else if (!reuse_grid) {
     if (const uint8_t* bad = first_bad_cqi(in->cqi, (size_t)n * R)) return fail(RS_ERR_INVALID, "CQI %d outside 1..15", *bad);
     memcpy(c->h_in + l.grid, in->cqi, (size_t)n * R);
   }
-  memset(c->h_in + l.grid + (size_t)n * R, 0, l.slice - (size_t)n * R);
+  if (!reuse_grid) memset(c->h_in + l.grid + (size_t)n * R, 0, l.slice - (size_t)n * R);
+  c->img_valid = false; /* (until this call has gone through) */
   memcpy(c->h_in + l.avg, in->avg_rate, 8 * (size_t)n);
   if (b->gen_exp) {
     /* general exponents: pow(averageRate / 1000.0, psi) with averageRate = 1 + the caller's sum (ref: :681-693), host libm */
@@ -1801,7 +2002,11 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   const bool zc = c->z_in != nullptr && !in->cqi_prb && !b->any_alpha;
   uint8_t* const dev_in = zc ? c->z_in : c->d_in;
   uint8_t* const dev_out = zc ? c->z_out : c->d_out;
-  if (!zc) HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, st));
+  if (!zc) {
+    /* (an unchanged report set: the grid and the per-PRB block are on the device already; the per-call words lie between them) */
+    if (reuse_grid) HIP_TRY(hipMemcpyAsync(c->d_in + l.slice, c->h_in + l.slice, l.prb - l.slice, hipMemcpyHostToDevice, st));
+    else HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, in_bytes, hipMemcpyHostToDevice, st));
+  }
   RsLaunch L = b->base;
   L.U = n;
   L.Upad = upad_of(n);
@@ -1817,6 +2022,8 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   L.user_slice = dev_in + l.slice;
   L.avg = (double*)(dev_in + l.avg);
   L.prb_cqi = in->cqi_prb ? dev_in + l.prb : nullptr;
+  L.grid_image = c->d_img;
+  L.image_mode = image_mode;
   L.queue_mode = b->any_alpha ? 1 : 0;
   L.hol = (const double*)(dev_in + l.hol);
   L.prio = dev_in + l.prio;
@@ -1837,8 +2044,35 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
   /* rs_ctx_specialize: this context's own build of the one-TTI kernel -- its lean form for the plain call (per-RBG CQI, no customised
    * slices, no gates, exponents in {0, 1}, every input inside the FP32 filter's range), the general one otherwise */
   RsJitKernel* kd = b->jit;
-  if (b->jit_lean && !L.prb_cqi && !L.queue_mode && !L.gate && !L.exact_scan && !L.gen_exp && !L.log_upper && !L.synthetic) kd = b->jit_lean;
-  const bool poll = zc && c->poll;
+  int which = 0; /* 0: general build, 1: lean build */
+  if (b->jit_lean && !L.prb_cqi && !L.queue_mode && !L.gate && !L.exact_scan && !L.gen_exp && !L.log_upper && !L.synthetic) { kd = b->jit_lean; which = 1; }
+  /* A run-time build that does not carry the self-check mark serves its first calls beside the built-in kernel (rs_ctx_jit_status):
+   * same inputs, same slice state; every output field and the slice state left behind must agree. */
+  const bool checked_call = kd != nullptr && c->chk_left[which] > 0;
+  const size_t sstate_bytes = 8 * (size_t)S, chk_half = round_up((int)sstate_bytes, 256) + round_up((int)sizeof(RsCellScalars), 256);
+  if (checked_call) {
+    uint8_t* const before = c->d_chk;
+    uint8_t* const after = c->d_chk + chk_half;
+    HIP_TRY(hipMemcpyAsync(before, b->d_sstate, sstate_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(before + round_up((int)sstate_bytes, 256), b->d_scal, sizeof(RsCellScalars), hipMemcpyDeviceToDevice, st));
+    RsLaunch Lb = L; /* the built-in kernel, its outputs into a block of its own */
+    Lb.log_tbs = (int32_t*)(c->d_out2 + l.tbs);
+    Lb.log_uinfo = (int32_t*)(c->d_out2 + l.uinfo);
+    Lb.log_map = (int16_t*)(c->d_out2 + l.map);
+    Lb.log_quota = (int16_t*)(c->d_out2 + l.quota);
+    Lb.log_target = (int16_t*)(c->d_out2 + l.target);
+    Lb.log_upper = want_upper ? (int32_t*)(c->d_out2 + l.upper) : nullptr;
+    Lb.done_flag = nullptr;
+    HIP_TRY(rs_launch_cells(&Lb, b->threads, st));
+    HIP_TRY(hipMemcpyAsync(c->h_out2.data(), c->d_out2, l.out_total, hipMemcpyDeviceToHost, st));
+    /* keep what it left, put back what it found: the specialised kernel starts from the same state */
+    HIP_TRY(hipMemcpyAsync(after, b->d_sstate, sstate_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_sstate, before, sstate_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->d_scal, before + round_up((int)sstate_bytes, 256), sizeof(RsCellScalars), hipMemcpyDeviceToDevice, st));
+    /* (a call with new reports: BOTH kernels transpose the caller's block and store the image -- the same bytes when the build is right;
+     * a wrong image would show in the checked calls that read it) */
+  }
+  const bool poll = zc && c->poll && !checked_call;
   volatile uint32_t* const h_flag = (volatile uint32_t*)(c->h_out + c->flag_off);
   if (poll) {
     if (++c->seq == 0) c->seq = 1; /* (0 is the word's initial value) */
@@ -1867,6 +2101,64 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
     }
   }
   if (!seen) HIP_TRY(hipStreamSynchronize(st));
+  if (checked_call) {
+    /* field by field: the first difference is the message */
+    std::vector<double> ss_jit(S), ss_ref(S);
+    HIP_TRY(hipMemcpy(ss_jit.data(), b->d_sstate, sstate_bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ss_ref.data(), c->d_chk + chk_half, sstate_bytes, hipMemcpyDeviceToHost));
+    const uint8_t *ho = c->h_out, *hr = c->h_out2.data();
+    char what[200] = "";
+    auto differ32 = [&](const char* name, size_t off, int count) {
+      const int32_t *a = (const int32_t*)(ho + off), *r = (const int32_t*)(hr + off);
+      for (int i = 0; i < count && !what[0]; i++)
+        if (a[i] != r[i]) snprintf(what, sizeof what, "%s[%d] = %d, the built-in kernel's %d", name, i, a[i], r[i]);
+    };
+    auto differ16 = [&](const char* name, size_t off, int count) {
+      const int16_t *a = (const int16_t*)(ho + off), *r = (const int16_t*)(hr + off);
+      for (int i = 0; i < count && !what[0]; i++)
+        if (a[i] != r[i]) snprintf(what, sizeof what, "%s[%d] = %d, the built-in kernel's %d", name, i, a[i], r[i]);
+    };
+    differ16("rbg_to_user (call position)", l.map, R);
+    differ16("quota_rbgs", l.quota, S);
+    differ16("target_rbs", l.target, S);
+    differ32("user_tbs_bits", l.tbs, n);
+    differ32("user_nprb | final_cqi << 16 | mcs << 24", l.uinfo, n);
+    if (want_upper) differ32("upper lists", l.upper, S * R);
+    for (int i = 0; i < S && !what[0]; i++)
+      if (to_bits(ss_jit[i]) != to_bits(ss_ref[i])) snprintf(what, sizeof what, "slice state[%d] = %a, the built-in kernel's %a", i, ss_jit[i], ss_ref[i]);
+    if (what[0]) {
+      /* the build is wrong: drop it (and its cache file), serve this call and all later ones from the built-in kernel */
+      rs_jit_reject(kd);
+      if (b->jit && b->jit != kd) rs_jit_reject(b->jit); /* (one wrong build of a shape: neither is trusted) */
+      if (b->jit_lean && b->jit_lean != kd) rs_jit_reject(b->jit_lean);
+      b->jit = nullptr;
+      b->jit_lean = nullptr;
+      c->jit_dropped = true;
+      c->chk_left[0] = c->chk_left[1] = 0;
+      memcpy(c->h_out, hr, l.out_total);
+      HIP_TRY(hipMemcpy(b->d_sstate, c->d_chk + chk_half, sstate_bytes, hipMemcpyDeviceToDevice));
+      snprintf(c->jit_msg, sizeof c->jit_msg, "self-check of the specialised %s build, checked call %d: %s; the build is dropped, the built-in kernel serves this "
+               "context (lint the code object: tools/lint_exec_restore.py)", which ? "lean" : "general", c->chk_agreed[which] + 1, what);
+      snprintf(g_err, sizeof g_err, "%s", c->jit_msg);
+    } else {
+      c->chk_agreed[which]++;
+      if (--c->chk_left[which] == 0) {
+        rs_jit_mark_verified(kd);
+        snprintf(c->jit_msg, sizeof c->jit_msg, "self-check: %d calls of the general and %d of the lean build agreed with the built-in kernel field by field",
+                 c->chk_agreed[0], c->chk_agreed[1]);
+      }
+    }
+  }
+  if (image_mode != 0) {
+    /* the device holds this call's reports now */
+    c->img_valid = true;
+    c->img_epoch = in->cqi_epoch;
+    c->img_n = n;
+    c->img_prb = in->cqi_prb != nullptr;
+    c->img_has_ids = in->user_id != nullptr;
+    if (in->user_id && !reuse_grid) c->img_ids.assign(in->user_id, in->user_id + n);
+    if (reuse_grid) c->n_img_reused++;
+  }
   const clk::time_point t3 = c->timing ? clk::now() : clk::time_point();
   const int16_t* h_map = (const int16_t*)(c->h_out + l.map);
   const int16_t* h_quota = (const int16_t*)(c->h_out + l.quota);
@@ -1918,19 +2210,42 @@ int rs_ctx_specialize(rs_ctx* c) {
   if (!c) return fail(RS_ERR_INVALID, "null context");
   rs_batch* b = c->b;
   if (b->jit) return RS_OK;
+  if (c->jit_dropped) return fail(RS_ERR_STATE, "%s", c->jit_msg);
   HIP_TRY(hipSetDevice(b->cfg.cell.device));
   const bool gate_scratch = b->sched == RS_SCHED_PF || b->sched == RS_SCHED_NVS;
   b->jit_wanted = true;
   b->jit = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, gate_scratch ? 1 : 0, 0, b->jit_msg, sizeof b->jit_msg, 1);
-  if (!b->jit) return fail(RS_ERR_HIP, "%s", b->jit_msg[0] ? b->jit_msg : "hiprtc build failed");
+  if (!b->jit) {
+    snprintf(c->jit_msg, sizeof c->jit_msg, "%s", b->jit_msg[0] ? b->jit_msg : "hiprtc build failed");
+    return fail(RS_ERR_HIP, "%s", c->jit_msg);
+  }
   b->jit_msg[0] = 0;
+  c->jit_msg[0] = 0;
   /* ... and its lean form (the per-call options of the plain call as constants); without it the general build serves every call */
   const char* const e_on = getenv("RS_JIT_LEAN");
   if (!e_on || atoi(e_on) != 0) {
     char msg[512] = "";
     b->jit_lean = rs_jit_get(b->cfg.cell.device, b->S, b->U, b->R, b->G, b->threads, b->sched, gate_scratch ? 1 : 0, 0, msg, sizeof msg, 1 | 4);
   }
+  /* how many calls each build serves beside the built-in kernel before it is trusted (see rs_ctx_jit_status in the header): none for a
+   * build that came from the cache with the mark of an earlier process's check */
+  int calls = 8;
+  if (const char* e = getenv("RS_DROPIN_SELFCHECK_CALLS")) calls = atoi(e) > 0 ? atoi(e) : 0;
+  const char* pol = getenv("RS_JIT_SELFCHECK");
+  const bool never = pol && pol[0] == '0', always = pol && pol[0] == '2';
+  c->chk_agreed[0] = c->chk_agreed[1] = 0;
+  c->chk_left[0] = (!never && (always || !rs_jit_is_verified(b->jit))) ? calls : 0;
+  c->chk_left[1] = (b->jit_lean && !never && (always || !rs_jit_is_verified(b->jit_lean))) ? calls : 0;
+  if (!never && !c->chk_left[0] && !c->chk_left[1] && calls)
+    snprintf(c->jit_msg, sizeof c->jit_msg, "the run-time builds carry the self-check mark of the process that compiled them (cache files)");
   return RS_OK;
+}
+
+int rs_ctx_jit_status(rs_ctx* c, char* msg, size_t msglen) {
+  if (!c) return fail(RS_ERR_INVALID, "null context");
+  if (msg && msglen) snprintf(msg, msglen, "%s", c->jit_msg);
+  if (c->jit_dropped) return -2;
+  return c->b->jit ? 1 : (c->b->jit_wanted ? -1 : 0);
 }
 
 int rs_get_slice_offset(rs_ctx* c, double* offset) {

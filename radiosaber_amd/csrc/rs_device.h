@@ -282,7 +282,7 @@ struct RsLaunch {
   const int32_t* gate;       /* drop-in mode, optional [U]: m_requiredRBs (sched 7) / dataToTransmit bytes (sched 1); NULL = backlogged */
   int32_t* log_upper;        /* sched 10, drop-in mode: [S][R] (rbg | user << 8), -1 padded; NULL = off */
   const uint8_t* draws;      /* sched 11, drop-in mode: rand() % 4 of the RS_NVS_SAMPLES x U draws, in draw order */
-  const int32_t* tbs_eff;    /* [R+1][27] TBS bits of n RBGs (n*G PRBs) at itbs, incl. the >110-PRB rule */
+  const int32_t* tbs_eff;    /* [R+1][16] TBS bits of n RBGs (n*G PRBs) at a final CQI (the CQI -> MCS -> I_TBS step folded in by the host), incl. the >110-PRB rule */
   /* state */
   double* avg;               /* [cells][U] */
   int32_t* tx_bytes;         /* [cells][U] */
@@ -319,6 +319,12 @@ struct RsLaunch {
    * scope, after every thread's outputs): rs_schedule_tti polls it instead of waiting for the stream's completion signal */
   uint32_t* done_flag;
   uint32_t done_seq;
+  /* drop-in mode, rs_tti_in.cqi_epoch (round 6): the context keeps the call's CQI grid on the device in the layout of the LDS grid
+   * (RBG-major [R][Upad], zero padding included).  image_mode 0: no image (cqi_epoch = 0); 1: the reports changed -- transpose the
+   * caller's [U][R] block as always, then store the LDS grid to grid_image; 2: same reports as the call before -- a straight 16-byte
+   * copy of grid_image into LDS, the caller's block is not read (39 calls of 40 in the reference: CQI_INTERVAL 40) */
+  uint8_t* grid_image;
+  int32_t image_mode;
   /* batches: cells per dispatch round = the device's compute units, when the batch puts exactly two cells on every CU (0: no
    * priority balancing between co-resident cells, RS_SETPRIO in rs_kernels.hip) */
   int32_t prio_round_cells;

@@ -325,14 +325,19 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * MaximizeCell 500 UEs x 25 RBGs 41.0 against 43.0, 100 x 64 53.8 against 55.0 -- but 500 x 64 (four grid words per thread)
    * 70.2 against 68.8, GreedyByRow 37.0 against 35.9, NVS 29.0 against 26.2: MaximizeCell with at most two grid words per thread. */
   constexpr int kPU = (FIXED && DIRECT) ? (RS_JIT_U + RS_JIT_NT - 1) / RS_JIT_NT : 1;
-  constexpr int kPG = (FIXED && DIRECT) ? ((RS_JIT_U * RS_JIT_R + 15) / 16 + RS_JIT_NT - 1) / RS_JIT_NT : 1;
+  /* (grid words per thread: the caller's [U][R] block, or the context's device-resident image of it -- [R][Upad], a little larger) */
+  constexpr int kPGsrc = (FIXED && DIRECT) ? ((RS_JIT_U * RS_JIT_R + 15) / 16 + RS_JIT_NT - 1) / RS_JIT_NT : 1;
+  constexpr int kPGimg = (FIXED && DIRECT) ? ((rs_upad_of(RS_JIT_U) * RS_JIT_R + 15) / 16 + RS_JIT_NT - 1) / RS_JIT_NT : 1;
+  constexpr int kPG = kPGsrc > kPGimg ? kPGsrc : kPGimg;
   constexpr bool kPrefetch = FIXED && DIRECT && SCHED == 9 && kPG <= 2;
+  /* rs_tti_in.cqi_epoch: this call's reports are the previous call's -- the grid comes from the context's image in HBM, as stored */
+  const bool grid_from_image = DIRECT && p.image_mode == 2;
   double pre_avg[kPU];
   int pre_sl[kPU];
   uint4 pre_grid[kPG];
   if constexpr (kPrefetch) {
-    const uint4* src = (const uint4*)p.epochs;
-    const int n16 = (int)(p.grid_stride >> 4);
+    const uint4* src = grid_from_image ? (const uint4*)p.grid_image : (const uint4*)p.epochs;
+    const int n16 = grid_from_image ? (R * (int)p.Upad + 15) >> 4 : (int)(p.grid_stride >> 4);
 #pragma unroll
     for (int k = 0; k < kPU; ++k) {
       const int u = tid + k * nt;
@@ -378,8 +383,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
   }
   /* TBS bits of n RBGs at a final CQI: the I_TBS step of CQI -> MCS -> I_TBS -> TBS folded in ([R+1][16]) */
-  for (int i = tid; i < (R + 1) * 16; i += nt) s_tbs[i] = p.tbs_eff[(i >> 4) * 27 + tab->itbs_of_cqi[i & 15]];
-  for (int i = tid; i < (R * Upad) >> 2; i += nt) ((uint32_t*)s_cqi)[i] = 0;
+  for (int i = tid; i < (R + 1) * 16; i += nt) s_tbs[i] = p.tbs_eff[i];
+  /* (the transposing refresh of a drop-in call writes bytes into a zeroed grid; an image, like a batch's grids, carries its padding) */
+  if (!grid_from_image)
+    for (int i = tid; i < (R * Upad) >> 2; i += nt) ((uint32_t*)s_cqi)[i] = 0;
   for (int i = tid; i < Upad + 16 * S; i += nt) s_rcp32[i] = 0.0f;
   if (tid < 16) {
     s_num[tid] = (SCHED == 1 || SCHED == 11) ? tab->pfnum[tid] : tab->kbps[tid];

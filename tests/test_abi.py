@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(rs):
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/radiosaber_hip.h but not exported"
     assert sorted(api.ABI_SYMBOLS) == declared
-    assert L.rs_abi_version() == 10
+    assert L.rs_abi_version() == 11
 
 
 def test_code_object_is_gfx950(rs):

@@ -53,7 +53,7 @@ def test_key_follows_the_options_and_the_variant(rs, tmp_path):
     assert len(list(tmp_path.glob("*.rsco"))) == 4
     # the key text (source hash, hiprtc version, every option) is stored in the file
     head = Path(a).read_bytes()[:4096]
-    assert head.startswith(b"RSJC1\n") and rs.device_source_hash().encode() in head and b"-DRS_JIT_S=4\n" in head
+    assert head.startswith(b"RSJC2\n") and rs.device_source_hash().encode() in head and b"-DRS_JIT_S=4\n" in head
 
 
 def test_corrupt_truncated_and_foreign_files_are_compiled_again(rs, tmp_path):

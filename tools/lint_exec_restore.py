@@ -100,10 +100,11 @@ def disassemble(code_object_bytes):
 
 
 def code_of_cache_file(path):
-    """radiosaber_amd's disk cache entry (rs_jit.cpp): "RSJC1\\n" | u64 key length | key | u64 code length | u64 checksum | code"""
+    """radiosaber_amd's disk cache entry (rs_jit.cpp): "RSJC2\\n" | u64 key length | key | u64 code length | u64 checksum | code | 8-byte
+    self-check mark ("VERIFIED" / "UNCHECKD")"""
     import struct
     b = open(path, "rb").read()
-    assert b[:6] == b"RSJC1\n", path
+    assert b[:6] == b"RSJC2\n", path
     klen = struct.unpack_from("<Q", b, 6)[0]
     key = b[14:14 + klen].decode()
     clen = struct.unpack_from("<Q", b, 14 + klen)[0]
