@@ -8,7 +8,8 @@ from .api import (  # noqa: F401
     RS_SCHED_MAXCELL, RS_SCHED_NVS, RS_SCHED_PF, RS_SCHED_NVS_NONGREEDY, RS_SCHED_SEQUENTIAL, RS_SCHED_UPPERBOUND, RS_SCHED_VOGEL, RS_SCHED_SUBOPT,
     BEARER_BACKLOG, BEARER_NONE, BEARER_QUEUE, FULL_PACKET, TRACE_CQI_HISTOGRAM, frames_to_bursts, internet_flow_arrivals,
     BatchScheduler, RadioSaberError, SliceConfig, TtiResult, TtiScheduler, device_count, device_source_hash, dl_prbs_for_bandwidth, get_rbg_size, hbm_copy_probe, jit_selfcheck, lds_bytes_per_cell,
-    jit_cache_file, jit_cache_stats, jit_cache_warm, lib,
+    jit_cache_file, jit_cache_stats, jit_cache_warm, jit_compiler_identity, lib, link_tables_compare,
+    RS_LINK_DEFAULT, RS_LINK_HOST_LIBM, RS_LINK_PINNED_GLIBC_2_35,
     link_tables, load_trace_dir, read_trace_mapping, read_ue_trace,
 )
 
@@ -16,4 +17,5 @@ __all__ = ["RS_SCHED_PF", "RS_SCHED_NVS", "RS_SCHED_SEQUENTIAL", "RS_SCHED_MAXCE
            "TtiScheduler", "TtiResult", "BatchScheduler", "RadioSaberError", "device_count", "lib",
            "link_tables", "jit_selfcheck", "device_source_hash", "TRACE_CQI_HISTOGRAM", "read_trace_mapping", "read_ue_trace",
            "load_trace_dir", "hbm_copy_probe", "lds_bytes_per_cell", "get_rbg_size", "dl_prbs_for_bandwidth", "internet_flow_arrivals", "frames_to_bursts",
-           "BEARER_NONE", "BEARER_BACKLOG", "BEARER_QUEUE", "FULL_PACKET", "jit_cache_file", "jit_cache_stats", "jit_cache_warm"]
+           "BEARER_NONE", "BEARER_BACKLOG", "BEARER_QUEUE", "FULL_PACKET", "jit_cache_file", "jit_cache_stats", "jit_cache_warm",
+           "jit_compiler_identity", "link_tables_compare", "RS_LINK_DEFAULT", "RS_LINK_HOST_LIBM", "RS_LINK_PINNED_GLIBC_2_35"]

@@ -1048,7 +1048,7 @@ int launch(rs_batch* b, int n_ttis, int16_t* d_map, int16_t* d_quota, int16_t* d
     const int rc = selfcheck(b, n_ttis, logged); /* (its trials come back through here with `in_selfcheck` set) */
     if (rc) return rc;
   }
-  if (b->cfg.autotune && !b->autotuned && !logged) {
+  if (b->cfg.autotune && !b->autotuned && !logged && !b->in_selfcheck) { /* (never inside a self-check trial: it checks the rule table's build) */
     const int rc = autotune(b, n_ttis);
     if (rc) return rc;
   }
@@ -2142,11 +2142,7 @@ int rs_schedule_tti(rs_ctx* c, const rs_tti_in* in, rs_tti_out* out) {
       snprintf(g_err, sizeof g_err, "%s", c->jit_msg);
     } else {
       c->chk_agreed[which]++;
-      if (--c->chk_left[which] == 0) {
-        rs_jit_mark_verified(kd);
-        snprintf(c->jit_msg, sizeof c->jit_msg, "self-check: %d calls of the general and %d of the lean build agreed with the built-in kernel field by field",
-                 c->chk_agreed[0], c->chk_agreed[1]);
-      }
+      if (--c->chk_left[which] == 0) rs_jit_mark_verified(kd);
     }
   }
   if (image_mode != 0) {
@@ -2236,16 +2232,32 @@ int rs_ctx_specialize(rs_ctx* c) {
   c->chk_agreed[0] = c->chk_agreed[1] = 0;
   c->chk_left[0] = (!never && (always || !rs_jit_is_verified(b->jit))) ? calls : 0;
   c->chk_left[1] = (b->jit_lean && !never && (always || !rs_jit_is_verified(b->jit_lean))) ? calls : 0;
-  if (!never && !c->chk_left[0] && !c->chk_left[1] && calls)
-    snprintf(c->jit_msg, sizeof c->jit_msg, "the run-time builds carry the self-check mark of the process that compiled them (cache files)");
   return RS_OK;
 }
 
 int rs_ctx_jit_status(rs_ctx* c, char* msg, size_t msglen) {
   if (!c) return fail(RS_ERR_INVALID, "null context");
-  if (msg && msglen) snprintf(msg, msglen, "%s", c->jit_msg);
+  rs_batch* b = c->b;
+  if (msg && msglen) {
+    if (c->jit_dropped || !b->jit) {
+      snprintf(msg, msglen, "%s", c->jit_msg);
+    } else {
+      /* per build: how it earned (or is still earning) its trust */
+      auto state = [&](RsJitKernel* k, int which, char* out, size_t n) {
+        if (!k) snprintf(out, n, "not built");
+        else if (c->chk_left[which] > 0) snprintf(out, n, "%d checked call(s) agreed with the built-in kernel field by field, %d to go", c->chk_agreed[which], c->chk_left[which]);
+        else if (c->chk_agreed[which] > 0) snprintf(out, n, "verified (%d checked calls agreed with the built-in kernel field by field)", c->chk_agreed[which]);
+        else if (rs_jit_is_verified(k)) snprintf(out, n, "carries the self-check mark of an earlier check (cache file)");
+        else snprintf(out, n, "unchecked (RS_JIT_SELFCHECK=0)");
+      };
+      char g[160], l[160];
+      state(b->jit, 0, g, sizeof g);
+      state(b->jit_lean, 1, l, sizeof l);
+      snprintf(msg, msglen, "general build: %s; lean build: %s", g, l);
+    }
+  }
   if (c->jit_dropped) return -2;
-  return c->b->jit ? 1 : (c->b->jit_wanted ? -1 : 0);
+  return b->jit ? 1 : (b->jit_wanted ? -1 : 0);
 }
 
 int rs_get_slice_offset(rs_ctx* c, double* offset) {

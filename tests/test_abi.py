@@ -35,12 +35,39 @@ def test_code_object_is_gfx950(rs):
     assert b"gfx950" in data and b"rs_cell_kernel" in data
 
 
-def test_link_tables_match_reference_known_answers(rs):
+def _check_link_tables(rs):
+    """This machine's libm against the pinned glibc-2.35 set and against the values the unmodified reference printed."""
+    hex_of = lambda a: [float.hex(float(x)) for x in a]  # noqa: E731
+    want_e = [float.hex(float.fromhex(h)) for h in KA["eesm_E_hex"]]
+    want_x = [float.hex(float.fromhex(h)) for h in KA["eesm_X_hex"]]
+    pinned = rs.link_tables(pinned=True)
+    assert pinned["eff"][1:].tolist() == KA["eff_of_cqi"] and pinned["kbps"][1:].tolist() == KA["kbps_of_cqi"]
+    assert hex_of(pinned["eesm_e"][1:]) == want_e and hex_of(pinned["eesm_x"][1:14]) == want_x, "the pinned set is not Appendix A's"
     t = rs.link_tables()
     assert t["eff"][1:].tolist() == KA["eff_of_cqi"]
     assert t["kbps"][1:].tolist() == KA["kbps_of_cqi"]
-    assert [float.hex(x) for x in t["eesm_e"][1:]] == [float.hex(float.fromhex(h)) for h in KA["eesm_E_hex"]]
-    assert [float.hex(x) for x in t["eesm_x"][1:14]] == [float.hex(float.fromhex(h)) for h in KA["eesm_X_hex"]]
+    n, text = rs.link_tables_compare()
+    import platform
+    libc = " ".join(platform.libc_ver())
+    assert n == 0 and hex_of(t["eesm_e"][1:]) == want_e and hex_of(t["eesm_x"][1:14]) == want_x, \
+        f"this machine's libm ({libc}) gives {n} EESM constant(s) that differ from glibc 2.35's: {text}"
+    return libc
+
+
+def test_link_tables_match_reference_known_answers(rs):
+    _check_link_tables(rs)
+
+
+@pytest.mark.gpu
+def test_link_tables_of_the_gpu_box_match_reference_known_answers(rs):
+    """the same check where the GPU runs -- there the device and the oracle share the box's libm, so they would agree
+    with each other whatever it returned; this is the test that says which libm the box has and that it is the fixtures'."""
+    libc = _check_link_tables(rs)
+    print(f"GPU box libm: {libc}; host-evaluated EESM constants == pinned glibc-2.35 set == SURVEY Appendix A")
+    # a drop-in context created with the default follows the host's libm and has nothing to warn about here
+    ts = rs.TtiScheduler(rs.SliceConfig([2, 2]), 12, 2)
+    assert ts.create_warning == "", ts.create_warning
+    ts.close()
 
 
 def test_threshold_classification_equals_libm_formula(rs, oracle):

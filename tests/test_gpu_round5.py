@@ -176,9 +176,10 @@ def test_selfcheck_drops_a_wrong_run_time_build(rs, oracle, monkeypatch):
         cell = oracle.Cell(ues, R, G, 9)
         cell.run_synth(grids[c], 5 + c, 300, log=False)
         np.testing.assert_array_equal(st["cum_bytes"][c], cell.state()["cum_bytes"])
-    # without the self-check the wrong build would have served the batch -- the fault injection really bites
+    # without the self-check the wrong build would have served the batch -- the fault injection really bites (selfcheck = -1: since
+    # round 6 the check is on by default; another workgroup size = another code object: the first one is rejected for this process)
     sc = rs.SliceConfig(ues)
-    b = rs.BatchScheduler(sc, R, G, 1, sched=9, jit=True)
+    b = rs.BatchScheduler(sc, R, G, 1, sched=9, jit=True, selfcheck=-1, threads_per_cell=256)
     b.seed(np.array([5], np.uint32))
     b.synthesize_cqi(11, 24)
     b.run(300)

@@ -85,3 +85,58 @@ def test_switch_and_unwritable_directory(rs, tmp_path):
     blocked.write_text("x")
     r = _child(blocked / "sub")  # mkdir fails: the kernel still compiles, nothing is stored
     assert r["size"] > 0 and r["stats"]["stores"] == 0 and r["stats"]["misses"] == 1
+
+
+# ---- round 6: the compiler's full identity in the key, the self-check mark, whose files are trusted ----
+
+def test_compiler_identity_names_the_compiler_down_to_its_commit(rs):
+    ident = rs.jit_compiler_identity()
+    # hiprtc major.minor alone was the key until round 5; a patch-level update must change the text
+    assert "hiprtc " in ident and "hip-runtime " in ident and "clang " in ident, ident
+    rt = int(ident.split("hip-runtime ")[1].split()[0])
+    assert rt > 10_000_000 and rt % 100_000 != 0, ident          # major * 10^7 + minor * 10^5 + PATCH
+    clang = ident.split("clang ")[1]
+    assert any(len(tok.strip("()")) == 40 and all(ch in "0123456789abcdef" for ch in tok.strip("()")) for tok in clang.split()), \
+        f"no 40-digit LLVM commit in the clang version string: {clang!r}"
+    head = None
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        f = Path(_child(d)["file"])
+        head = f.read_bytes()[:4096]
+    assert ident.encode() in head, "the identity is not part of the stored key text"
+
+
+def test_two_compiler_identities_give_two_files(rs, tmp_path):
+    """VERDICT r05 #2: yesterday's code objects must not be served after a compiler update.  RS_JIT_COMPILER_ID stands in for one."""
+    a = _child(tmp_path, env_extra={"RS_JIT_COMPILER_ID": "hiprtc 9.0 patch 26015 clang 22.0.0git aaaa"})
+    b = _child(tmp_path, env_extra={"RS_JIT_COMPILER_ID": "hiprtc 9.0 patch 26016 clang 22.0.0git bbbb"})
+    assert a["file"] != b["file"] and a["stats"]["misses"] == 1 and b["stats"]["misses"] == 1
+    assert len(list(tmp_path.glob("*.rsco"))) == 2
+    again = _child(tmp_path, env_extra={"RS_JIT_COMPILER_ID": "hiprtc 9.0 patch 26015 clang 22.0.0git aaaa"})
+    assert again["file"] == a["file"] and again["stats"]["hits"] == 1
+
+
+def test_new_files_are_unchecked_private_and_foreign_or_writable_files_are_not_trusted(rs, tmp_path):
+    cache = tmp_path / "deep" / "cache"
+    first = _child(cache)
+    f = Path(first["file"])
+    assert f.read_bytes()[-8:] == b"UNCHECKD"                     # no process has self-checked it yet (that needs a GPU)
+    assert (cache.stat().st_mode & 0o077) == 0 and (f.stat().st_mode & 0o077) == 0, "the cache is the caller's alone"
+    # a file somebody else could have written is compiled again, not run
+    f.chmod(0o666)
+    r = _child(cache)
+    assert r["stats"] == {"hits": 0, "misses": 1, "stores": 1, "rejected": 1}
+    assert (f.stat().st_mode & 0o077) == 0
+    # ... unless the deployment says the cache is shared
+    f.chmod(0o664)
+    assert _child(cache, env_extra={"RS_JIT_CACHE_SHARED": "1"})["stats"]["hits"] == 1
+    # the mark is 8 bytes at the end, rewritten in place: a file that carries it is a hit like any other
+    b = bytearray(f.read_bytes())
+    b[-8:] = b"VERIFIED"
+    f.chmod(0o600)
+    f.write_bytes(bytes(b))
+    assert _child(cache)["stats"] == {"hits": 1, "misses": 0, "stores": 0, "rejected": 0}
+    # anything else in those 8 bytes just means "unchecked"
+    b[-8:] = b"whatever"
+    f.write_bytes(bytes(b))
+    assert _child(cache)["stats"]["hits"] == 1
