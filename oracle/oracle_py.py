@@ -96,6 +96,9 @@ def lib():
         L.rso_run_synth_many.argtypes = [C.POINTER(_Config), C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int,
                                          C.POINTER(C.c_uint), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int)]
+        L.rso_run_synth_cells.argtypes = [C.POINTER(_Config), C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.POINTER(C.c_uint), C.c_int,
+                                          C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.rso_cell_enable_queues.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         L.rso_cell_set_arrivals.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_int32)]
@@ -383,6 +386,26 @@ def run_synth_many(template, n_cells, cqi_epochs, seeds, n_ttis, threads=0, refr
     if rc:
         raise RuntimeError(f"rso_run_synth_many rc={rc}")
     return int(total.value), int(used.value)
+
+
+def run_synth_cells(template, cqi_epochs, seeds, n_ttis, threads=0, refresh=40, phy_error_draws=0):
+    """Independent cells configured like `template`, each on its own epochs cqi_epochs [n_cells][n_epochs][U][R], OpenMP over the host
+    cores.  Returns the cells' final state: dict(avg_rate, cum_bytes, cum_rbs [n_cells][U], slice_state [n_cells][S], threads)."""
+    e = np.ascontiguousarray(cqi_epochs, np.uint8)
+    n_cells = e.shape[0]
+    assert e.ndim == 4 and e.shape[2:] == (template.U, template.R)
+    sd = np.ascontiguousarray(seeds, np.uint32)
+    assert sd.shape == (n_cells,)
+    avg = np.zeros((n_cells, template.U), np.float64)
+    cb = np.zeros((n_cells, template.U), np.int64)
+    cr = np.zeros((n_cells, template.U), np.int64)
+    sl = np.zeros((n_cells, template.S), np.float64)
+    used = C.c_int(0)
+    rc = lib().rso_run_synth_cells(C.byref(template.cfg), n_cells, _p(e, C.c_uint8), e.shape[1], refresh, _p(sd, C.c_uint), phy_error_draws,
+                                   n_ttis, threads, _p(avg, C.c_double), _p(cb, C.c_int64), _p(cr, C.c_int64), _p(sl, C.c_double), C.byref(used))
+    if rc:
+        raise RuntimeError(f"rso_run_synth_cells rc={rc}")
+    return {"avg_rate": avg, "cum_bytes": cb, "cum_rbs": cr, "slice_state": sl, "threads": int(used.value)}
 
 
 def ref_lib(name):

@@ -971,6 +971,37 @@ int rso_run_synth_many(const rso_config* cfg, int n_cells, const uint8_t* cqi_ep
   return rc_all;
 }
 
+/* bench.py's parity sample (round 6): the same, but every cell reads ITS OWN epochs (cqi_epochs [n_cells][n_epochs][U][R]: the grids the
+ * GPU batch synthesised for those global cell ids, downloaded) and leaves its final state behind -- avg_rate [n_cells][U],
+ * cum_bytes / cum_rbs [n_cells][U], slice_state [n_cells][S] (any may be NULL) -- so that the caller can compare cell by cell. */
+int rso_run_synth_cells(const rso_config* cfg, int n_cells, const uint8_t* cqi_epochs, int n_epochs, int refresh, const unsigned* seeds,
+                        int phy_error_draws, int n_ttis, int threads, double* avg_rate, int64_t* cum_bytes, int64_t* cum_rbs,
+                        double* slice_state, int* threads_used) {
+  int rc_all = 0, used = 1;
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < n_cells; i++) {
+    if (i == 0) used = omp_get_num_threads();
+    rso_cell* c = rso_cell_create(cfg);
+    const size_t U = (size_t)c->U, S = (size_t)c->S, grid = U * c->R;
+    int rc = rso_run_synth(c, cqi_epochs + (size_t)i * n_epochs * grid, n_epochs, refresh, seeds[i], phy_error_draws, n_ttis, nullptr, nullptr);
+    if (rc) {
+#pragma omp critical
+      if (!rc_all) rc_all = rc;
+    }
+    std::vector<double> a(U), sl(S);
+    std::vector<int64_t> cb(U), cr(U);
+    rso_cell_get_state(c, a.data(), cb.data(), cr.data(), sl.data());
+    if (avg_rate) memcpy(avg_rate + i * U, a.data(), 8 * U);
+    if (cum_bytes) memcpy(cum_bytes + i * U, cb.data(), 8 * U);
+    if (cum_rbs) memcpy(cum_rbs + i * U, cr.data(), 8 * U);
+    if (slice_state) memcpy(slice_state + i * S, sl.data(), 8 * S);
+    rso_cell_destroy(c);
+  }
+  if (threads_used) *threads_used = used;
+  return rc_all;
+}
+
 
 /* =====================================================================================
  * Finite queues: bearers with MAC queues, arrivals handed in as bursts.

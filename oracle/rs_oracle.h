@@ -201,6 +201,10 @@ void rso_clock_ticks(int first_tti, int n, double* out);
 int rso_run_synth_many(const rso_config* cfg, int n_cells, const uint8_t* cqi_epochs, int n_epochs, int refresh,
                        const unsigned* seeds, int phy_error_draws, int n_ttis, int threads, int64_t* total_bytes,
                        int* threads_used);
+/* the same with per-cell epochs [n_cells][n_epochs][U][R] and every cell's final state returned (bench.py's parity sample) */
+int rso_run_synth_cells(const rso_config* cfg, int n_cells, const uint8_t* cqi_epochs, int n_epochs, int refresh, const unsigned* seeds,
+                        int phy_error_draws, int n_ttis, int threads, double* avg_rate, int64_t* cum_bytes, int64_t* cum_rbs,
+                        double* slice_state, int* threads_used);
 
 #ifdef __cplusplus
 }

@@ -471,11 +471,11 @@ def test_specialised_drop_in_kernel_matches_the_built_in_one(rs, oracle, sched):
 def test_bench_streamed_mode_line(rs):
     """`bench.py --cqi-refresh 1` runs the main batch in the streamed-CQI mode (epochs cycle), and the default line carries
     roofline.streamed beside the resident-design figures (VERDICT r03 next #2)."""
-    r = _bench(["--steps", "2", "--warmup", "1", "--cells", "16", "--ttis", "200", "--no-cpu-baseline", "--no-r64", "--cqi-refresh", "1"])
+    r = _bench(["--steps", "2", "--warmup", "1", "--cells", "16", "--ttis", "200", "--no-cpu-baseline", "--no-r64", "--no-cells1024", "--cqi-refresh", "1"])
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["config"]["cqi_refresh"] == 1 and d["value"] > 0 and "streamed" not in d["roofline"]
-    r = _bench(["--steps", "2", "--warmup", "1", "--cells", "16", "--ttis", "200", "--no-cpu-baseline", "--no-r64"])
+    r = _bench(["--steps", "2", "--warmup", "1", "--cells", "16", "--ttis", "200", "--no-cpu-baseline", "--no-r64", "--no-cells1024"])
     assert r.returncode == 0, r.stderr[-2000:]
     d2 = json.loads(r.stdout.strip().splitlines()[-1])
     st = d2["roofline"]["streamed"]
@@ -499,7 +499,7 @@ def test_two_gpus_bench_over_rccl_adds_up():
     not depend on the sharding) -- VERDICT r03 next #5, ref run_backlogged.sh:6-14."""
     if _n_gpus() < 2:
         pytest.skip("needs two GPUs")
-    common = ["--steps", "2", "--warmup", "1", "--ttis", "400", "--no-cpu-baseline", "--no-r64", "--no-streamed"]
+    common = ["--steps", "2", "--warmup", "1", "--ttis", "400", "--no-cpu-baseline", "--no-r64", "--no-streamed", "--no-cells1024"]
     r = _bench(["--gpus", "2", "--cells", "64"] + common)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])

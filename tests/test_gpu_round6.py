@@ -381,8 +381,8 @@ def test_a_rejection_that_meets_packed_grant_words(rs, oracle, monkeypatch):
     grids = synth_cqi(61, (2, (n1 + n2 + 39) // 40, 500, R), HIST)
     seeds = np.array([8, 9], np.uint32)
 
-    def make():
-        b = rs.BatchScheduler(rs.SliceConfig(ues), R, G, 2, sched=9, jit=True)
+    def make(threads=0):
+        b = rs.BatchScheduler(rs.SliceConfig(ues), R, G, 2, sched=9, jit=True, threads_per_cell=threads)
         b.seed(seeds)
         b.upload_cqi_epochs(grids)
         return b
@@ -391,8 +391,8 @@ def test_a_rejection_that_meets_packed_grant_words(rs, oracle, monkeypatch):
     blob = a.checkpoint()
     a.close()
     monkeypatch.setenv("RS_JIT_EXTRA", "-DRS_FAULT_INJECT_JIT")
-    b = make()
-    assert b.kernel_name == "rs_cell_kernel_jit"
+    b = make(threads=448)  # (a workgroup size no other test rejects this fault-injected build at: a rejection holds for the whole process)
+    assert b.kernel_name == "rs_cell_kernel_jit", b.jit_status()
     b.restore(blob)
     b.run(n2)
     code, msg = b.jit_status()
@@ -429,3 +429,35 @@ def test_checkpoint_of_a_differently_configured_batch_is_refused(rs):
     assert same.ttis_done == 50
     same.run(10)
     same.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the bench line proves its own run
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def _bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ("RS_JIT_EXTRA", "RS_JIT", "RS_JIT_SELFCHECK"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_line_carries_a_parity_sample_and_fails_when_it_is_wrong():
+    common = ["--steps", "1", "--warmup", "0", "--cells", "64", "--ttis", "400", "--no-r64", "--no-streamed", "--no-cells1024",
+              "--cpu-baseline-seconds", "0.5"]
+    r = _bench(common)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    ps = d["parity_sample"]
+    assert ps["cells"] == 32 and ps["ttis"] == 2000 and ps["bit_exact"] is True and ps["kernel"] == "rs_cell_kernel_jit", ps
+    assert d["occupancy"]["waves_per_cu"] == 64 / d["compute_units"] * 8 and d["cpu_baseline"]["value"] > 0
+    # a deliberately wrong kernel (and the self-check switched off, or it would have been dropped): the line says false, the run fails
+    r = _bench(common + ["--allow-variant"], {"RS_JIT_EXTRA": "-DRS_FAULT_INJECT_JIT", "RS_JIT_SELFCHECK": "0"})
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["parity_sample"]["bit_exact"] is False and "cum_bytes" in d["parity_sample"]["differs_in"]
+    assert "DIFFER on the parity sample" in r.stderr
+    # with the default self-check the same wrong build never serves: the batch falls back, and bench.py refuses a headline on the built-in kernels
+    r = _bench(common + ["--allow-variant"], {"RS_JIT_EXTRA": "-DRS_FAULT_INJECT_JIT"})
+    assert r.returncode != 0

@@ -9,6 +9,9 @@
  *   dropin_concurrency procs   K SHAPE [calls] [epoch|noepoch] [builtin]     K processes, one context each (fork + exec of this binary
  *                                                                            from a parent that never touches the GPU)
  *   SHAPE: 500x25 (20 slices x 25 UEs, 25 RBGs of 4 PRBs) | 100x64 (20 x 5 UEs, 64 RBGs of 8: the shipped exp-fix20slices/5ues shape)
+ *   further options: think=US (host time between two calls of a worker: the simulator's own work per TTI; default 0 = back to back),
+ *                    hwq=N (GPU_MAX_HW_QUEUES=N before the first HIP call: ROCclr maps a process's streams onto 4 hardware queues by default),
+ *                    sched=N
  *
  * Every worker: rs_create, rs_ctx_specialize (unless `builtin`), 60 warm-up calls (they include the specialised build's checked calls,
  * see rs_ctx_jit_status), then -- all workers released together -- `calls` timed calls (default 2 000).  The CQI block changes every 40
@@ -49,6 +52,7 @@ bool parse_shape(const char* s, Shape* out) {
 struct Worker {
   Shape sh;
   int calls = 2000, sched = RS_SCHED_MAXCELL, id = 0;
+  int think_us = 0; /* host time between two calls (the simulator's own work per TTI): 0 = back to back */
   bool epoch = true, specialise = true;
   std::vector<float> us;      /* per-call latency */
   double t_first = 0, t_last = 0; /* seconds on CLOCK_MONOTONIC (the same clock in every process of the machine) */
@@ -114,6 +118,11 @@ struct Worker {
     clk::time_point t0 = clk::now();
     t_first = sec(t0);
     for (int i = 0; i < calls; i++) {
+      if (think_us > 0) { /* the simulator computes: the latency clock starts when it comes back to the scheduler */
+        const clk::time_point until = t0 + std::chrono::microseconds(think_us);
+        while (clk::now() < until) __builtin_ia32_pause();
+        t0 = clk::now();
+      }
       if (!one_call()) return false;
       const clk::time_point t1 = clk::now();
       us[i] = std::chrono::duration<float, std::micro>(t1 - t0).count();
@@ -132,8 +141,11 @@ void report(const char* mode, int K, const char* shape, const Worker& proto, std
   double mean = 0;
   for (float x : all) mean += x;
   mean /= all.empty() ? 1 : all.size();
-  printf("%s K=%d %s %s %s calls=%d: per call p50 %.1f us, p90 %.1f, p99 %.1f, max %.1f, mean %.1f; aggregate %.0f TTIs/s over %.1f ms (checksum %lld; worker 0: %s)\n",
-         mode, K, shape, proto.specialise ? "specialised" : "built-in", proto.epoch ? "cqi_epoch" : "no-epoch", proto.calls, pct(0.5), pct(0.9), pct(0.99),
+  char extra[96] = "";
+  if (proto.think_us) snprintf(extra, sizeof extra, " think=%dus", proto.think_us);
+  if (const char* q = getenv("GPU_MAX_HW_QUEUES")) snprintf(extra + strlen(extra), sizeof extra - strlen(extra), " GPU_MAX_HW_QUEUES=%s", q);
+  printf("%s K=%d %s %s %s%s calls=%d: per call p50 %.1f us, p90 %.1f, p99 %.1f, max %.1f, mean %.1f; aggregate %.0f TTIs/s over %.1f ms (checksum %lld; worker 0: %s)\n",
+         mode, K, shape, proto.specialise ? "specialised" : "built-in", proto.epoch ? "cqi_epoch" : "no-epoch", extra, proto.calls, pct(0.5), pct(0.9), pct(0.99),
          all.empty() ? 0.f : all.back(), mean, all.size() / (last - first), (last - first) * 1e3, checksum, status.c_str());
   fflush(stdout);
 }
@@ -251,6 +263,9 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "noepoch")) proto.epoch = false;
     else if (!strcmp(argv[i], "builtin")) proto.specialise = false;
     else if (!strncmp(argv[i], "sched=", 6)) proto.sched = atoi(argv[i] + 6);
+    else if (!strncmp(argv[i], "think=", 6)) proto.think_us = atoi(argv[i] + 6);
+    /* ROCclr multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues: set before the first HIP call */
+    else if (!strncmp(argv[i], "hwq=", 4)) setenv("GPU_MAX_HW_QUEUES", argv[i] + 4, 1);
     else if (atoi(argv[i]) > 0) proto.calls = atoi(argv[i]);
   }
   if (mode == "worker") return run_worker(K /* = id */, argv[3], proto);
