@@ -532,6 +532,7 @@ def main():
                          "measured_copy_gbs": copy_gbs},
         }
         line["source_hash"] = src_hash
+        line["compiler"] = rs.jit_compiler_identity()  # the hiprtc / clang that built the timed kernel (part of every cache key)
         ent, inst_stale = recorded("inst_counts.json")
         if ent:
             rate = value / world  # per GPU

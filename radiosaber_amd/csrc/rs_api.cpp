@@ -11,6 +11,7 @@
  */
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -1779,6 +1780,10 @@ struct rs_ctx {
 };
 
 namespace {
+/* drop-in contexts alive in this process: the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the
+ * environment says otherwise), and one-TTI kernels of contexts that share a hardware queue run one after the other
+ * (profiles/r06_dropin_concurrency.md: nine threads, four queues, at most four kernels in flight) */
+std::atomic<int> g_live_ctx{0};
 struct CtxLayout {
   size_t grid, slice, avg, hol, prio, gate, draws, prb, in_total, tbs, uinfo, map, quota, target, upper, out_total;
 };
@@ -1878,11 +1883,23 @@ rs_ctx* rs_create(const rs_config* cfg) {
       snprintf(g_err, sizeof g_err, "warning: this host's libm gives %d EESM constant(s) that differ from the pinned glibc-2.35 set (%.300s): the context "
                "follows the host (RS_LINK_HOST_LIBM); RS_LINK_PINNED_GLIBC_2_35 reproduces the fixtures", diff, where);
   }
+  {
+    const int live = ++g_live_ctx;
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    const int hwq = e && atoi(e) > 0 ? atoi(e) : 4;
+    if (live > hwq && !cfg->stream) {
+      const size_t at = strlen(g_err);
+      snprintf(g_err + at, sizeof g_err - at, "%swarning: %d drop-in contexts in this process share %d hardware queues (GPU_MAX_HW_QUEUES, read by the HIP "
+               "runtime at its first call): their one-TTI kernels run %d at a time; export GPU_MAX_HW_QUEUES=%d (or more) before the process starts",
+               at ? "; " : "", live, hwq, hwq, live);
+    }
+  }
   return c;
 }
 
 void rs_destroy(rs_ctx* c) {
   if (!c) return;
+  if (c->h_out2.size()) --g_live_ctx; /* (counted by rs_create once it got that far) */
   if (c->timing && c->n_calls)
     fprintf(stderr, "rs_schedule_tti x %ld: prepare %.2f us, enqueue %.2f us, wait %.2f us, unpack %.2f us per call (%ld completed by the polled word, %ld fell back to the stream, %ld read the device-resident CQI image)\n", c->n_calls,
             c->t_prep / c->n_calls, c->t_enq / c->n_calls, c->t_wait / c->n_calls, c->t_unpack / c->n_calls, c->n_polled, c->n_fallback, c->n_img_reused);

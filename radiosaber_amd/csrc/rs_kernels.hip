@@ -154,6 +154,9 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   /* schedulers 1 and 7 with queues allocate RBG by RBG on wave 0 (the satisfied-flow break / the m_requiredRBs gate bind) */
   constexpr bool kQSerial = QUEUE && (SCHED == 1 || SCHED == 7);
   const int cell = blockIdx.x;
+#ifdef RS_STAMPS
+  const unsigned long long stamp_entry = __builtin_readcyclecounter(); /* diagnostic build: the load phase is slot 9, the store phase slot 10 */
+#endif
   /* only the drop-in entry point (DIRECT: one TTI on caller-provided state) uses these; batches never do, and their
    * kernels carry neither the code nor the registers */
   constexpr bool kDirect = DIRECT;
@@ -368,7 +371,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   }
   for (int u = tid; u < U && !kCumRegs; u += nt) {
     if (!kPrefetch) s_avg[u] = p.avg[(size_t)cell * U + u];
-    s_tx[u] = p.tx_bytes[(size_t)cell * U + u];
+    /* (a drop-in call carries no state but slice_rbs_offset_: the pending grants, the clock, the rand() ring and the cumulative
+     * counters belong to the caller's simulator -- the one-TTI kernel neither loads nor stores them; round 6: the store phase was
+     * 7 K of the call's 62 K cycles, its averages going BACK over the host link) */
+    s_tx[u] = kDirect ? 0 : p.tx_bytes[(size_t)cell * U + u];
     if (kDirect) { /* rs_schedule_tti: one row of per-user outputs, cleared here instead of by a memset */
       if (p.log_tbs) p.log_tbs[u] = 0;
       if (p.log_uinfo) p.log_uinfo[u] = 0;
@@ -445,18 +451,18 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       for (int u = tid; u < U; u += nt) s_uoff[u] = (int16_t)(m->rcp_off[p.user_slice[u]] | (p.psi[p.user_slice[u]] ? 1 : 0));
     }
   }
-  double t = scal->t;
-  double last_update = scal->last_update;
-  long long last_sent = scal->last_sent;
-  int reported = scal->reported;
-  int cqi_row = scal->cqi_row;
-  int served_prev = scal->served_prev;
-  long long n_done = scal->n_done;
+  double t = kDirect ? 0.0 : scal->t;
+  double last_update = kDirect ? 0.0 : scal->last_update;
+  long long last_sent = kDirect ? 0 : scal->last_sent;
+  int reported = kDirect ? 0 : scal->reported;
+  int cqi_row = kDirect ? 0 : scal->cqi_row;
+  int served_prev = kDirect ? 0 : scal->served_prev;
+  long long n_done = kDirect ? 0 : scal->n_done;
   WaveRng rng;
   rng.r = 0;
-  rng.f = scal->rng_f;
-  rng.b = scal->rng_b;
-  if (wave == quota_wave && lane < 31) rng.r = scal->rng_r[lane];
+  rng.f = kDirect ? 0 : scal->rng_f;
+  rng.b = kDirect ? 0 : scal->rng_b;
+  if (!kDirect && wave == quota_wave && lane < 31) rng.r = scal->rng_r[lane];
   const int nb_rbs = R * G;
   int local_err = 0;
   __syncthreads();
@@ -494,6 +500,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   unsigned long long* sort_sub = sort_sub_store;
   unsigned long long stamp_prev = __builtin_readcyclecounter();
   unsigned long long stamp1_prev = 0;
+  stamp_acc[9] = stamp_prev - stamp_entry;
 #endif
   /* position inside the CQI epoch and the epoch's index, kept as counters: a 64-bit modulo per TTI costs more than the
    * quota phase */
@@ -695,21 +702,21 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
       p.tx_bytes[(size_t)cell * U + u] = v ? (v | RS_TX_COUNTED) : 0;
     }
   }
-  for (int u = tid; u < U && !kCumRegs; u += nt) {
+  for (int u = tid; u < U && !kCumRegs && !kDirect; u += nt) {
     p.avg[(size_t)cell * U + u] = ((kSpecSched || kHoldSched) && s_avg[u] < 1) ? 1.0 : s_avg[u];
     p.tx_bytes[(size_t)cell * U + u] = s_tx[u];
   }
   if (tid < S) p.slice_state[(size_t)cell * S + tid] = s_sstate[tid];
-  if (wave == quota_wave && lane < 31) scal->rng_r[lane] = rng.r;
+  if (!kDirect && wave == quota_wave && lane < 31) scal->rng_r[lane] = rng.r;
   if (tid == 0) {
-    scal->t = t;
-    scal->last_update = last_update;
-    scal->last_sent = last_sent;
-    scal->reported = reported;
-    scal->cqi_row = cqi_row;
-    scal->served_prev = served_prev;
-    scal->n_done = n_done;
     if (!DIRECT) {
+      scal->t = t;
+      scal->last_update = last_update;
+      scal->last_sent = last_sent;
+      scal->reported = reported;
+      scal->cqi_row = cqi_row;
+      scal->served_prev = served_prev;
+      scal->n_done = n_done;
       scal->clk_end = __builtin_readcyclecounter();
       scal->real_end = __builtin_amdgcn_s_memrealtime();
     }
@@ -721,6 +728,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
 #ifdef RS_STAMPS
     if (p.stamps) {
+      stamp_acc[10] += __builtin_readcyclecounter() - stamp_prev; /* (everything behind the last TTI's closing barrier: the store phase) */
       for (int i = 0; i < 12; ++i) p.stamps[(size_t)cell * 20 + i] = stamp_acc[i];
 #ifndef RS_STAMPS_W1
       for (int i = 0; i < 8; ++i) p.stamps[(size_t)cell * 20 + 12 + i] = sort_sub[i];
@@ -732,7 +740,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   if (tid == RS_STAMPS_W1_TID && p.stamps)
     for (int i = 0; i < 8; ++i) p.stamps[(size_t)cell * 20 + 12 + i] = sort_sub[i];
 #endif
-  if (wave == quota_wave && lane == 0) {
+  if (!kDirect && wave == quota_wave && lane == 0) {
     scal->rng_f = rng.f;
     scal->rng_b = rng.b;
   }

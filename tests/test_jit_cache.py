@@ -7,18 +7,23 @@ import sys
 import time
 from pathlib import Path
 
+import pytest
+
 ROOT = Path(__file__).resolve().parents[1]
 
 SHAPE = (4, 12, 12, 2, 128, 9)  # small: ~1.5 s of hiprtc
 
 CHILD = r"""
-import json, sys, time
+import json, sys, time, os
+if os.environ.get("RS_TEST_IMPORT_TORCH_FIRST") == "1":
+    import torch  # noqa: F401 -- the torch wheel bundles its own ROCm user space: whichever libhiprtc a process loads first serves it
 sys.path.insert(0, %r)
 import radiosaber_amd as rs
 shape = %r
 t = time.time()
 n = rs.jit_cache_warm(*shape, lean=%r)
-print(json.dumps({"size": n, "seconds": time.time() - t, "stats": rs.jit_cache_stats(), "file": rs.jit_cache_file(*shape, lean=%r)}))
+print(json.dumps({"size": n, "seconds": time.time() - t, "stats": rs.jit_cache_stats(), "file": rs.jit_cache_file(*shape, lean=%r),
+                  "identity": rs.jit_compiler_identity()}))
 """
 
 
@@ -89,21 +94,31 @@ def test_switch_and_unwritable_directory(rs, tmp_path):
 
 # ---- round 6: the compiler's full identity in the key, the self-check mark, whose files are trusted ----
 
-def test_compiler_identity_names_the_compiler_down_to_its_commit(rs):
-    ident = rs.jit_compiler_identity()
+def test_compiler_identity_names_the_compiler_down_to_its_commit(rs, tmp_path):
+    r = _child(tmp_path)   # (a bare process: this pytest process may have torch -- and with it another ROCm -- loaded, see below)
+    ident = r["identity"]
     # hiprtc major.minor alone was the key until round 5; a patch-level update must change the text
-    assert "hiprtc " in ident and "hip-runtime " in ident and "clang " in ident, ident
+    assert "hiprtc " in ident and "hip-runtime " in ident and "clang " in ident and "comgr " in ident, ident
     rt = int(ident.split("hip-runtime ")[1].split()[0])
     assert rt > 10_000_000 and rt % 100_000 != 0, ident          # major * 10^7 + minor * 10^5 + PATCH
     clang = ident.split("clang ")[1]
     assert any(len(tok.strip("()")) == 40 and all(ch in "0123456789abcdef" for ch in tok.strip("()")) for tok in clang.split()), \
         f"no 40-digit LLVM commit in the clang version string: {clang!r}"
-    head = None
-    import tempfile
-    with tempfile.TemporaryDirectory() as d:
-        f = Path(_child(d)["file"])
-        head = f.read_bytes()[:4096]
-    assert ident.encode() in head, "the identity is not part of the stored key text"
+    assert ident.encode() in Path(r["file"]).read_bytes()[:4096], "the identity is not part of the stored key text"
+
+
+def test_a_process_that_loaded_torch_first_has_another_compiler_and_another_file(rs, tmp_path):
+    """Found in round 6: this image holds TWO ROCm user spaces -- /opt/rocm (what hipcc and the library link against) and the one inside
+    the torch wheel.  A process that imports torch first (bench.py does) gets torch's libhiprtc, i.e. ANOTHER clang, for its run-time
+    builds.  hiprtc's major.minor is the same for both (9.0), so round 5's key served one compiler's code objects to the other; the
+    identity tells them apart."""
+    bare = _child(tmp_path)
+    with_torch = _child(tmp_path, env_extra={"RS_TEST_IMPORT_TORCH_FIRST": "1"})
+    if bare["identity"] == with_torch["identity"]:
+        pytest.skip("torch runs on the system's ROCm here: one compiler")
+    assert bare["identity"].split(" clang ")[0].split()[:2] == with_torch["identity"].split(" clang ")[0].split()[:2], "hiprtc major.minor differ too"
+    assert bare["file"] != with_torch["file"] and with_torch["stats"]["misses"] == 1, (bare, with_torch)
+    assert len(list(tmp_path.glob("*.rsco"))) == 2
 
 
 def test_two_compiler_identities_give_two_files(rs, tmp_path):
