@@ -1,4 +1,5 @@
 /* dl-gpu-pf-packet-scheduler.cpp -- see dl-gpu-pf-packet-scheduler.h. */
+#include <cstdlib>
 #include "dl-gpu-pf-packet-scheduler.h"
 
 #include <stdexcept>
@@ -10,8 +11,21 @@
 #include "../../../phy/lte-phy.h"
 #include "../mac-entity.h"
 
+namespace {
+/* One simulator process = one GPU context = one HIP stream: ask the HIP runtime for ONE hardware queue instead of its default of four
+ * (GPU_MAX_HW_QUEUES, read at the runtime's first call) -- a dozen such processes then share an MI355X without oversubscribing its
+ * hardware queue slots, with the default six of them already stall each other for milliseconds (profiles/r06_dropin_concurrency.md) --
+ * and pick the GPU: RS_HIP_DEVICE when set (the experiment scripts start one process per run: export RS_HIP_DEVICE=$((i % 8)) in their loops), else the
+ * constructor's argument.  The environment wins over both. */
+int GpuProcessPolicy(int hip_device) {
+  setenv("GPU_MAX_HW_QUEUES", "1", 0 /* keep what the user exported */);
+  const char* d = getenv("RS_HIP_DEVICE");
+  return d ? atoi(d) : hip_device;
+}
+}  // namespace
+
 DL_GPU_PF_PacketScheduler::DL_GPU_PF_PacketScheduler(std::string config_fname, int max_flows, int hip_device)
-    : DL_PF_PacketScheduler(config_fname), ctx_(NULL), hip_device_(hip_device), max_flows_(max_flows), nb_rbs_(0), cqi_epoch_(0) {}
+    : DL_PF_PacketScheduler(config_fname), ctx_(NULL), hip_device_(GpuProcessPolicy(hip_device)), max_flows_(max_flows), nb_rbs_(0), cqi_epoch_(0) {}
 
 DL_GPU_PF_PacketScheduler::~DL_GPU_PF_PacketScheduler() { rs_destroy(ctx_); }
 

@@ -28,9 +28,22 @@ int SchedOfInterSliceAlgo(int algo) {
 }
 }  // namespace
 
+namespace {
+/* One simulator process = one GPU context = one HIP stream: ask the HIP runtime for ONE hardware queue instead of its default of four
+ * (GPU_MAX_HW_QUEUES, read at the runtime's first call) -- a dozen such processes then share an MI355X without oversubscribing its
+ * hardware queue slots, with the default six of them already stall each other for milliseconds (profiles/r06_dropin_concurrency.md) --
+ * and pick the GPU: RS_HIP_DEVICE when set (the experiment scripts start one process per run: export RS_HIP_DEVICE=$((i % 8)) in their loops), else the
+ * constructor's argument.  The environment wins over both. */
+int GpuProcessPolicy(int hip_device) {
+  setenv("GPU_MAX_HW_QUEUES", "1", 0 /* keep what the user exported */);
+  const char* d = getenv("RS_HIP_DEVICE");
+  return d ? atoi(d) : hip_device;
+}
+}  // namespace
+
 DownlinkGpuScheduler::DownlinkGpuScheduler(std::string config_fname, int interslice_algo, int hip_device)
     : DownlinkTransportScheduler(config_fname, interslice_algo),
-      ctx_(NULL), hip_device_(hip_device), sched_(SchedOfInterSliceAlgo(interslice_algo)), num_slices_(0),
+      ctx_(NULL), hip_device_(GpuProcessPolicy(hip_device)), sched_(SchedOfInterSliceAlgo(interslice_algo)), num_slices_(0),
       nb_rbs_(0), rbg_size_(0), any_alpha_(false), cqi_epoch_(0) {
   /* the same keys the parent's constructor reads (downlink-transport-scheduler.cpp:55-88) */
   std::ifstream ifs(config_fname);
