@@ -104,6 +104,23 @@ def test_eight_threads_each_with_its_own_context_mixed_schedulers(rs, oracle):
     assert done == [n_calls] * len(plan)
 
 
+def test_rs_create_says_when_contexts_outnumber_the_hardware_queues(rs, monkeypatch):
+    """profiles/r06_dropin_concurrency.md: the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default);
+    the fifth context of a process still works, and rs_last_error() after its creation names the variable to export."""
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    sc = rs.SliceConfig([2, 2])
+    ctxs = [rs.TtiScheduler(sc, 12, 2) for _ in range(5)]
+    assert all("GPU_MAX_HW_QUEUES" not in c.create_warning for c in ctxs[:4]), [c.create_warning for c in ctxs]
+    assert "GPU_MAX_HW_QUEUES=5" in ctxs[4].create_warning and "5 drop-in contexts" in ctxs[4].create_warning, ctxs[4].create_warning
+    cqi = np.full((4, 12), 7, np.uint8)
+    for c in ctxs:
+        assert c.schedule_tti(cqi, np.full(4, 1e5), 1, 2).rbg_to_user.min() >= 0
+        c.close()
+    again = rs.TtiScheduler(sc, 12, 2)   # the closed ones no longer count
+    assert "GPU_MAX_HW_QUEUES" not in again.create_warning
+    again.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # rs_tti_in.cqi_epoch: the device-resident CQI image
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -4,7 +4,7 @@
 # (rocm-smi) beside each.  Output: gpurun_out/gap/*.log; HERE: python tools/summarize_gap.py -> profiles/r04_rocprof_vs_events.md
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/gap; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-r64 --no-streamed --steps 12 --warmup 2"
+ARGS="--no-cpu-baseline --no-r64 --no-streamed --no-cells1024 --steps 12 --warmup 2"
 sample() { # tag: shader / memory clock and power twice a second while the run lasts
   ( while true; do echo "$(date +%s.%N) $(rocm-smi --showclocks --showpower 2>/dev/null | grep -E 'sclk|mclk|Power' | tr -s ' ' | tr '\n' ';')"; sleep 0.5; done ) > $O/clocks_$1.log 2>&1 &
   SAMPLER=$!

@@ -9,7 +9,7 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_kt $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt -- python3 $R/bench.py --no-cpu-baseline --no-r64 --no-streamed "$@" > $R/gpurun_out/prof_kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --no-cpu-baseline --no-r64 --no-streamed --steps 6 --warmup 1 "$@" > $R/gpurun_out/prof_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --no-cpu-baseline --no-r64 --no-streamed --steps 6 --warmup 1 "$@" > $R/gpurun_out/prof_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt -- python3 $R/bench.py --no-cpu-baseline --no-r64 --no-streamed --no-cells1024 "$@" > $R/gpurun_out/prof_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --no-cpu-baseline --no-r64 --no-streamed --no-cells1024 --steps 6 --warmup 1 "$@" > $R/gpurun_out/prof_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --no-cpu-baseline --no-r64 --no-streamed --no-cells1024 --steps 6 --warmup 1 "$@" > $R/gpurun_out/prof_write.log 2>&1
 grep '^{' $R/gpurun_out/prof_kt.log | tail -1

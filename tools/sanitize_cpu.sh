@@ -6,10 +6,10 @@
 #                                                     rs_trace_*, rs_internet_flow_arrivals, rs_link_tables, config validation, the
 #                                                     checked create functions, the hiprtc option handling
 #   3. tests/csrc/{sort_emul_check,umap_emul_check}.cpp   the host+device sort / unordered_map emulation against the real containers
-# then `pytest -m "not gpu"` with both libraries selected and libasan preloaded into python.  Output: profiles/r05_sanitizers.log
+# then `pytest -m "not gpu"` with both libraries selected and libasan preloaded into python.  Output: profiles/r06_sanitizers.log
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd); cd "$R"
-LOG=${1:-$R/profiles/r05_sanitizers.log}
+LOG=${1:-$R/profiles/r06_sanitizers.log}
 SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer"
 ASAN_LIB=$(g++ -print-file-name=libasan.so)
 STDCXX_LIB=$(g++ -print-file-name=libstdc++.so)  # preloaded too: ASan resolves __cxa_throw when it starts, and python itself does not link libstdc++
@@ -17,7 +17,7 @@ STDCXX_LIB=$(g++ -print-file-name=libstdc++.so)  # preloaded too: ASan resolves 
 echo "# tools/sanitize_cpu.sh  $(date -u +%Y-%m-%dT%H:%MZ)  g++ $(g++ -dumpversion), flags: $SAN"
 echo "## 1. oracle"; make -C oracle asan 2>&1 | tail -2
 echo "## 2. host side of the library"
-python3 -c "from radiosaber_amd import build; build.write_tables_inc(); build.write_jit_sources()"
+python3 -c "from radiosaber_amd import build; build.write_tables_inc(); build.write_link_pinned_inc(); build.write_jit_sources()"
 g++ -std=c++17 $SAN -ffp-contract=off -fno-fast-math -fPIC -shared -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude \
     radiosaber_amd/csrc/rs_api.cpp radiosaber_amd/csrc/rs_jit.cpp tests/csrc/host_launch_stubs.cpp \
     -L/opt/rocm/lib -lamdhip64 -lhiprtc -Wl,-rpath,/opt/rocm/lib -o radiosaber_amd/libradiosaber_hip_hostasan.so && echo "built radiosaber_amd/libradiosaber_hip_hostasan.so"
