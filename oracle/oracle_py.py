@@ -264,6 +264,13 @@ class Cell:
         assert a.shape == (self.U,)
         lib().rso_cell_set_second_bearer_avg(self.h, _p(a, C.c_double))
 
+    def set_slice_offset(self, offset):
+        """slice_rbs_offset_ [S] from outside (a test that follows a context whose calls the oracle did not all take part in)."""
+        a = np.ascontiguousarray(offset, np.float64)
+        assert a.shape == (self.S,)
+        lib().rso_cell_set_slice_offset.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        lib().rso_cell_set_slice_offset(self.h, _p(a, C.c_double))
+
     def set_avg_rate(self, avg):
         a = np.ascontiguousarray(avg, np.float64)
         lib().rso_cell_set_avg_rate(self.h, _p(a, C.c_double))

@@ -354,6 +354,8 @@ void rso_cell_set_user_cqi(rso_cell* c, int user, const uint8_t* row) {
   memcpy(&c->cqi[(size_t)user * c->R], row, c->R);
 }
 void rso_cell_set_last_update(rso_cell* c, double t) { c->last_update.assign(c->U, t); }
+/* slice_rbs_offset_ (downlink-transport-scheduler.h:38) from outside: lets a test follow a context whose calls the oracle did not all take part in */
+void rso_cell_set_slice_offset(rso_cell* c, const double* offset) { c->offset.assign(offset, offset + c->S); }
 void rso_cell_set_synthetic_exp(rso_cell* c, int on) { c->synthetic = on ? 1 : 0; }
 /* queue state the customised (alpha = 1) slice metrics read: downlink-transport-scheduler.cpp:694-711 */
 void rso_cell_set_queue_state(rso_cell* c, const double* hol, const uint8_t* prio_has_data) {

@@ -136,6 +136,7 @@ int rso_cell_step_rng(rso_cell* c, double now, rso_rng* g, rso_tti_out* out);
 void rso_cell_get_state(const rso_cell* c, double* avg_rate, int64_t* cum_bytes, int64_t* cum_rbs,
                         double* slice_offset_or_ewma);
 void rso_cell_set_avg_rate(rso_cell* c, const double* avg_rate);
+void rso_cell_set_slice_offset(rso_cell* c, const double* offset); /* slice_rbs_offset_ [S] */
 /* users holding two bearers in this TTI (MAX_BEARERS = 2, packet-scheduler.h:31): avg_rate is the lower-priority
  * bearer's average, avg2[u] the other one's (< 0: one bearer); NULL clears.  Summed as the reference does, (1 + a) + a2. */
 void rso_cell_set_second_bearer_avg(rso_cell* c, const double* avg2);

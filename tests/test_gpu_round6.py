@@ -484,3 +484,15 @@ def test_bench_line_carries_a_parity_sample_and_fails_when_it_is_wrong():
     # with the default self-check the same wrong build never serves: the batch falls back, and bench.py refuses a headline on the built-in kernels
     r = _bench(common + ["--allow-variant"], {"RS_JIT_EXTRA": "-DRS_FAULT_INJECT_JIT"})
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5, 6])
+def test_drop_in_fuzz_seeds(rs, oracle, seed, monkeypatch):
+    """tools/fuzz_dropin.py (random shapes and schedulers; the CQI block and the user list change independently; per-PRB reports on some
+    seeds): a specialised, self-checked context with cqi_epoch == a built-in context without == the oracle where every user is listed."""
+    import importlib.util
+    monkeypatch.setenv("RS_JIT_SELFCHECK", "2")
+    spec = importlib.util.spec_from_file_location("fuzz_dropin", ROOT / "tools" / "fuzz_dropin.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.one_seed(seed, 24)
