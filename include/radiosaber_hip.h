@@ -222,7 +222,12 @@ typedef struct rs_tti_out {
 /* replaces DownlinkTransportScheduler::RBsAllocation (ref: downlink-transport-scheduler.cpp:453-675),
  * DownlinkPacketScheduler::RBsAllocation (ref: downlink-packet-scheduler.cpp:179-331) and
  * DownlinkNVSScheduler::RBsAllocation (ref: downlink-nvs-scheduler.cpp:275-358; pass the users of the
- * slice SelectSliceToServe chose).  The context carries slice_rbs_offset_ between calls. */
+ * slice SelectSliceToServe chose).  The context carries slice_rbs_offset_ between calls -- and nothing else of the simulator's state:
+ * PF averages, pending grants, cumulative counters, the clock and the rand() stream stay the caller's (DoSchedule / DoStopSchedule keep
+ * them in the reference too); with rs_tti_in.cqi_epoch it also keeps an image of the last CQI grid on the device.
+ * One context per host thread.  Many contexts in one process: export GPU_MAX_HW_QUEUES >= their number (up to 16) before the process
+ * starts -- the HIP runtime maps a process's streams onto 4 hardware queues by default, and one-TTI kernels of contexts that share a
+ * queue run one after the other; rs_create says so through rs_last_error() when it happens (profiles/r06_dropin_concurrency.md). */
 int rs_schedule_tti(rs_ctx* ctx, const rs_tti_in* in, rs_tti_out* out);
 /* Optional, once after rs_create: compile this context's own build of the one-TTI kernel (hiprtc, ~2 s per shape and process,
  * cached) -- slices, RBGs, PRBs per RBG, scheduler and the user capacity as compile-time constants, the users of a call still a

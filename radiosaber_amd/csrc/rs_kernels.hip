@@ -155,7 +155,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   constexpr bool kQSerial = QUEUE && (SCHED == 1 || SCHED == 7);
   const int cell = blockIdx.x;
 #ifdef RS_STAMPS
-  const unsigned long long stamp_entry = __builtin_readcyclecounter(); /* diagnostic build: the load phase is slot 9, the store phase slot 10 */
+  const unsigned long long stamp_entry = __builtin_readcyclecounter(); /* diagnostic build, one-TTI kernels: the load phase is slot 9, the store phase slot 10 */
 #endif
   /* only the drop-in entry point (DIRECT: one TTI on caller-provided state) uses these; batches never do, and their
    * kernels carry neither the code nor the registers */
@@ -500,7 +500,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
   unsigned long long* sort_sub = sort_sub_store;
   unsigned long long stamp_prev = __builtin_readcyclecounter();
   unsigned long long stamp1_prev = 0;
-  stamp_acc[9] = stamp_prev - stamp_entry;
+  if (DIRECT) stamp_acc[9] = stamp_prev - stamp_entry; /* (one-TTI kernels: the load phase; batches keep the slot for the greedy scan's diagnostics, rs_interslice.h) */
 #endif
   /* position inside the CQI epoch and the epoch's index, kept as counters: a 64-bit modulo per TTI costs more than the
    * quota phase */
@@ -728,7 +728,7 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
     }
 #ifdef RS_STAMPS
     if (p.stamps) {
-      stamp_acc[10] += __builtin_readcyclecounter() - stamp_prev; /* (everything behind the last TTI's closing barrier: the store phase) */
+      if (DIRECT) stamp_acc[10] += __builtin_readcyclecounter() - stamp_prev; /* (one-TTI kernels: everything behind the TTI's closing barrier = the store phase) */
       for (int i = 0; i < 12; ++i) p.stamps[(size_t)cell * 20 + i] = stamp_acc[i];
 #ifndef RS_STAMPS_W1
       for (int i = 0; i < 8; ++i) p.stamps[(size_t)cell * 20 + 12 + i] = sort_sub[i];
