@@ -328,6 +328,11 @@ def main():
         # no launcher around us: start the ranks ourselves, BEFORE anything in this process touches HIP (or imports torch)
         raise SystemExit(_launch_own_ranks(args.gpus))
 
+    # The run-time kernels of this process are built by the toolchain the library itself was built with (radiosaber_amd/toolchain.py:
+    # the system's comgr is mapped before torch brings its wheel's copy; RS_SYSTEM_COMGR=0 leaves it to the import order).  The line's
+    # `compiler` field says which compiler it was.
+    from radiosaber_amd import toolchain
+    comgr_in_use = toolchain.prefer_system_compiler()
     import torch
     import torch.distributed as dist
 
@@ -533,6 +538,7 @@ def main():
         }
         line["source_hash"] = src_hash
         line["compiler"] = rs.jit_compiler_identity()  # the hiprtc / clang that built the timed kernel (part of every cache key)
+        line["comgr"] = comgr_in_use
         ent, inst_stale = recorded("inst_counts.json")
         if ent:
             rate = value / world  # per GPU

@@ -15,6 +15,10 @@ SHAPE = (4, 12, 12, 2, 128, 9)  # small: ~1.5 s of hiprtc
 
 CHILD = r"""
 import json, sys, time, os
+sys.path.insert(0, %r)
+if os.environ.get("RS_TEST_PREFER_SYSTEM_COMPILER") == "1":
+    from radiosaber_amd import toolchain
+    toolchain.prefer_system_compiler()
 if os.environ.get("RS_TEST_IMPORT_TORCH_FIRST") == "1":
     import torch  # noqa: F401 -- the torch wheel bundles its own ROCm user space: whichever libhiprtc a process loads first serves it
 sys.path.insert(0, %r)
@@ -32,7 +36,7 @@ def _child(cache_dir, lean=False, env_extra=None):
     env = dict(os.environ, RS_JIT_CACHE_DIR=str(cache_dir), AMD_COMGR_CACHE="0")
     env.pop("RS_JIT_CACHE", None)
     env.update(env_extra or {})
-    r = subprocess.run([sys.executable, "-c", CHILD % (str(ROOT), SHAPE, lean, lean)], capture_output=True, text=True, env=env, timeout=600)
+    r = subprocess.run([sys.executable, "-c", CHILD % (str(ROOT), str(ROOT), SHAPE, lean, lean)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr
     return json.loads(r.stdout.strip().split("\n")[-1])
 
@@ -119,6 +123,10 @@ def test_a_process_that_loaded_torch_first_has_another_compiler_and_another_file
     assert bare["identity"].split(" clang ")[0].split()[:2] == with_torch["identity"].split(" clang ")[0].split()[:2], "hiprtc major.minor differ too"
     assert bare["file"] != with_torch["file"] and with_torch["stats"]["misses"] == 1, (bare, with_torch)
     assert len(list(tmp_path.glob("*.rsco"))) == 2
+    # radiosaber_amd.toolchain.prefer_system_compiler() before `import torch` (what bench.py does): the system's comgr is mapped first and
+    # the process compiles with the toolchain the library was built with -- the bare process's compiler, the bare process's cache file
+    fixed = _child(tmp_path, env_extra={"RS_TEST_IMPORT_TORCH_FIRST": "1", "RS_TEST_PREFER_SYSTEM_COMPILER": "1"})
+    assert fixed["identity"].split(" clang ")[1] == bare["identity"].split(" clang ")[1], (fixed["identity"], bare["identity"])
 
 
 def test_two_compiler_identities_give_two_files(rs, tmp_path):
