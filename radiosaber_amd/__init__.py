@@ -4,7 +4,13 @@ Thin ctypes mirror of the C ABI in include/radiosaber_hip.h (libradiosaber_hip.s
 HIP for gfx950).  There is no CPU fallback: creating a scheduler without a HIP device, or without the
 built library, raises.
 """
-from .api import (  # noqa: F401
+from . import toolchain as _toolchain
+
+# the run-time kernels are built by the toolchain the library was built with, whatever is imported after this package (toolchain.py;
+# a process that imported torch BEFORE this package keeps the wheel's compiler: call toolchain.prefer_system_compiler() first, as bench.py does)
+_toolchain.prefer_system_compiler()
+
+from .api import (  # noqa: F401,E402
     RS_SCHED_MAXCELL, RS_SCHED_NVS, RS_SCHED_PF, RS_SCHED_NVS_NONGREEDY, RS_SCHED_SEQUENTIAL, RS_SCHED_UPPERBOUND, RS_SCHED_VOGEL, RS_SCHED_SUBOPT,
     BEARER_BACKLOG, BEARER_NONE, BEARER_QUEUE, FULL_PACKET, TRACE_CQI_HISTOGRAM, frames_to_bursts, internet_flow_arrivals,
     BatchScheduler, RadioSaberError, SliceConfig, TtiResult, TtiScheduler, device_count, device_source_hash, dl_prbs_for_bandwidth, get_rbg_size, hbm_copy_probe, jit_selfcheck, lds_bytes_per_cell,
