@@ -292,14 +292,14 @@ __device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* 
   if (mine) v[x] = e;
 }
 
-template <int EPT>
+template <int EPT, int NT = 0> /* NT: the workgroup's size where it is a compile-time constant (shape-specialised builds), 0: blockDim.x */
 __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t* cuts, Misc* m,
                                      unsigned long long* sub, int seg_len = 0) {
   /* sub-ranges per wave at which the last levels go to single waves (same-box A/B, 512 cells: one position per lane -- 500 records --
    * 33.38 M TTIs/s with 2 against 33.18 with 4 and 32.70 with 1; three positions per lane -- 1 280 records -- 13.24 with 2 against 13.41
    * with 4; round 4, 1 280 records: 2 / 4 / 8 within 0.3 % of each other) */
   constexpr int kFinishMax = EPT == 1 ? 2 : 4;
-  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+  const int tid = threadIdx.x, nt = NT > 0 ? NT : (int)blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
 #ifdef RS_STAMPS
   unsigned long long sub_prev = __builtin_readcyclecounter();
 #endif
@@ -327,110 +327,162 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
   if (tid == 0) m->pad[0] = 0; /* entries in the list of sub-ranges handed to single waves */
   int depth = 2 * rs_sort::floor_log2(n_first > 1 ? n_first : 1);
   __syncthreads();
+  int n_alive = 0;
   for (int level = 0; level < 47; ++level, --depth) {
-    const int n_alive = m->n_level[level]; /* complete: the previous level ended with a barrier */
-    if (n_alive == 0) break;
-    /* (a first level that fills every lane -- UpperBound's row of short vectors at one position per lane -- stays a workgroup level) */
-    if (depth != 0 && n_alive <= kFinishMax * nwaves && (level > 0 || EPT > 1 || n_alive == 1)) {
-      /* few sub-ranges left, none longer than 64: their first positions publish them, every wave takes its share and
-       * finishes them alone (finish_subranges_on_wave) */
+#ifndef RS_SORT_BRANCHY
+    /* F, stage 1 (see below): the median-of-3 samples of every position's sub-range, asked for together with the level's count of
+     * live sub-ranges -- one LDS round trip at the top of a level instead of two (the reads are harmless whatever the count says) */
+    uint32_t s0[EPT], sa[EPT], sb[EPT], sc[EPT];
+    int ibx[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const bool active = L[i] != 0;
+      const int f = active ? F[i] : 0, l = active ? L[i] : 2;
+      ibx[i] = f + (int)((unsigned)(l - f) >> 1); /* l > f: the halving needs no sign fix */
+      s0[i] = v[f];
+      sa[i] = v[f + 1];
+      sb[i] = v[ibx[i]];
+      sc[i] = v[l - 1];
+    }
+#endif
+    n_alive = m->n_level[level]; /* complete: the previous level ended with a barrier */
+#ifndef RS_SORT_BRANCHY
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) asm volatile("" : "+v"(s0[i]), "+v"(sa[i]), "+v"(sb[i]), "+v"(sc[i])); /* keep the reads in this batch */
+#endif
+    /* one test per level; what happens at the two early ends is written behind the loop (round 6: with the ends inside the loop
+     * the compiler carried a copy of every position's bounds to each of them, ~20 instructions per level)
+     * (a first level that fills every lane -- UpperBound's row of short vectors at one position per lane -- stays a workgroup level) */
+    const bool hand_off = depth != 0 && n_alive <= kFinishMax * nwaves && (level > 0 || EPT > 1 || n_alive == 1);
+    if (n_alive == 0 || hand_off || depth == 0) break;
+#ifndef RS_SORT_BRANCHY
+    /*
+     * Round 6: the three phases in STAGES over the EPT positions of a lane, without a branch.  The form kept under
+     * -DRS_SORT_BRANCHY wrapped every position's work in `if (active)`: the compiler turned that into one block per position
+     * with its own s_cbranch_execz and its own s_waitcnt, so the EPT independent chains of a lane ran one after the other --
+     * three LDS round trips per phase at three positions per lane, every instruction waiting for the one before it (8.5 cycles
+     * each against 5.3 for independent ones, profiles/r03_sort_experiments.md).  Here every stage first issues the LDS reads of
+     * ALL positions (a retired position reads the harmless sub-range [0, 2)), then does the arithmetic of all of them with
+     * selects; only stores and the atomic stay under a lane mask.  profiles/r06_sort_staged.md.
+     */
+    /* F: pivot of my sub-range (median of 3, std::__move_median_to_first), stop ballots */
+    unsigned long long mAi[EPT], mBi[EPT];
+    bool isA[EPT], isB[EPT], moved[EPT];
+    {
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
         const int x = i * nt + tid;
-        const bool leader = L[i] != 0 && x == F[i];
-        const unsigned long long mL = __ballot(leader);
-        if (mL != 0ull) {
-          int base = 0;
-          if (lane == 0) base = atomicAdd(&m->pad[0], __popcll(mL));
-          base = __builtin_amdgcn_readfirstlane(base);
-          if (leader) cuts[base + __popcll(mL & lt_lane)] = F[i] | (L[i] << 16);
+        const int c = i * nwaves + wave;
+        const bool active = L[i] != 0;
+        /* std::__move_median_to_first with rs_sort::before() = "key greater": five selects on (element, position) each */
+        const bool ab = (sa[i] >> 16) > (sb[i] >> 16), bc = (sb[i] >> 16) > (sc[i] >> 16), ac = (sa[i] >> 16) > (sc[i] >> 16);
+        const int pa = F[i] + 1, pb = ibx[i], pc_ = L[i] - 1;
+        const uint32_t t1 = ac ? sc[i] : sa[i], t2 = bc ? sc[i] : sb[i];
+        const int q1 = ac ? pc_ : pa, q2 = bc ? pc_ : pb;
+        const uint32_t r1 = bc ? sb[i] : t1, r2 = ac ? sa[i] : t2;
+        const int u1 = bc ? pb : q1, u2 = ac ? pa : q2;
+        const uint32_t sp = ab ? r1 : r2;
+        const int pick = ab ? u1 : u2;
+        const bool at_f = active & (x == F[i]), at_pick = active & (x == pick); /* pick > f: never both */
+        e[i] = at_f ? sp : at_pick ? s0[i] : e[i];
+        moved[i] = at_f | at_pick;
+        if (at_f) cuts[F[i] >> 4] = 0x7fffffff;
+        /* keys are 0..15: compared as floats, with NaN for a position outside (f, l), each stop ballot is ONE v_cmp (both
+         * comparisons are false on NaN; an integer form needs the range test ANDed in and the mask rebuilt under EXEC) */
+        const bool in = active & (x > F[i]);
+        const float kf = in ? (float)(e[i] >> 16) : __builtin_nanf("");
+        const float pkf = (float)(sp >> 16);
+        isA[i] = kf <= pkf;
+        isB[i] = kf >= pkf;
+        mAi[i] = __builtin_amdgcn_ballot_w64(isA[i]);
+        mBi[i] = __builtin_amdgcn_ballot_w64(isB[i]);
+        if (lane == 0 && c < n_chunks) {
+          m->maskA[c] = mAi[i];
+          m->maskB[c] = mBi[i];
         }
       }
-      __syncthreads();
-      /* (same-box A/B, 512 cells: the zigzag below 33.17 against 32.99 M TTIs/s at 500 records, one position per lane; at 1 280
-       * records -- up to 32 entries to rank -- 13.30 against 13.49: list order there) */
-      constexpr bool kZigzag = EPT == 1;
-      if constexpr (!kZigzag) {
-      /* my share: entries wave, wave + nwaves, ... (lane t fetches the t-th of them), packed side by side while they fit */
-      int n_mine = 0; /* entries j = wave + t * nwaves below n_alive (no division: nwaves is a run-time value) */
-#pragma unroll
-      for (int t = 0; t < kFinishMax; ++t) n_mine += wave + t * nwaves < n_alive ? 1 : 0;
-      const int my_ent = lane < n_mine ? cuts[wave + lane * nwaves] : 0;
-      for (int t = 0; t < n_mine;) {
-        int fb = 0, lb = 0, l0 = 0, used = 0;
-        do {
-          const int ent = __builtin_amdgcn_readlane(my_ent, t);
-          const int f = ent & 0xffff, l = ent >> 16;
-          if (used + (l - f) > 64) break;
-          if (lane >= used && lane < used + (l - f)) { fb = f; lb = used; l0 = l; }
-          used += l - f;
-          ++t;
-        } while (t < n_mine);
-        finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth, m);
-      }
-      } else {
-      /* Every wave reads the whole list (at most kFinishMax * nwaves <= 32 entries, lane j = entry j), ranks the entries
-       * by length and takes them in a zigzag over the waves (rank 0..nwaves-1 -> wave 0..nwaves-1, the next nwaves backwards, ...):
-       * a wave with two entries gets a long and a short one, which usually fit its 64 lanes together -- entries that do not fit
-       * are finished one after the other, and with the entries dealt out in list order one wave of the eight did that in about
-       * half of the sorts (two of ~10 sub-ranges of 20-60 elements each on one wave).  Any assignment is correct: the
-       * sub-ranges are disjoint. */
-      const int ent_l = lane < n_alive ? cuts[lane] : 0;
-      const int len_l = lane < n_alive ? (ent_l >> 16) - (ent_l & 0xffff) : -1;
-      int rank = 0;
-      for (int j = 0; j < n_alive; ++j) {
-        const int lj = __builtin_amdgcn_readlane(len_l, j);
-        rank += (lj > len_l || (lj == len_l && j < lane)) ? 1 : 0;
-      }
-      int blk = 0, posn = rank; /* rank = blk * nwaves + posn without a division (nwaves is a run-time value) */
-#pragma unroll
-      for (int q = 1; q < kFinishMax; ++q)
-        if (rank >= q * nwaves) { blk = q; posn = rank - q * nwaves; }
-      const int to_wave = (blk & 1) ? nwaves - 1 - posn : posn;
-      unsigned long long mine = __ballot(lane < n_alive && to_wave == wave);
-      while (mine != 0ull) {
-        int fb = 0, lb = 0, l0 = 0, used = 0;
-        unsigned long long rest = mine;
-        while (rest != 0ull) { /* pack what fits side by side (in list order; whatever does not fit waits for the next call) */
-          const int j = __ffsll((long long)rest) - 1;
-          rest &= rest - 1ull;
-          const int ent = __builtin_amdgcn_readlane(ent_l, j);
-          const int f = ent & 0xffff, l = ent >> 16;
-          if (used + (l - f) > 64) continue;
-          if (lane >= used && lane < used + (l - f)) { fb = f; lb = used; l0 = l; }
-          used += l - f;
-          mine &= ~(1ull << j);
-        }
-        finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth, m);
-      }
-      }
-      __syncthreads();
-      break;
     }
-    if (depth == 0) {
-      /* std::__partial_sort fallback for every sub-range still longer than 16: their first positions publish them (the list of
-       * the hand-off above; `v` is current, every level writes what it moves), the waves take them in turn (heap_sort_on_wave) */
+    RS_SUBSTAMP(0);
+    __syncthreads();
+    RS_SUBSTAMP(1);
+    /* R: stop counts -> swap decision; swapped elements to the exchange buffer, cut candidates to the slot */
+    int pre; /* lane c: stops in chunks < c, A-stops in the low half, B-stops in the high half */
+    {
+      int cnt = 0;
+      if (lane < n_chunks) cnt = __popcll(m->maskA[lane]) | (__popcll(m->maskB[lane]) << 16);
+      pre = n_chunks <= 8 ? wave_scan_excl8(cnt) : wave_scan_incl(cnt) - cnt; /* (512 records: the counts sit in lanes 0..7) */
+    }
+    int slot[EPT]; /* where my element went / where its replacement arrives; -1: not swapped */
+    {
+      int plo[EPT], phi[EPT], lo_[EPT], hm_[EPT];
+      unsigned long long mlo[EPT], mhi[EPT];
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
         const int x = i * nt + tid;
-        const bool leader = L[i] != 0 && x == F[i];
-        const unsigned long long mL = __ballot(leader);
-        if (mL != 0ull) {
-          int base = 0;
-          if (lane == 0) base = atomicAdd(&m->pad[0], __popcll(mL));
-          base = __builtin_amdgcn_readfirstlane(base);
-          if (leader) cuts[base + __popcll(mL & lt_lane)] = F[i] | (L[i] << 16);
-        }
+        if (moved[i]) v[x] = e[i];
+        /* counts are taken by every lane: ds_bpermute returns 0 for a source lane that is masked off */
+        lo_[i] = F[i] + 1;
+        hm_[i] = L[i] != 0 ? L[i] - 1 : 0;
+        const int wlo = lo_[i] >> 6, whi = hm_[i] >> 6;
+        plo[i] = __builtin_amdgcn_ds_bpermute(wlo << 2, pre);
+        phi[i] = __builtin_amdgcn_ds_bpermute(whi << 2, pre);
+        mlo[i] = m->maskA[wlo];
+        mhi[i] = m->maskB[whi];
       }
-      __syncthreads();
-      const int n_list = n_alive & 0xffff;
-      for (int j = wave; j < n_list; j += nwaves) {
-        const int ent = cuts[j];
-        heap_sort_on_wave(v, ent & 0xffff, ent >> 16, m, 0);
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int x = i * nt + tid;
+        const int c = i * nwaves + wave;
+        const int lo = lo_[i], hm = hm_[i];
+        const int pc = __builtin_amdgcn_readlane(pre, c & 63);
+        const int a = (pc & 0xffff) + __popcll(mAi[i] & lt_lane) - (plo[i] & 0xffff) - __popcll(mlo[i] & ((1ull << (lo & 63)) - 1ull));
+        const int b = (int)((unsigned)phi[i] >> 16) + __popcll(mhi[i] & (~0ull >> (63 - (hm & 63)))) - (int)((unsigned)pc >> 16) -
+                      __popcll(mBi[i] & le_lane);
+        const bool swA = isA[i] & (b > a), swB = isB[i] & (a > b); /* never both: b > a excludes a > b */
+        const bool sw = swA | swB;
+        const int to = swA ? F[i] + a : hm - b;
+        slot[i] = sw ? to : -1;
+        if (sw) xbuf[to] = e[i];
+        const bool cand = (isA[i] & !swA) | swB;
+        /* The candidates of a sub-range are exactly its positions from the cut on (right of the cut every position ends with a key
+         * that is not before the pivot: an A-stop that stayed or a B-stop that received one; left of it there is none), so the cut is
+         * the one candidate whose left neighbour is not one -- the neighbour of a sub-range's first inner position is its pivot
+         * slot, never a candidate.  Lane 0 does not see its neighbour and reports too: the slot takes the minimum. */
+        const int prev = __builtin_amdgcn_update_dpp(0, cand ? 1 : 0, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        const bool report = cand & (prev == 0);
+        if (report) atomicMin(&cuts[F[i] >> 4], x);
       }
-      __syncthreads();
-      break;
     }
+    RS_SUBSTAMP(2);
+    __syncthreads();
+    RS_SUBSTAMP(3);
+    /* S: receive the swapped element, then move to the child sub-range; sub-ranges of at most 16 retire */
+    int alive = 0; /* wave-uniform: sub-ranges of the next level that start in my chunks (+ 65536 per one longer than 64) */
+    {
+      int cut_[EPT];
+      uint32_t rx[EPT];
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        cut_[i] = cuts[F[i] >> 4];
+        /* an A-stop's slot f+a pairs with B-stop slot l-1-a and vice versa */
+        rx[i] = xbuf[slot[i] >= 0 ? F[i] + L[i] - 1 - slot[i] : 0];
+      }
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int x = i * nt + tid;
+        const bool live = L[i] != 0, got = slot[i] >= 0;
+        e[i] = got ? rx[i] : e[i];
+        if (got) v[x] = e[i];
+        const bool left = x < cut_[i];
+        const int nF = left ? F[i] : cut_[i], nL = left ? cut_[i] : L[i];
+        F[i] = live ? nF : F[i];
+        L[i] = (live & (nL - nF > 16)) ? nL : 0;
+        const int len = x == F[i] ? L[i] - F[i] : 0; /* > 0 on the first position of a live sub-range only (a retired one has L = 0) */
+        alive += __popcll(__builtin_amdgcn_ballot_w64(len > 0)) + (__popcll(__builtin_amdgcn_ballot_w64(len > 64)) << 16);
+      }
+    }
+    if (alive != 0 && lane == 0) atomicAdd(&m->n_level[level + 1], alive);
+#else /* RS_SORT_BRANCHY: rounds 2-5 */
     /* F: pivot of my sub-range (median of 3, std::__move_median_to_first), stop ballots */
     unsigned long long mAi[EPT], mBi[EPT];
     bool isA[EPT], isB[EPT], moved[EPT];
@@ -530,12 +582,111 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       alive += __popcll(__ballot(leader)) + (__popcll(__ballot(leader && L[i] - F[i] > 64)) << 16);
     }
     if (alive != 0 && lane == 0) atomicAdd(&m->n_level[level + 1], alive);
+#endif /* RS_SORT_BRANCHY */
     RS_SUBSTAMP(4);
     __syncthreads();
     RS_SUBSTAMP(5);
 #ifdef RS_STAMPS
     if (tid == 0) sub[7] += 1;
 #endif
+  }
+  if (n_alive == 0) return; /* every sub-range is at most 16 long */
+  if (depth != 0) {
+    /* few sub-ranges left, none longer than 64: their first positions publish them, every wave takes its share and
+     * finishes them alone (finish_subranges_on_wave) */
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int x = i * nt + tid;
+      const bool leader = L[i] != 0 && x == F[i];
+      const unsigned long long mL = __ballot(leader);
+      if (mL != 0ull) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&m->pad[0], __popcll(mL));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (leader) cuts[base + __popcll(mL & lt_lane)] = F[i] | (L[i] << 16);
+      }
+    }
+    __syncthreads();
+    /* (same-box A/B, 512 cells: the zigzag below 33.17 against 32.99 M TTIs/s at 500 records, one position per lane; at 1 280
+     * records -- up to 32 entries to rank -- 13.30 against 13.49: list order there) */
+    constexpr bool kZigzag = EPT == 1;
+    if constexpr (!kZigzag) {
+    /* my share: entries wave, wave + nwaves, ... (lane t fetches the t-th of them), packed side by side while they fit */
+    int n_mine = 0; /* entries j = wave + t * nwaves below n_alive (no division: nwaves is a run-time value) */
+#pragma unroll
+    for (int t = 0; t < kFinishMax; ++t) n_mine += wave + t * nwaves < n_alive ? 1 : 0;
+    const int my_ent = lane < n_mine ? cuts[wave + lane * nwaves] : 0;
+    for (int t = 0; t < n_mine;) {
+      int fb = 0, lb = 0, l0 = 0, used = 0;
+      do {
+        const int ent = __builtin_amdgcn_readlane(my_ent, t);
+        const int f = ent & 0xffff, l = ent >> 16;
+        if (used + (l - f) > 64) break;
+        if (lane >= used && lane < used + (l - f)) { fb = f; lb = used; l0 = l; }
+        used += l - f;
+        ++t;
+      } while (t < n_mine);
+      finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth, m);
+    }
+    } else {
+    /* Every wave reads the whole list (at most kFinishMax * nwaves <= 32 entries, lane j = entry j), ranks the entries
+     * by length and takes them in a zigzag over the waves (rank 0..nwaves-1 -> wave 0..nwaves-1, the next nwaves backwards, ...):
+     * a wave with two entries gets a long and a short one, which usually fit its 64 lanes together -- entries that do not fit
+     * are finished one after the other, and with the entries dealt out in list order one wave of the eight did that in about
+     * half of the sorts (two of ~10 sub-ranges of 20-60 elements each on one wave).  Any assignment is correct: the
+     * sub-ranges are disjoint. */
+    const int ent_l = lane < n_alive ? cuts[lane] : 0;
+    const int len_l = lane < n_alive ? (ent_l >> 16) - (ent_l & 0xffff) : -1;
+    int rank = 0;
+    for (int j = 0; j < n_alive; ++j) {
+      const int lj = __builtin_amdgcn_readlane(len_l, j);
+      rank += (lj > len_l || (lj == len_l && j < lane)) ? 1 : 0;
+    }
+    int blk = 0, posn = rank; /* rank = blk * nwaves + posn without a division (nwaves is a run-time value) */
+#pragma unroll
+    for (int q = 1; q < kFinishMax; ++q)
+      if (rank >= q * nwaves) { blk = q; posn = rank - q * nwaves; }
+    const int to_wave = (blk & 1) ? nwaves - 1 - posn : posn;
+    unsigned long long mine = __ballot(lane < n_alive && to_wave == wave);
+    while (mine != 0ull) {
+      int fb = 0, lb = 0, l0 = 0, used = 0;
+      unsigned long long rest = mine;
+      while (rest != 0ull) { /* pack what fits side by side (in list order; whatever does not fit waits for the next call) */
+        const int j = __ffsll((long long)rest) - 1;
+        rest &= rest - 1ull;
+        const int ent = __builtin_amdgcn_readlane(ent_l, j);
+        const int f = ent & 0xffff, l = ent >> 16;
+        if (used + (l - f) > 64) continue;
+        if (lane >= used && lane < used + (l - f)) { fb = f; lb = used; l0 = l; }
+        used += l - f;
+        mine &= ~(1ull << j);
+      }
+      finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth, m);
+    }
+    }
+    __syncthreads();
+  } else {
+    /* std::__partial_sort fallback for every sub-range still longer than 16: their first positions publish them (the list of
+     * the hand-off above; `v` is current, every level writes what it moves), the waves take them in turn (heap_sort_on_wave) */
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int x = i * nt + tid;
+      const bool leader = L[i] != 0 && x == F[i];
+      const unsigned long long mL = __ballot(leader);
+      if (mL != 0ull) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&m->pad[0], __popcll(mL));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (leader) cuts[base + __popcll(mL & lt_lane)] = F[i] | (L[i] << 16);
+      }
+    }
+    __syncthreads();
+    const int n_list = n_alive & 0xffff;
+    for (int j = wave; j < n_list; j += nwaves) {
+      const int ent = cuts[j];
+      heap_sort_on_wave(v, ent & 0xffff, ent >> 16, m, 0);
+    }
+    __syncthreads();
   }
 }
 
@@ -625,10 +776,10 @@ __device__ __forceinline__ int xor_lanes_sum(int x) { /* x summed over lanes l, 
   return x;
 }
 
-template <int CPW>
+template <int CPW, int NT = 0>
 __device__ __forceinline__ void counting_sort_desc_owned_v2(const uint32_t* v, uint32_t* out, int N, Misc* m) {
   static_assert(CPW >= 1 && CPW <= 4, "at most four chunks per wave");
-  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
+  const int lane = lane_id(), wave = wave_id(), nwaves = (NT > 0 ? NT : (int)blockDim.x) >> 6;
   const int n_chunks = (N + 63) >> 6;
   const unsigned long long gt_lane = lane == 63 ? 0ull : (~0ull << (lane + 1));
   uint32_t* const hist32 = (uint32_t*)m->hist;
@@ -702,18 +853,18 @@ __device__ __forceinline__ void counting_sort_desc_owned_v2(const uint32_t* v, u
   __syncthreads();
 }
 
-template <int CPW>
+template <int CPW, int NT = 0>
 __device__ __forceinline__ void counting_sort_desc_owned(const uint32_t* v, uint32_t* out, int N, Misc* m) {
 #ifndef RS_COUNTING_SORT_V1
 #ifndef RS_COUNTING_SORT_V2_MIN_CPW
 #define RS_COUNTING_SORT_V2_MIN_CPW 2
 #endif
   if constexpr (CPW >= RS_COUNTING_SORT_V2_MIN_CPW) {
-    counting_sort_desc_owned_v2<CPW>(v, out, N, m);
+    counting_sort_desc_owned_v2<CPW, NT>(v, out, N, m);
     return;
   }
 #endif
-  const int lane = lane_id(), wave = wave_id(), nwaves = blockDim.x >> 6;
+  const int lane = lane_id(), wave = wave_id(), nwaves = (NT > 0 ? NT : (int)blockDim.x) >> 6;
   const int n_chunks = (N + 63) >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t e[CPW];

@@ -165,7 +165,7 @@ __device__ __forceinline__ void introsort_task_levels(uint32_t* v, uint32_t* xbu
           used += l - f;
           ++t;
         } while (t < n_mine);
-        finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth);
+        finish_subranges_on_wave(v, xbuf, fb, lb, l0, depth, m);
       }
       __syncthreads();
       break;
