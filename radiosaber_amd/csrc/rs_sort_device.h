@@ -228,6 +228,82 @@ __device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
  * when it runs out).  Used for the last, sparsely populated levels: at 500 records they hold 9 / 4 / 2 / 1 sub-ranges of
  * 20-30 elements on average.
  */
+#ifndef RS_FINISH_V1
+/* Round 6: the level step as straight-line code -- the four pivot candidates in ONE batch of register reads (the fourth used to
+ * follow the median: a second trip), the median as five selects, the stop ballots as one v_cmp each (keys as floats, NaN outside a
+ * piece), the two stop counts from two per-lane 64-bit masks built by one shift each (pieces end at lane 64 at most: ~0 >> (64 - pl)
+ * needs no special case), 32-bit counts, and the cut as the first candidate at or above the piece's first inner lane (a piece's
+ * candidates are exactly its lanes from the cut on, so no upper bound is needed).  ~95 instructions per level against ~150
+ * (profiles/r06_sort_staged.md); -DRS_FINISH_V1 keeps the form of rounds 3-5. */
+__device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* xbuf, int fb, int lb, int l0, int depth, Misc* m) {
+  const int lane = lane_id();
+  const bool mine = l0 != 0;
+  const int x = fb + lane - lb, shift = lb - fb; /* lane = position + shift */
+  const unsigned long long lt_lane = (1ull << lane) - 1ull, gt_lane = lane == 63 ? 0ull : (~0ull << (lane + 1));
+  uint32_t e = mine ? v[x] : 0u;
+  int F = fb, L = l0; /* my piece; L == 0: retired */
+  while (__builtin_amdgcn_ballot_w64(L != 0) != 0ull) {
+    const bool active = L != 0;
+    if (depth == 0) { /* std::__partial_sort fallback: one piece after the other, each on every lane (heap_sort_on_wave) */
+      if (mine) v[x] = e;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      unsigned long long lead = __builtin_amdgcn_ballot_w64(active && x == F);
+      while (lead != 0ull) {
+        const int j = __ffsll((long long)lead) - 1;
+        lead &= lead - 1ull;
+        heap_sort_on_wave(v, __builtin_amdgcn_readlane(F, j), __builtin_amdgcn_readlane(L, j), m, 1);
+      }
+      return;
+    }
+    /* piece bounds in lane space; every lane takes part in the four register reads (a masked-off source lane would
+     * read as 0) */
+    const int pf = active ? F + shift : 0, pl = active ? L + shift : 2;
+    const int ja = pf + 1, jb = pf + (int)((unsigned)(pl - pf) >> 1), jc = pl - 1;
+    uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_bpermute(pf << 2, (int)e);
+    uint32_t sa = (uint32_t)__builtin_amdgcn_ds_bpermute(ja << 2, (int)e);
+    uint32_t sb = (uint32_t)__builtin_amdgcn_ds_bpermute(jb << 2, (int)e);
+    uint32_t sc = (uint32_t)__builtin_amdgcn_ds_bpermute(jc << 2, (int)e);
+    asm volatile("" : "+v"(s0), "+v"(sa), "+v"(sb), "+v"(sc)); /* all four in one batch */
+    const bool ab = (sa >> 16) > (sb >> 16), bc = (sb >> 16) > (sc >> 16), ac = (sa >> 16) > (sc >> 16);
+    const uint32_t t1 = ac ? sc : sa, t2 = bc ? sc : sb;
+    const int q1 = ac ? jc : ja, q2 = bc ? jc : jb;
+    const uint32_t r1 = bc ? sb : t1, r2 = ac ? sa : t2;
+    const int u1 = bc ? jb : q1, u2 = ac ? ja : q2;
+    const uint32_t sp = ab ? r1 : r2;
+    const int pick = ab ? u1 : u2;
+    const bool at_f = active & (lane == pf), at_pick = active & (lane == pick);
+    e = at_f ? sp : at_pick ? s0 : e;
+    const bool in = active & (lane > pf);
+    const float kf = in ? (float)(e >> 16) : __builtin_nanf(""), pkf = (float)(sp >> 16);
+    const bool isA = kf <= pkf, isB = kf >= pkf;
+    const unsigned long long mA = __builtin_amdgcn_ballot_w64(isA), mB = __builtin_amdgcn_ballot_w64(isB);
+    const unsigned long long ge_ja = ~0ull << ja, lt_pl = ~0ull >> (64 - pl); /* 1 <= ja <= 63, 2 <= pl <= 64 */
+    /* A-stops of my piece left of me, B-stops of my piece right of me */
+    const unsigned long long wa = mA & ge_ja & lt_lane, wb = mB & lt_pl & gt_lane;
+    const int a = __builtin_popcount((uint32_t)wa) + __builtin_popcount((uint32_t)(wa >> 32));
+    const int b = __builtin_popcount((uint32_t)wb) + __builtin_popcount((uint32_t)(wb >> 32));
+    const bool swA = isA & (b > a), swB = isB & (a > b);
+    const bool sw = swA | swB;
+    const int slot = swA ? F + a : L - 1 - b;
+    if (sw) xbuf[slot] = e;
+    /* candidates = A-stops that stay + B-stops that receive: the two comparisons as wave masks, combined on the scalar side */
+    const unsigned long long gBA = __builtin_amdgcn_ballot_w64(b > a), gAB = __builtin_amdgcn_ballot_w64(a > b);
+    const unsigned long long mC = ((mA & ~gBA) | (mB & gAB)) & ge_ja;
+    const uint32_t got = xbuf[sw ? F + L - 1 - slot : 0];
+    e = sw ? got : e;
+    /* the first candidate at or above my piece's first inner lane is my piece's cut */
+    const int cut_lane = __builtin_ctzll(mC | 0x8000000000000000ull);
+    const int cut = cut_lane - shift;
+    const bool left = x < cut;
+    const int nF = left ? F : cut, nL = left ? cut : L;
+    F = active ? nF : F;
+    L = (active & (nL - nF > 16)) ? nL : 0;
+    --depth;
+  }
+  if (mine) v[x] = e;
+}
+#else
 __device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* xbuf, int fb, int lb, int l0, int depth, Misc* m) {
   const int lane = lane_id();
   const bool mine = l0 != 0;
@@ -291,6 +367,8 @@ __device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* 
   }
   if (mine) v[x] = e;
 }
+
+#endif /* RS_FINISH_V1 */
 
 template <int EPT, int NT = 0> /* NT: the workgroup's size where it is a compile-time constant (shape-specialised builds), 0: blockDim.x */
 __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t* cuts, Misc* m,
