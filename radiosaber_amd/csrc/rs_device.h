@@ -124,6 +124,12 @@ constexpr int rs_nvs_scratch_bytes(int U, int R, int seg) {
  *   bearer kind u8[U][2] | user flags u8[U] | user slice u8[U] */
 #define RS_QSTATE_BYTES_PER_USER 156
 #define RS_LDS_LIMIT (160 * 1024)
+/* Register form of the sort's workgroup levels (rs_sort_device.h): one cut slot per 16 positions, and -- round 6 -- a 16-bit stop-rank
+ * entry per position.  Up to 1 024 positions the ranks live in RsMisc::hist (free between the metric scan and the counting sort: one,
+ * two positions per thread keep their LDS footprint -- four 500 x 25 cells per CU); longer arrays (the 64-RBG grid: 1 280) get their own
+ * room behind the cut slots. */
+constexpr int rs_sort_cuts_bytes(int N) { return rs_round_up(4 * (N / 16 + 2), 16); }
+constexpr int rs_sort_ranks_bytes(int N) { return ((N + 63) / 64) * 64 > 1024 ? 2 * 64 * ((N + 63) / 64) : 0; }
 constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int nvs_seg, int queue = 0) {
   RsCarve c{};
   c.Upad = rs_upad_of(U);
@@ -152,7 +158,7 @@ constexpr RsCarve rs_carve_with(int S, int U, int R, int sched, int threads, int
   c.off_items = off; off += rs_round_up((spec ? 4 : 2) * c.n_items, 16);
   /* level-synchronous introsort scratch: cut per sub-range (+ bounds/pivots when the state lives in LDS) */
   /* register form (ept <= 4): one cut slot per 16 positions; LDS form: bounds, pivots and cuts per position */
-  c.off_sortx = off; off += (sched == 9 || sched == 10) ? rs_round_up(c.ept <= 4 ? 4 * (R * S / 16 + 2) : 8 * R * S, 16)
+  c.off_sortx = off; off += (sched == 9 || sched == 10) ? rs_round_up(c.ept <= 4 ? rs_sort_cuts_bytes(R * S) + rs_sort_ranks_bytes(R * S) : 8 * R * S, 16)
                                                            : (sched == 11 ? rs_round_up(rs_nvs_scratch_bytes(U, R, nvs_seg), 16) : (sched == 101 ? RS_UMAP_SCRATCH_BYTES : 0));
   c.off_cqi = off; off += rs_round_up(c.Upad * R, 16);
   c.off_queue = off; off += (queue && (sched == 1 || sched == 7)) ? rs_round_up(18 * U, 16) : 0;

@@ -372,7 +372,7 @@ __device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* 
 
 template <int EPT, int NT = 0> /* NT: the workgroup's size where it is a compile-time constant (shape-specialised builds), 0: blockDim.x */
 __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t* cuts, Misc* m,
-                                     unsigned long long* sub, int seg_len = 0) {
+                                     unsigned long long* sub, int seg_len = 0, uint16_t* ranks = nullptr) {
   /* sub-ranges per wave at which the last levels go to single waves (same-box A/B, 512 cells: one position per lane -- 500 records --
    * 33.38 M TTIs/s with 2 against 33.18 with 4 and 32.70 with 1; three positions per lane -- 1 280 records -- 13.24 with 2 against 13.41
    * with 4; round 4, 1 280 records: 2 / 4 / 8 within 0.3 % of each other) */
@@ -444,8 +444,9 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
      * selects; only stores and the atomic stay under a lane mask.  profiles/r06_sort_staged.md.
      */
     /* F: pivot of my sub-range (median of 3, std::__move_median_to_first), stop ballots */
-    unsigned long long mAi[EPT], mBi[EPT];
+    int rk[EPT]; /* my stop ranks inside my chunk: A-stops below me | B-stops up to me << 8 */
     bool isA[EPT], isB[EPT], moved[EPT];
+    uint32_t* const tot = (uint32_t*)m->maskA; /* per chunk: A-stops | B-stops << 16 */
     {
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
@@ -464,7 +465,13 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
         const bool at_f = active & (x == F[i]), at_pick = active & (x == pick); /* pick > f: never both */
         e[i] = at_f ? sp : at_pick ? s0[i] : e[i];
         moved[i] = at_f | at_pick;
-        if (at_f) cuts[F[i] >> 4] = 0x7fffffff;
+        {
+          /* (the store's predicate is computed from a copy the compiler cannot see through: with `if (at_f)` it threaded the
+           * selects above over the store's branch and split the wave into "first position" and "others" for a dozen instructions) */
+          int fo = F[i];
+          asm volatile("" : "+v"(fo));
+          if (active & (x == fo)) cuts[fo >> 4] = 0x7fffffff;
+        }
         /* keys are 0..15: compared as floats, with NaN for a position outside (f, l), each stop ballot is ONE v_cmp (both
          * comparisons are false on NaN; an integer form needs the range test ANDed in and the mask rebuilt under EXEC) */
         const bool in = active & (x > F[i]);
@@ -472,12 +479,16 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
         const float pkf = (float)(sp >> 16);
         isA[i] = kf <= pkf;
         isB[i] = kf >= pkf;
-        mAi[i] = __builtin_amdgcn_ballot_w64(isA[i]);
-        mBi[i] = __builtin_amdgcn_ballot_w64(isB[i]);
-        if (lane == 0 && c < n_chunks) {
-          m->maskA[c] = mAi[i];
-          m->maskB[c] = mBi[i];
-        }
+        const unsigned long long mA = __builtin_amdgcn_ballot_w64(isA[i]), mB = __builtin_amdgcn_ballot_w64(isB[i]);
+        /* Round 6: what a position will be asked for is "how many stops of your chunk lie below (at or below) you": it writes
+         * that down -- A-stops below it in the low byte, B-stops up to and including it in the high byte -- and the chunk its
+         * two totals; R then needs ONE 16-bit read at its sub-range's first inner position and one at its last instead of two
+         * 64-bit masks, two shifted masks and eight mask / count instructions. */
+        const int rA = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
+        const int rB = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u)) + (isB[i] ? 1 : 0);
+        rk[i] = rA | (rB << 8);
+        if (c < n_chunks) ranks[x] = (uint16_t)rk[i];
+        if (lane == 0 && c < n_chunks) tot[c] = (uint32_t)__popcll(mA) | ((uint32_t)__popcll(mB) << 16);
       }
     }
     RS_SUBSTAMP(0);
@@ -486,36 +497,34 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     /* R: stop counts -> swap decision; swapped elements to the exchange buffer, cut candidates to the slot */
     int pre; /* lane c: stops in chunks < c, A-stops in the low half, B-stops in the high half */
     {
-      int cnt = 0;
-      if (lane < n_chunks) cnt = __popcll(m->maskA[lane]) | (__popcll(m->maskB[lane]) << 16);
+      const int cnt = lane < n_chunks ? (int)tot[lane] : 0;
       pre = n_chunks <= 8 ? wave_scan_excl8(cnt) : wave_scan_incl(cnt) - cnt; /* (512 records: the counts sit in lanes 0..7) */
     }
     int slot[EPT]; /* where my element went / where its replacement arrives; -1: not swapped */
     {
-      int plo[EPT], phi[EPT], lo_[EPT], hm_[EPT];
-      unsigned long long mlo[EPT], mhi[EPT];
+      int plo[EPT], phi[EPT], rlo[EPT], rhm[EPT], hm_[EPT];
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
         const int x = i * nt + tid;
         if (moved[i]) v[x] = e[i];
         /* counts are taken by every lane: ds_bpermute returns 0 for a source lane that is masked off */
-        lo_[i] = F[i] + 1;
+        const int lo = F[i] + 1;
         hm_[i] = L[i] != 0 ? L[i] - 1 : 0;
-        const int wlo = lo_[i] >> 6, whi = hm_[i] >> 6;
-        plo[i] = __builtin_amdgcn_ds_bpermute(wlo << 2, pre);
-        phi[i] = __builtin_amdgcn_ds_bpermute(whi << 2, pre);
-        mlo[i] = m->maskA[wlo];
-        mhi[i] = m->maskB[whi];
+        plo[i] = __builtin_amdgcn_ds_bpermute((lo >> 6) << 2, pre);
+        phi[i] = __builtin_amdgcn_ds_bpermute((hm_[i] >> 6) << 2, pre);
+        rlo[i] = ranks[lo];
+        rhm[i] = ranks[hm_[i]];
       }
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
         const int x = i * nt + tid;
         const int c = i * nwaves + wave;
-        const int lo = lo_[i], hm = hm_[i];
+        const int hm = hm_[i];
         const int pc = __builtin_amdgcn_readlane(pre, c & 63);
-        const int a = (pc & 0xffff) + __popcll(mAi[i] & lt_lane) - (plo[i] & 0xffff) - __popcll(mlo[i] & ((1ull << (lo & 63)) - 1ull));
-        const int b = (int)((unsigned)phi[i] >> 16) + __popcll(mhi[i] & (~0ull >> (63 - (hm & 63)))) - (int)((unsigned)pc >> 16) -
-                      __popcll(mBi[i] & le_lane);
+        /* A-stops of my sub-range left of me = (stops before me) - (stops before its first inner position); B-stops right of me =
+         * (stops up to its last position) - (stops up to me) */
+        const int a = ((pc & 0xffff) + (rk[i] & 0xff)) - ((plo[i] & 0xffff) + (rlo[i] & 0xff));
+        const int b = ((int)((unsigned)phi[i] >> 16) + (rhm[i] >> 8)) - ((int)((unsigned)pc >> 16) + (rk[i] >> 8));
         const bool swA = isA[i] & (b > a), swB = isB[i] & (a > b); /* never both: b > a excludes a > b */
         const bool sw = swA | swB;
         const int to = swA ? F[i] + a : hm - b;

@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(MB_NT) bench(const uint32_t* recs, int n_prob_
   __shared__ uint32_t s_elems[MB_N + 64];
   __shared__ uint32_t s_sorted[MB_N + 64];
   __shared__ int32_t s_cuts[MB_N / 16 + 8];
+  __shared__ uint16_t s_ranks[(MB_N + 63) / 64 * 64 + 64];
   __shared__ RsMisc misc;
   const int tid = threadIdx.x;
   unsigned long long t_loop = 0, t_count = 0;
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(MB_NT) bench(const uint32_t* recs, int n_prob_
       __syncthreads();
       unsigned long long t0 = __builtin_readcyclecounter();
       __builtin_amdgcn_s_setprio(1);
-      if (V == 0) introsort_levels_reg<kEpt>(s_elems, MB_N, s_sorted, s_cuts, &misc, nullptr);
+      if (V == 0) introsort_levels_reg<kEpt>(s_elems, MB_N, s_sorted, s_cuts, &misc, nullptr, 0, s_ranks);
 #ifdef MB_HYBRID
       else introsort_levels_hybrid<kEpt, MB_HYBRID>(s_elems, MB_N, s_sorted, s_cuts, &misc, sub);
 #else
