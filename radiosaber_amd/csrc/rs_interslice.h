@@ -178,16 +178,22 @@ __device__ __forceinline__ void rs_scan_decide_vector(const uint32_t* src, int p
     by_rbg[rbg] = 0ull;
     by_slice[sl] = 0ull;
   }
-  const unsigned long long live = __ballot(valid & (((free_rbg >> rbg) & 1) != 0) & (sl_left > 0));
+  /* (round 6: every wave mask below is the AND of ballots of plain comparisons -- a ballot of a combined predicate costs a
+   * v_cndmask + v_cmp on top -- and a lane's own bit of T is the predicate it was built from) */
+  const bool rbg_free = ((free_rbg >> rbg) & 1) != 0, under = sl_left > 0;
+  const unsigned long long live = __builtin_amdgcn_ballot_w64(valid) & __builtin_amdgcn_ballot_w64(rbg_free) & __builtin_amdgcn_ballot_w64(under);
   unsigned long long T = live;
+  bool mine = false; /* my bit of T */
   for (;;) {
-    const bool rbg_gone = (before_r & T) != 0ull;
-    const int used = __popcll(before_s & T);
-    const unsigned long long Tn = __ballot(!rbg_gone & (used < sl_left)) & live;
+    const uint32_t gone = (uint32_t)(before_r & T) | (uint32_t)((before_r & T) >> 32);
+    const int used = __builtin_popcount((uint32_t)(before_s & T)) + __builtin_popcount((uint32_t)((before_s & T) >> 32));
+    const bool keep_r = gone == 0u, keep_s = used < sl_left;
+    const unsigned long long Tn = __builtin_amdgcn_ballot_w64(keep_r) & __builtin_amdgcn_ballot_w64(keep_s) & live;
+    mine = keep_r & keep_s;
     if (Tn == T) break;
     T = Tn;
   }
-  if ((T >> lane) & 1ull) owner_of[rbg] = (unsigned char)sl;
+  if (mine & valid & rbg_free & under) owner_of[rbg] = (unsigned char)sl;
   free_rbg &= ~(set_t)__ballot((of_rbg & T) != 0ull);
   left -= __popcll(of_slice & T);
   n_taken += __popcll(T);
@@ -204,7 +210,6 @@ __device__ __forceinline__ int interslice_maximize_cell_vector(uint32_t* s_sorte
   const int N = R * S;
   /* RBG and slice sets as 32-bit scalars when they fit (64-bit shifts by a lane value are slow) */
   typedef typename RsMaskT<K32>::type set_t;
-  const unsigned long long lt = (1ull << lane) - 1ull;
   set_t free_rbg = R >= (int)(8 * sizeof(set_t)) ? ~(set_t)0 : (set_t)(((set_t)1 << R) - 1);
   int left = lane < S ? m->quota[lane] : 0; /* lane s: quota[s] - granted[s] */
   int n_taken = 0;
@@ -236,8 +241,10 @@ __device__ __forceinline__ int interslice_maximize_cell_vector(uint32_t* s_sorte
         for (int j = 0; j < 8; ++j) {
           const int x = b + j * 64 + lane;
           const int rbg = (e[j] >> 8) & 63, sl = e[j] & 63;
-          const unsigned long long mk = __ballot((x < n) & (((free_rbg >> rbg) & (open_sl >> sl) & 1) != 0));
-          if ((mk >> lane) & 1ull) s_sorted[kept + __popcll(mk & lt)] = e[j];
+          const bool inb = x < n, lv = ((free_rbg >> rbg) & (open_sl >> sl) & 1) != 0;
+          const unsigned long long mk = __builtin_amdgcn_ballot_w64(inb) & __builtin_amdgcn_ballot_w64(lv);
+          const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+          if (inb & lv) s_sorted[kept + below] = e[j];
           kept += __popcll(mk);
         }
       }

@@ -376,7 +376,13 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
   /* sub-ranges per wave at which the last levels go to single waves (same-box A/B, 512 cells: one position per lane -- 500 records --
    * 33.38 M TTIs/s with 2 against 33.18 with 4 and 32.70 with 1; three positions per lane -- 1 280 records -- 13.24 with 2 against 13.41
    * with 4; round 4, 1 280 records: 2 / 4 / 8 within 0.3 % of each other) */
-  constexpr int kFinishMax = EPT == 1 ? 2 : 4;
+#ifndef RS_FINISH_MAX_1
+#define RS_FINISH_MAX_1 2
+#endif
+#ifndef RS_FINISH_MAX_N
+#define RS_FINISH_MAX_N 4
+#endif
+  constexpr int kFinishMax = EPT == 1 ? RS_FINISH_MAX_1 : RS_FINISH_MAX_N;
   const int tid = threadIdx.x, nt = NT > 0 ? NT : (int)blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
 #ifdef RS_STAMPS
   unsigned long long sub_prev = __builtin_readcyclecounter();
@@ -725,9 +731,21 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     const int ent_l = lane < n_alive ? cuts[lane] : 0;
     const int len_l = lane < n_alive ? (ent_l >> 16) - (ent_l & 0xffff) : -1;
     int rank = 0;
-    for (int j = 0; j < n_alive; ++j) {
-      const int lj = __builtin_amdgcn_readlane(len_l, j);
-      rank += (lj > len_l || (lj == len_l && j < lane)) ? 1 : 0;
+    if constexpr (NT > 0 && kFinishMax * (NT / 64) <= 16) {
+      /* round 6: at most 16 entries = one DPP row: fifteen row rotations of a key that holds the length and, below it, the list
+       * position reversed (unique keys; an unused lane's is 0) -- two or three instructions per rotation instead of a ten-instruction
+       * scalar loop round per entry on every wave */
+      const int key = lane < n_alive ? (len_l << 4) | (15 - lane) : 0;
+#define RS_ROR_STEP(k) rank += __builtin_amdgcn_update_dpp(0, key, 0x120 + (k) /* row_ror:k */, 0xf, 0xf, false) > key ? 1 : 0
+      RS_ROR_STEP(1); RS_ROR_STEP(2); RS_ROR_STEP(3); RS_ROR_STEP(4); RS_ROR_STEP(5);
+      RS_ROR_STEP(6); RS_ROR_STEP(7); RS_ROR_STEP(8); RS_ROR_STEP(9); RS_ROR_STEP(10);
+      RS_ROR_STEP(11); RS_ROR_STEP(12); RS_ROR_STEP(13); RS_ROR_STEP(14); RS_ROR_STEP(15);
+#undef RS_ROR_STEP
+    } else {
+      for (int j = 0; j < n_alive; ++j) {
+        const int lj = __builtin_amdgcn_readlane(len_l, j);
+        rank += (lj > len_l || (lj == len_l && j < lane)) ? 1 : 0;
+      }
     }
     int blk = 0, posn = rank; /* rank = blk * nwaves + posn without a division (nwaves is a run-time value) */
 #pragma unroll
@@ -944,7 +962,7 @@ template <int CPW, int NT = 0>
 __device__ __forceinline__ void counting_sort_desc_owned(const uint32_t* v, uint32_t* out, int N, Misc* m) {
 #ifndef RS_COUNTING_SORT_V1
 #ifndef RS_COUNTING_SORT_V2_MIN_CPW
-#define RS_COUNTING_SORT_V2_MIN_CPW 2
+#define RS_COUNTING_SORT_V2_MIN_CPW 1 /* round 6: the ballot form wins at one chunk per wave too (42.4 against 42.0 M TTIs/s at the headline shape, same lease) */
 #endif
   if constexpr (CPW >= RS_COUNTING_SORT_V2_MIN_CPW) {
     counting_sort_desc_owned_v2<CPW, NT>(v, out, N, m);
