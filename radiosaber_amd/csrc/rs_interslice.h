@@ -182,7 +182,11 @@ __device__ __forceinline__ void rs_scan_decide_vector(const uint32_t* src, int p
    * v_cndmask + v_cmp on top -- and a lane's own bit of T is the predicate it was built from) */
   const bool rbg_free = ((free_rbg >> rbg) & 1) != 0, under = sl_left > 0;
   const unsigned long long live = __builtin_amdgcn_ballot_w64(valid) & __builtin_amdgcn_ballot_w64(rbg_free) & __builtin_amdgcn_ballot_w64(under);
-  unsigned long long T = live;
+  /* (the iteration converges to the scan's answer from ANY start -- position 0 is final after one round whatever T was, position 1
+   * after two, ... -- so it starts from the live records that are the first live one of their RBG in this vector, which is what
+   * two or three rounds from T = live arrive at first) */
+  const uint32_t dup0 = (uint32_t)(before_r & live) | (uint32_t)((before_r & live) >> 32);
+  unsigned long long T = live & __builtin_amdgcn_ballot_w64(dup0 == 0u);
   bool mine = false; /* my bit of T */
   for (;;) {
     const uint32_t gone = (uint32_t)(before_r & T) | (uint32_t)((before_r & T) >> 32);
