@@ -411,6 +411,16 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
   if (tid == 0) m->pad[0] = 0; /* entries in the list of sub-ranges handed to single waves */
   int depth = 2 * rs_sort::floor_log2(n_first > 1 ? n_first : 1);
   __syncthreads();
+  /* Round 6: a wave whose LAST position slot holds no array position at all (1 280 records on 512 threads: 20 chunks, the third slot
+   * of waves 4-7 is behind the array's end) skips that slot's instructions in every stage -- wave-uniform, fixed for the whole sort;
+   * the slots before it keep running side by side.  (Round 4's skip of every retired chunk lost 3.5 %: it put a branch around each
+   * of the three slots on the critical waves.)  -DRS_SORT_NO_LAST_SKIP: off. */
+#ifndef RS_SORT_NO_LAST_SKIP
+  const bool has_last = EPT == 1 || (EPT - 1) * nwaves + wave < n_chunks;
+#else
+  const bool has_last = true;
+#endif
+#define RS_HAS(i) (EPT == 1 || (i) < EPT - 1 || has_last)
   int n_alive = 0;
   for (int level = 0; level < 47; ++level, --depth) {
 #ifndef RS_SORT_BRANCHY
@@ -420,6 +430,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     int ibx[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
+      if (!RS_HAS(i)) continue;
       const bool active = L[i] != 0;
       const int f = active ? F[i] : 0, l = active ? L[i] : 2;
       ibx[i] = f + (int)((unsigned)(l - f) >> 1); /* l > f: the halving needs no sign fix */
@@ -432,7 +443,8 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     n_alive = m->n_level[level]; /* complete: the previous level ended with a barrier */
 #ifndef RS_SORT_BRANCHY
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) asm volatile("" : "+v"(s0[i]), "+v"(sa[i]), "+v"(sb[i]), "+v"(sc[i])); /* keep the reads in this batch */
+    for (int i = 0; i < EPT; ++i)
+      if (RS_HAS(i)) asm volatile("" : "+v"(s0[i]), "+v"(sa[i]), "+v"(sb[i]), "+v"(sc[i])); /* keep the reads in this batch */
 #endif
     /* one test per level; what happens at the two early ends is written behind the loop (round 6: with the ends inside the loop
      * the compiler carried a copy of every position's bounds to each of them, ~20 instructions per level)
@@ -456,6 +468,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     {
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
+        if (!RS_HAS(i)) { isA[i] = isB[i] = moved[i] = false; rk[i] = 0; continue; }
         const int x = i * nt + tid;
         const int c = i * nwaves + wave;
         const bool active = L[i] != 0;
@@ -511,6 +524,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       int plo[EPT], phi[EPT], rlo[EPT], rhm[EPT], hm_[EPT];
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
+        if (!RS_HAS(i)) continue;
         const int x = i * nt + tid;
         if (moved[i]) v[x] = e[i];
         /* counts are taken by every lane: ds_bpermute returns 0 for a source lane that is masked off */
@@ -523,6 +537,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       }
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
+        if (!RS_HAS(i)) { slot[i] = -1; continue; }
         const int x = i * nt + tid;
         const int c = i * nwaves + wave;
         const int hm = hm_[i];
@@ -556,12 +571,14 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       uint32_t rx[EPT];
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
+        if (!RS_HAS(i)) continue;
         cut_[i] = cuts[F[i] >> 4];
         /* an A-stop's slot f+a pairs with B-stop slot l-1-a and vice versa */
         rx[i] = xbuf[slot[i] >= 0 ? F[i] + L[i] - 1 - slot[i] : 0];
       }
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
+        if (!RS_HAS(i)) continue;
         const int x = i * nt + tid;
         const bool live = L[i] != 0, got = slot[i] >= 0;
         e[i] = got ? rx[i] : e[i];
