@@ -907,8 +907,10 @@ __device__ __forceinline__ void counting_sort_desc_owned_v2(const uint32_t* v, u
   uint32_t* const hist32 = (uint32_t*)m->hist;
   uint32_t e[CPW];
   int rank[CPW];
+  const bool has_last = CPW == 1 || (CPW - 1) * nwaves + wave < n_chunks; /* (round 6: a wave without a last chunk skips it, as in the levels) */
 #pragma unroll
   for (int j = 0; j < CPW; ++j) {
+    if (CPW > 1 && j == CPW - 1 && !has_last) { e[j] = 0u; rank[j] = 0; continue; }
     const int c = j * nwaves + wave, i = (c << 6) + lane;
     const bool valid = c < n_chunks && i < N;
     e[j] = valid ? v[i] : 0u;
@@ -967,6 +969,7 @@ __device__ __forceinline__ void counting_sort_desc_owned_v2(const uint32_t* v, u
   const int all = __builtin_amdgcn_readlane(inc, 15);
 #pragma unroll
   for (int j = 0; j < CPW; ++j) {
+    if (CPW > 1 && j == CPW - 1 && !has_last) continue;
     const int c = j * nwaves + wave, i = (c << 6) + lane;
     const int base_q = all - inc + below[j]; /* lane q < 16 */
     const int base = __builtin_amdgcn_ds_bpermute((int)(e[j] >> 16) << 2, base_q); /* every lane: no branch around it */
