@@ -216,7 +216,10 @@ __device__ __forceinline__ void rs_cell_body(const RsLaunch& p, unsigned char* l
    * phase to the point where the speculation no longer pays for its fix-up pass and its flags (31.1 M without, 30.8 M with the
    * averages alone prepared, 29.9 M with the scan): MaximizeCell speculates only where it keeps the serial scan.
    * (64 RBGs again in round 4, vector form with nothing speculated: 12.3 against 13.5 M -- profiles/r04_r64.md.) */
-  constexpr int kVecMaxR = 32;
+#ifndef RS_VEC_MAX_R
+#define RS_VEC_MAX_R 32
+#endif
+  constexpr int kVecMaxR = RS_VEC_MAX_R;
   constexpr bool kVecScan = SCHED == 9 && (!FIXED || RS_JIT_R <= kVecMaxR);
   const bool vec_scan = kVecScan && R <= kVecMaxR;
   /* Held winners (round 3): the winner of a (slice, RBG) item is NOT looked for again in a TTI in which it cannot
