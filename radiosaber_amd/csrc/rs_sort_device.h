@@ -183,13 +183,6 @@ __device__ void introsort_loop_levels(uint32_t* v, int N, uint16_t* posA, uint16
  * 64-position chunk per i).  Every lane of a sub-range reads the three median samples itself, so
  * the pivot is known without a publishing step; three workgroup barriers per level.
  */
-__device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
-  /* bits [lo, hi) of a 64-bit mask, 0 <= lo, hi <= 64 */
-  if (hi <= lo) return 0ull;
-  const unsigned long long upto_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
-  return upto_hi & (~0ull << lo);
-}
-
 #if defined(RS_STAMPS) && !defined(RS_STAMPS_HOLD) && !defined(RS_STAMPS_P5)
 #define RS_SUBSTAMP(i)                                            \
   do {                                                            \
@@ -216,7 +209,10 @@ __device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
  * and the returned cut is the leftmost position that is an unswapped A-stop or a swapped B-stop.
  * Swapped elements travel through `xbuf` (A-stop number a at f+a, B-stop number b at l-1-b: they cannot
  * meet, a + b <= len - 3); the cut is an LDS atomicMin per sub-range (slot f>>4: live sub-ranges are longer
- * than 16, so their slots differ).  Counts come from per-chunk ballots + one prefix scan per wave.
+ * than 16, so their slots differ).  Counts (round 6): every position writes down how many A-stops of its 64-position chunk lie
+ * below it and how many B-stops up to and including it (16 bits, from the two ballots), every chunk its two totals; after the
+ * barrier one prefix scan per wave over the totals and, per position, one rank read at each end of its sub-range give
+ * A(x) = P_A(x) - P_A(lo), B(x) = P_B(hi - 1) - P_B(x).
  */
 /*
  * One wave finishes sub-ranges of at most 64 elements on its own, several at a time when they fit side by side in its 64
@@ -228,13 +224,12 @@ __device__ __forceinline__ unsigned long long bit_range(int lo, int hi) {
  * when it runs out).  Used for the last, sparsely populated levels: at 500 records they hold 9 / 4 / 2 / 1 sub-ranges of
  * 20-30 elements on average.
  */
-#ifndef RS_FINISH_V1
 /* Round 6: the level step as straight-line code -- the four pivot candidates in ONE batch of register reads (the fourth used to
  * follow the median: a second trip), the median as five selects, the stop ballots as one v_cmp each (keys as floats, NaN outside a
  * piece), the two stop counts from two per-lane 64-bit masks built by one shift each (pieces end at lane 64 at most: ~0 >> (64 - pl)
  * needs no special case), 32-bit counts, and the cut as the first candidate at or above the piece's first inner lane (a piece's
  * candidates are exactly its lanes from the cut on, so no upper bound is needed).  ~95 instructions per level against ~150
- * (profiles/r06_sort_staged.md); -DRS_FINISH_V1 keeps the form of rounds 3-5. */
+ * (profiles/r06_sort_staged.md; the form of rounds 3-5 is in the history up to commit 5593943, behind -DRS_FINISH_V1). */
 __device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* xbuf, int fb, int lb, int l0, int depth, Misc* m) {
   const int lane = lane_id();
   const bool mine = l0 != 0;
@@ -303,72 +298,6 @@ __device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* 
   }
   if (mine) v[x] = e;
 }
-#else
-__device__ __forceinline__ void finish_subranges_on_wave(uint32_t* v, uint32_t* xbuf, int fb, int lb, int l0, int depth, Misc* m) {
-  const int lane = lane_id();
-  const bool mine = l0 != 0;
-  const int x = fb + lane - lb, shift = lb - fb; /* lane = position + shift */
-  const unsigned long long le_lane = ~0ull >> (63 - lane);
-  uint32_t e = mine ? v[x] : 0u;
-  int F = fb, L = l0; /* my piece; L == 0: retired */
-  while (__ballot(L != 0) != 0ull) {
-    const bool active = L != 0;
-    if (depth == 0) { /* std::__partial_sort fallback: one piece after the other, each on every lane (heap_sort_on_wave) */
-      if (mine) v[x] = e;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      unsigned long long lead = __ballot(active && x == F);
-      while (lead != 0ull) {
-        const int j = __ffsll((long long)lead) - 1;
-        lead &= lead - 1ull;
-        heap_sort_on_wave(v, __builtin_amdgcn_readlane(F, j), __builtin_amdgcn_readlane(L, j), m, 1);
-      }
-      return;
-    }
-    /* piece bounds in lane space; every lane takes part in the four register reads (a masked-off source lane would
-     * read as 0) */
-    const int pf = active ? F + shift : 0, pl = active ? L + shift : 2;
-    const int ja = pf + 1, jb = pf + (int)((unsigned)(pl - pf) >> 1), jc = pl - 1;
-    const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_bpermute(pf << 2, (int)e);
-    const uint32_t sa = (uint32_t)__builtin_amdgcn_ds_bpermute(ja << 2, (int)e);
-    const uint32_t sb = (uint32_t)__builtin_amdgcn_ds_bpermute(jb << 2, (int)e);
-    const uint32_t sc = (uint32_t)__builtin_amdgcn_ds_bpermute(jc << 2, (int)e);
-    int pick;
-    uint32_t sp;
-    if (rs_sort::before(sa, sb)) {
-      if (rs_sort::before(sb, sc)) { pick = jb; sp = sb; }
-      else if (rs_sort::before(sa, sc)) { pick = jc; sp = sc; }
-      else { pick = ja; sp = sa; }
-    } else if (rs_sort::before(sa, sc)) { pick = ja; sp = sa; }
-    else if (rs_sort::before(sb, sc)) { pick = jc; sp = sc; }
-    else { pick = jb; sp = sb; }
-    if (active) {
-      if (lane == pf) e = sp;
-      else if (lane == pick) e = s0;
-    }
-    const int pk = (int)(sp >> 16), k = (int)(e >> 16);
-    const bool in = active && lane > pf;
-    const bool isA = in && k <= pk, isB = in && k >= pk;
-    const unsigned long long mA = __ballot(isA), mB = __ballot(isB);
-    /* A-stops of my piece left of me, B-stops of my piece right of me */
-    const int a = __popcll(mA & bit_range(ja, lane));
-    const int b = __popcll(mB & bit_range(ja, pl) & ~le_lane);
-    const bool swA = isA & (b > a), swB = isB & (a > b);
-    const int slot = swA ? F + a : L - 1 - b;
-    if (swA | swB) xbuf[slot] = e;
-    const unsigned long long mC = __ballot((isA & !swA) | swB) & bit_range(ja, pl);
-    if (swA | swB) e = xbuf[F + L - 1 - slot];
-    if (active) {
-      const int cut = __ffsll((long long)mC) - 1 - shift;
-      if (x < cut) L = cut; else F = cut;
-      if (L - F <= 16) L = 0;
-    }
-    --depth;
-  }
-  if (mine) v[x] = e;
-}
-
-#endif /* RS_FINISH_V1 */
 
 template <int EPT, int NT = 0> /* NT: the workgroup's size where it is a compile-time constant (shape-specialised builds), 0: blockDim.x */
 __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_t* xbuf, int32_t* cuts, Misc* m,
@@ -423,7 +352,6 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
 #define RS_HAS(i) (EPT == 1 || (i) < EPT - 1 || has_last)
   int n_alive = 0;
   for (int level = 0; level < 47; ++level, --depth) {
-#ifndef RS_SORT_BRANCHY
     /* F, stage 1 (see below): the median-of-3 samples of every position's sub-range, asked for together with the level's count of
      * live sub-ranges -- one LDS round trip at the top of a level instead of two (the reads are harmless whatever the count says) */
     uint32_t s0[EPT], sa[EPT], sb[EPT], sc[EPT];
@@ -439,22 +367,18 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       sb[i] = v[ibx[i]];
       sc[i] = v[l - 1];
     }
-#endif
     n_alive = m->n_level[level]; /* complete: the previous level ended with a barrier */
-#ifndef RS_SORT_BRANCHY
 #pragma unroll
     for (int i = 0; i < EPT; ++i)
       if (RS_HAS(i)) asm volatile("" : "+v"(s0[i]), "+v"(sa[i]), "+v"(sb[i]), "+v"(sc[i])); /* keep the reads in this batch */
-#endif
     /* one test per level; what happens at the two early ends is written behind the loop (round 6: with the ends inside the loop
      * the compiler carried a copy of every position's bounds to each of them, ~20 instructions per level)
      * (a first level that fills every lane -- UpperBound's row of short vectors at one position per lane -- stays a workgroup level) */
     const bool hand_off = depth != 0 && n_alive <= kFinishMax * nwaves && (level > 0 || EPT > 1 || n_alive == 1);
     if (n_alive == 0 || hand_off || depth == 0) break;
-#ifndef RS_SORT_BRANCHY
     /*
-     * Round 6: the three phases in STAGES over the EPT positions of a lane, without a branch.  The form kept under
-     * -DRS_SORT_BRANCHY wrapped every position's work in `if (active)`: the compiler turned that into one block per position
+     * Round 6: the three phases in STAGES over the EPT positions of a lane, without a branch.  The form of rounds 2-5 (in the
+     * history up to commit 5593943, behind -DRS_SORT_BRANCHY) wrapped every position's work in `if (active)`: the compiler turned that into one block per position
      * with its own s_cbranch_execz and its own s_waitcnt, so the EPT independent chains of a lane ran one after the other --
      * three LDS round trips per phase at three positions per lane, every instruction waiting for the one before it (8.5 cycles
      * each against 5.3 for independent ones, profiles/r03_sort_experiments.md).  Here every stage first issues the LDS reads of
@@ -592,107 +516,6 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       }
     }
     if (alive != 0 && lane == 0) atomicAdd(&m->n_level[level + 1], alive);
-#else /* RS_SORT_BRANCHY: rounds 2-5 */
-    /* F: pivot of my sub-range (median of 3, std::__move_median_to_first), stop ballots */
-    unsigned long long mAi[EPT], mBi[EPT];
-    bool isA[EPT], isB[EPT], moved[EPT];
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int x = i * nt + tid;
-      const int c = i * nwaves + wave;
-      const bool active = L[i] != 0;
-      int pk = 0;
-      moved[i] = false;
-      if (active) {
-        const int f = F[i], l = L[i];
-        const int ia = f + 1, ib = f + (int)((unsigned)(l - f) >> 1), ic = l - 1; /* l > f: the halving needs no sign fix */
-        uint32_t s0 = v[f];
-        const uint32_t sa = v[ia], sb = v[ib], sc = v[ic];
-        asm volatile("" : "+v"(s0)); /* keep the four LDS reads in one batch (one latency, not two) */
-        int pick;
-        uint32_t sp;
-        if (rs_sort::before(sa, sb)) {
-          if (rs_sort::before(sb, sc)) { pick = ib; sp = sb; }
-          else if (rs_sort::before(sa, sc)) { pick = ic; sp = sc; }
-          else { pick = ia; sp = sa; }
-        } else if (rs_sort::before(sa, sc)) { pick = ia; sp = sa; }
-        else if (rs_sort::before(sb, sc)) { pick = ic; sp = sc; }
-        else { pick = ib; sp = sb; }
-        pk = (int)(sp >> 16);
-        if (x == f) { e[i] = sp; moved[i] = true; cuts[f >> 4] = 0x7fffffff; }
-        else if (x == pick) { e[i] = s0; moved[i] = true; }
-      }
-      /* keys are 0..15: compared as floats, with NaN for a position outside (f, l), each stop ballot is ONE v_cmp (both
-       * comparisons are false on NaN; an integer form needs the range test ANDed in and the mask rebuilt under EXEC) */
-      const bool in = active && x > F[i];
-      const float kf = in ? (float)(e[i] >> 16) : __builtin_nanf("");
-      const float pkf = (float)pk;
-      isA[i] = kf <= pkf;
-      isB[i] = kf >= pkf;
-      mAi[i] = __ballot(isA[i]);
-      mBi[i] = __ballot(isB[i]);
-      if (lane == 0 && c < n_chunks) {
-        m->maskA[c] = mAi[i];
-        m->maskB[c] = mBi[i];
-      }
-    }
-    RS_SUBSTAMP(0);
-    __syncthreads();
-    RS_SUBSTAMP(1);
-    /* R: stop counts -> swap decision; swapped elements to the exchange buffer, cut candidates to the slot */
-    int pre; /* lane c: stops in chunks < c, A-stops in the low half, B-stops in the high half */
-    {
-      int cnt = 0;
-      if (lane < n_chunks) cnt = __popcll(m->maskA[lane]) | (__popcll(m->maskB[lane]) << 16);
-      pre = n_chunks <= 8 ? wave_scan_excl8(cnt) : wave_scan_incl(cnt) - cnt; /* (512 records: the counts sit in lanes 0..7) */
-    }
-    int slot[EPT]; /* where my element went / where its replacement arrives; -1: not swapped */
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int x = i * nt + tid;
-      const int c = i * nwaves + wave;
-      if (moved[i]) v[x] = e[i];
-      /* counts are taken by every lane: ds_bpermute returns 0 for a source lane that is masked off */
-      const int lo = F[i] + 1, hm = L[i] != 0 ? L[i] - 1 : 0;
-      const int wlo = lo >> 6, whi = hm >> 6;
-      const int plo = __builtin_amdgcn_ds_bpermute(wlo << 2, pre) & 0xffff;
-      const int phi = (int)((unsigned)__builtin_amdgcn_ds_bpermute(whi << 2, pre) >> 16);
-      const unsigned long long mlo = m->maskA[wlo], mhi = m->maskB[whi];
-      const int pc = __builtin_amdgcn_readlane(pre, c & 63);
-      const int a = (pc & 0xffff) + __popcll(mAi[i] & lt_lane) - plo - __popcll(mlo & ((1ull << (lo & 63)) - 1ull));
-      const int b = phi + __popcll(mhi & (~0ull >> (63 - (hm & 63)))) - (int)((unsigned)pc >> 16) - __popcll(mBi[i] & le_lane);
-      const bool swA = isA[i] & (b > a), swB = isB[i] & (a > b); /* never both: b > a excludes a > b */
-      slot[i] = (swA | swB) ? (swA ? F[i] + a : hm - b) : -1;
-      if (swA | swB) xbuf[slot[i]] = e[i];
-      const bool cand = (isA[i] & !swA) | swB;
-      /* leftmost candidate of its sub-range inside this chunk reports */
-      const unsigned long long mC = __ballot(cand);
-      const int lo_in = lo - (c << 6);
-      if (cand && (mC & bit_range(lo_in > 0 ? lo_in : 0, lane)) == 0ull) atomicMin(&cuts[F[i] >> 4], x);
-    }
-    RS_SUBSTAMP(2);
-    __syncthreads();
-    RS_SUBSTAMP(3);
-    /* S: receive the swapped element, then move to the child sub-range; sub-ranges of at most 16 retire */
-    int alive = 0; /* wave-uniform: sub-ranges of the next level that start in my chunks (+ 65536 per one longer than 64) */
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int x = i * nt + tid;
-      if (L[i] != 0) {
-        const int cut = cuts[F[i] >> 4];
-        if (slot[i] >= 0) {
-          /* an A-stop's slot f+a pairs with B-stop slot l-1-a and vice versa */
-          e[i] = xbuf[F[i] + L[i] - 1 - slot[i]];
-          v[x] = e[i];
-        }
-        if (x < cut) L[i] = cut; else F[i] = cut;
-        if (L[i] - F[i] <= 16) L[i] = 0;
-      }
-      const bool leader = L[i] != 0 && x == F[i];
-      alive += __popcll(__ballot(leader)) + (__popcll(__ballot(leader && L[i] - F[i] > 64)) << 16);
-    }
-    if (alive != 0 && lane == 0) atomicAdd(&m->n_level[level + 1], alive);
-#endif /* RS_SORT_BRANCHY */
     RS_SUBSTAMP(4);
     __syncthreads();
     RS_SUBSTAMP(5);
