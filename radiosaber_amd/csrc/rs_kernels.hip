@@ -89,7 +89,9 @@ __device__ __forceinline__ double rs_div_1000(double x) {
   } while (0)
 #define RS_SPEC_NAP 2    /* s_sleep argument (x 64 cycles) while the scanning waves wait for the allocation */
 #define RS_SERIAL_PRIO 3 /* issue priority of the wave that runs the serial end of the TTI (inter-slice policy, link adaptation) */
+#ifndef RS_SPEC_PRIO
 #define RS_SPEC_PRIO 0   /* issue priority of the scanning waves during the serial phase */
+#endif
 #ifndef RS_P3_BLOCK
 #define RS_P3_BLOCK 32 /* users ranked per stage-1 block (multiple of 8, <= 32) */
 #endif

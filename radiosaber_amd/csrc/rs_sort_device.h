@@ -338,6 +338,7 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
   const int n_calls = seg_len == 0 ? 1 : idiv_small(N, seg_len);
   if (tid < 48) m->n_level[tid] = (tid == 0 && n_first > 16) ? n_calls + (n_first > 64 ? n_calls << 16 : 0) : 0;
   if (tid == 0) m->pad[0] = 0; /* entries in the list of sub-ranges handed to single waves */
+  for (int j = tid; j < 128; j += nt) ((uint32_t*)m->maskA)[j] = 0u; /* the two chunk-prefix tables of the levels */
   int depth = 2 * rs_sort::floor_log2(n_first > 1 ? n_first : 1);
   __syncthreads();
   /* Round 6: a wave whose LAST position slot holds no array position at all (1 280 records on 512 threads: 20 chunks, the third slot
@@ -388,7 +389,12 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
     /* F: pivot of my sub-range (median of 3, std::__move_median_to_first), stop ballots */
     int rk[EPT]; /* my stop ranks inside my chunk: A-stops below me | B-stops up to me << 8 */
     bool isA[EPT], isB[EPT], moved[EPT];
-    uint32_t* const tot = (uint32_t*)m->maskA; /* per chunk: A-stops | B-stops << 16 */
+    /* chunk prefixes (round 6, last step): pre[j] = stops in the chunks before j, A-stops | B-stops << 16.  Every wave ADDS its chunk's
+     * two totals to the entries of all later chunks -- one LDS atomic instruction, lanes = the later chunks -- so that R reads its
+     * prefixes ready-made beside its two rank reads: ONE LDS round trip where it was a read of the totals, a prefix scan over the
+     * lanes and two lane gathers of it.  Two tables by level parity: wave 0 clears the next level's while this one is filled. */
+    uint32_t* const pre_w = (uint32_t*)m->maskA + ((level & 1) << 6);
+    if (wave == 0) ((uint32_t*)m->maskA)[(((level + 1) & 1) << 6) + lane] = 0u;
     {
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
@@ -431,31 +437,26 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
         const int rB = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u)) + (isB[i] ? 1 : 0);
         rk[i] = rA | (rB << 8);
         if (c < n_chunks) ranks[x] = (uint16_t)rk[i];
-        if (lane == 0 && c < n_chunks) tot[c] = (uint32_t)__popcll(mA) | ((uint32_t)__popcll(mB) << 16);
+        if (lane > c && lane < n_chunks) atomicAdd(&pre_w[lane], (uint32_t)__popcll(mA) | ((uint32_t)__popcll(mB) << 16));
       }
     }
     RS_SUBSTAMP(0);
     __syncthreads();
     RS_SUBSTAMP(1);
     /* R: stop counts -> swap decision; swapped elements to the exchange buffer, cut candidates to the slot */
-    int pre; /* lane c: stops in chunks < c, A-stops in the low half, B-stops in the high half */
-    {
-      const int cnt = lane < n_chunks ? (int)tot[lane] : 0;
-      pre = n_chunks <= 8 ? wave_scan_excl8(cnt) : wave_scan_incl(cnt) - cnt; /* (512 records: the counts sit in lanes 0..7) */
-    }
     int slot[EPT]; /* where my element went / where its replacement arrives; -1: not swapped */
     {
-      int plo[EPT], phi[EPT], rlo[EPT], rhm[EPT], hm_[EPT];
+      int plo[EPT], phi[EPT], pcs[EPT], rlo[EPT], rhm[EPT], hm_[EPT];
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
         if (!RS_HAS(i)) continue;
         const int x = i * nt + tid;
         if (moved[i]) v[x] = e[i];
-        /* counts are taken by every lane: ds_bpermute returns 0 for a source lane that is masked off */
         const int lo = F[i] + 1;
         hm_[i] = L[i] != 0 ? L[i] - 1 : 0;
-        plo[i] = __builtin_amdgcn_ds_bpermute((lo >> 6) << 2, pre);
-        phi[i] = __builtin_amdgcn_ds_bpermute((hm_[i] >> 6) << 2, pre);
+        plo[i] = (int)pre_w[lo >> 6];
+        phi[i] = (int)pre_w[hm_[i] >> 6];
+        pcs[i] = (int)pre_w[(i * nwaves + wave) & 63];
         rlo[i] = ranks[lo];
         rhm[i] = ranks[hm_[i]];
       }
@@ -463,9 +464,8 @@ __device__ __forceinline__ void introsort_levels_reg(uint32_t* v, int N, uint32_
       for (int i = 0; i < EPT; ++i) {
         if (!RS_HAS(i)) { slot[i] = -1; continue; }
         const int x = i * nt + tid;
-        const int c = i * nwaves + wave;
         const int hm = hm_[i];
-        const int pc = __builtin_amdgcn_readlane(pre, c & 63);
+        const int pc = pcs[i];
         /* A-stops of my sub-range left of me = (stops before me) - (stops before its first inner position); B-stops right of me =
          * (stops up to its last position) - (stops up to me) */
         const int a = ((pc & 0xffff) + (rk[i] & 0xff)) - ((plo[i] & 0xffff) + (rlo[i] & 0xff));
